@@ -1,0 +1,611 @@
+// Host side of the EFE rollout engine: context, weight packing, launch orchestration and the C ABI
+// declared in include/efe_engine.h.  The schedule follows SURVEY.md section 7 ("key scheduling
+// insight"): depth and the MC loops are sequential only through the tiny transition net, so one call
+// runs  (1) D small transition launches,  (2) ONE batched decoder pass over rows x D x 3S evaluations,
+// (3) ONE batched encoder pass over rows x D x S,  (4) a per-row term combine.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/efe_engine.h"
+#include "kernels.h"
+
+using namespace efe;
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { return ctx->fail(std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
+
+namespace {
+
+constexpr int S_DIM = 10, PI_DIM = 4;
+constexpr int64_t MAC_TRANS = 541696, MAC_DEC = 43256320, MAC_ENC = 3868960, MAC_HABIT = 18176;
+
+struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
+
+struct Layer {
+    float* Wp = nullptr; float* bias = nullptr;
+    int cin = 0;      // padded K per tap
+    int cout = 0; int mtiles = 0; int ntaps = 1;
+};
+
+struct Arena {
+    std::vector<std::pair<char*, size_t>> blocks;
+    size_t cur = 0, off = 0, used_total = 0;
+    void reset() { cur = 0; off = 0; used_total = 0; }
+};
+
+}  // namespace
+
+struct efe_ctx {
+    int device = 0;
+    std::string err;
+    std::map<std::string, HostTensor> raw;
+    bool committed = false;
+    Layer top[3], mid[4], enc_conv[3], enc_fc[4], dec_fc[4], dec_ct[3];
+    float *enc_w1 = nullptr, *enc_b1 = nullptr, *dec_wf = nullptr;
+    float dec_bf = 0.f;
+    float* zeros = nullptr;
+    std::vector<void*> owned;
+    Arena arena;
+    int64_t dec_chunk = 1024, enc_chunk = 4096;
+    int64_t last_macs = 0;
+
+    int fail(const std::string& m) { err = m; return 1; }
+
+    // bump allocator over a list of device blocks; grows (synchronously) on first use at a new size
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        while (true) {
+            if (arena.cur < arena.blocks.size()) {
+                auto& b = arena.blocks[arena.cur];
+                if (arena.off + bytes <= b.second) { void* p = b.first + arena.off; arena.off += bytes; arena.used_total += bytes; return p; }
+                arena.cur++; arena.off = 0;
+                continue;
+            }
+            size_t sz = std::max(bytes, (size_t)256 << 20);
+            char* p = nullptr;
+            if (hipMalloc((void**)&p, sz) != hipSuccess) { err = "arena hipMalloc failed"; return nullptr; }
+            arena.blocks.push_back({p, sz});
+        }
+    }
+    template <class T> T* allocT(size_t n) { return reinterpret_cast<T*>(alloc(n * sizeof(T))); }
+};
+
+namespace {
+
+// ---- weight packing into the MFMA fragment-major layout [tap][mtile][kc][lane][4] -------------------
+template <class Get>
+int upload_packed(efe_ctx* ctx, Layer& L, int ntaps, int cout, int cin, Get get, const float* bias_src, const int* bias_perm) {
+    L.ntaps = ntaps; L.cout = cout; L.mtiles = (cout + 31) / 32; L.cin = (cin + 7) / 8 * 8;
+    const int KC = L.cin / 8;
+    std::vector<float> p((size_t)ntaps * L.mtiles * KC * 256);
+    size_t idx = 0;
+    for (int t = 0; t < ntaps; ++t)
+        for (int mt = 0; mt < L.mtiles; ++mt)
+            for (int kc = 0; kc < KC; ++kc)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s) {
+                        const int co = mt * 32 + (lane & 31), ci = kc * 8 + 4 * (lane >> 5) + s;
+                        p[idx++] = (co < cout && ci < cin) ? get(t, co, ci) : 0.f;
+                    }
+    std::vector<float> b((size_t)L.mtiles * 32, 0.f);
+    for (int co = 0; co < cout; ++co) b[co] = bias_src[bias_perm ? bias_perm[co] : co];
+    HIPCHK(hipMalloc((void**)&L.Wp, p.size() * 4)); ctx->owned.push_back(L.Wp);
+    HIPCHK(hipMalloc((void**)&L.bias, b.size() * 4)); ctx->owned.push_back(L.bias);
+    HIPCHK(hipMemcpy(L.Wp, p.data(), p.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(L.bias, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+const HostTensor* need(efe_ctx* ctx, const std::string& key, std::initializer_list<int64_t> shape) {
+    auto it = ctx->raw.find(key);
+    if (it == ctx->raw.end()) { ctx->err = "missing weight " + key; return nullptr; }
+    if (it->second.shape != std::vector<int64_t>(shape)) { ctx->err = "bad shape for " + key; return nullptr; }
+    return &it->second;
+}
+
+int pack_linear(efe_ctx* ctx, Layer& L, const std::string& key, int out, int in, const int* row_perm, const int* col_perm) {
+    const HostTensor* w = need(ctx, key + ".weight", {out, in});
+    const HostTensor* b = need(ctx, key + ".bias", {out});
+    if (!w || !b) return 1;
+    const float* W = w->data.data();
+    return upload_packed(ctx, L, 1, out, in,
+        [&](int, int co, int ci) { return W[(size_t)(row_perm ? row_perm[co] : co) * in + (col_perm ? col_perm[ci] : ci)]; },
+        b->data.data(), row_perm);
+}
+
+// ---- launch helpers ----------------------------------------------------------------------------------
+struct NoiseCfg {
+    uint32_t k0 = 0, k1 = 0;
+    GroupMap gm{1, 1, {0, 0, 0}, 0, 0};
+    int rows_per_group = 1;
+    uint32_t row_offset = 0;
+};
+
+void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float* Y, int ldy, int M, bool relu, bool drop,
+        uint32_t tag, const NoiseCfg& nc, int m0, hipStream_t st) {
+    GemmArgs a{};
+    a.Wp = L.Wp; a.bias = L.bias; a.X = X; a.Y = Y; a.zeros = ctx->zeros;
+    a.n_pix = M; a.cin = L.cin; a.cout = L.cout; a.mtiles = L.mtiles; a.ldx = ldx; a.ldy = ldy; a.x_mod = x_mod;
+    a.relu = relu; a.dropout = drop; a.tag = tag; a.k0 = nc.k0; a.k1 = nc.k1; a.gm = nc.gm;
+    a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = m0;
+    launch_tapgemm(MODE_FC, L.mtiles == 1 ? 1 : 2, 2, a, st);
+}
+
+void conv(efe_ctx* ctx, int mode, int MT, int NT, const Layer& L, const float* X, float* Y, int n_pix, int geo_n, int geo_o, hipStream_t st) {
+    GemmArgs a{};
+    a.Wp = L.Wp; a.bias = L.bias; a.X = X; a.Y = Y; a.zeros = ctx->zeros;
+    a.n_pix = n_pix; a.cin = L.cin; a.cout = L.cout; a.mtiles = L.mtiles; a.geo_n = geo_n; a.geo_o = geo_o; a.relu = 1;
+    launch_tapgemm(mode, MT, NT, a, st);
+}
+
+// ModelMid.ps_net over M = groups*R rows; X is [R][16], every group reads the same rows (x_mod).
+int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*/, const NoiseCfg& nc, hipStream_t st) {
+    float* h1 = ctx->allocT<float>((size_t)M * 512);
+    float* h2 = ctx->allocT<float>((size_t)M * 512);
+    if (!h1 || !h2) return 1;
+    fc(ctx, ctx->mid[0], X, 16, x_mod, h1, 512, M, true, true, TAG_MID + 0, nc, 0, st);
+    fc(ctx, ctx->mid[1], h1, 512, 0, h2, 512, M, true, true, TAG_MID + 1, nc, 0, st);
+    fc(ctx, ctx->mid[2], h2, 512, 0, h1, 512, M, true, true, TAG_MID + 2, nc, 0, st);
+    fc(ctx, ctx->mid[3], h1, 512, 0, tr, 32, M, false, false, 0, nc, 0, st);
+    ctx->last_macs += (int64_t)M * MAC_TRANS;
+    return 0;
+}
+
+// ModelDown.po_net over N rows ([group][row] batch), chunked; fused final conv + sigmoid + reductions.
+int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const NoiseCfg& nc, int reward0, int store0,
+                float* val /*[N]*/, float* po_store, hipStream_t st) {
+    const int C = (int)std::min<int64_t>(ctx->dec_chunk, N);
+    float* hA = ctx->allocT<float>((size_t)C * 256);
+    float* hB = ctx->allocT<float>((size_t)C * 256);
+    float* x4 = ctx->allocT<float>((size_t)C * 16384);
+    float* y1 = ctx->allocT<float>((size_t)C * 16384);
+    float* y2 = ctx->allocT<float>((size_t)C * 65536);
+    float* y3 = ctx->allocT<float>((size_t)C * 131072);
+    if (!hA || !hB || !x4 || !y1 || !y2 || !y3) return 1;
+    for (int m0 = 0; m0 < N; m0 += C) {
+        const int c = std::min(C, N - m0);
+        fc(ctx, ctx->dec_fc[0], dec_in + (size_t)m0 * 16, 16, 0, hA, 256, c, true, true, TAG_DEC + 0, nc, m0, st);
+        fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, c, true, true, TAG_DEC + 1, nc, m0, st);
+        fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, c, true, true, TAG_DEC + 2, nc, m0, st);
+        fc(ctx, ctx->dec_fc[3], hA, 256, 0, x4, 16384, c, true, true, TAG_DEC + 3, nc, m0, st);
+        conv(ctx, MODE_CONVT_S1, 2, 2, ctx->dec_ct[0], x4, y1, c * 256, 16, 0, st);
+        conv(ctx, MODE_CONVT_S2, 2, 2, ctx->dec_ct[1], y1, y2, c * 256, 16, 0, st);
+        conv(ctx, MODE_CONVT_S2, 1, 4, ctx->dec_ct[2], y2, y3, c * 1024, 32, 0, st);
+        FinalArgs f{};
+        f.X = y3; f.wf = ctx->dec_wf; f.bias = ctx->dec_bf; f.rows = c; f.m0 = m0; f.rows_per_group = nc.rows_per_group;
+        f.gm = nc.gm; f.reward0 = reward0; f.store0 = store0; f.val = val; f.po = po_store;
+        launch_final(f, st);
+    }
+    ctx->last_macs += (int64_t)N * MAC_DEC;
+    return 0;
+}
+
+// ModelDown.qs_net over N rows; o is [N][4096]; out enc [N][32] (mean 0..9, logvar 10..19).
+int run_encoder(efe_ctx* ctx, const float* o, int N, const NoiseCfg& nc, float* enc, hipStream_t st) {
+    const int C = (int)std::min<int64_t>(ctx->enc_chunk, N);
+    float* c1 = ctx->allocT<float>((size_t)C * 961 * 32);
+    float* c2 = ctx->allocT<float>((size_t)C * 225 * 32);
+    float* c3 = ctx->allocT<float>((size_t)C * 49 * 64);
+    float* c4 = ctx->allocT<float>((size_t)C * 9 * 64);
+    float* hA = ctx->allocT<float>((size_t)C * 256);
+    float* hB = ctx->allocT<float>((size_t)C * 256);
+    if (!c1 || !c2 || !c3 || !c4 || !hA || !hB) return 1;
+    for (int m0 = 0; m0 < N; m0 += C) {
+        const int c = std::min(C, N - m0);
+        launch_enc_conv1(o + (size_t)m0 * 4096, ctx->enc_w1, ctx->enc_b1, c1, c, st);
+        conv(ctx, MODE_CONV_S2, 1, 2, ctx->enc_conv[0], c1, c2, c * 225, 31, 15, st);
+        conv(ctx, MODE_CONV_S2, 2, 2, ctx->enc_conv[1], c2, c3, c * 49, 15, 7, st);
+        conv(ctx, MODE_CONV_S2, 2, 2, ctx->enc_conv[2], c3, c4, c * 9, 7, 3, st);
+        fc(ctx, ctx->enc_fc[0], c4, 576, 0, hA, 256, c, true, true, TAG_ENC + 0, nc, m0, st);
+        fc(ctx, ctx->enc_fc[1], hA, 256, 0, hB, 256, c, true, true, TAG_ENC + 1, nc, m0, st);
+        fc(ctx, ctx->enc_fc[2], hB, 256, 0, hA, 256, c, true, true, TAG_ENC + 2, nc, m0, st);
+        fc(ctx, ctx->enc_fc[3], hA, 256, 0, enc + (size_t)m0 * 32, 32, c, false, false, 0, nc, m0, st);
+    }
+    ctx->last_macs += (int64_t)N * MAC_ENC;
+    return 0;
+}
+
+int run_habit(efe_ctx* ctx, const float* s16 /*[M][16]*/, int M, float* l32 /*[M][32]*/, hipStream_t st) {
+    float* h1 = ctx->allocT<float>((size_t)M * 128);
+    float* h2 = ctx->allocT<float>((size_t)M * 128);
+    if (!h1 || !h2) return 1;
+    NoiseCfg nc;
+    fc(ctx, ctx->top[0], s16, 16, 0, h1, 128, M, true, false, 0, nc, 0, st);
+    fc(ctx, ctx->top[1], h1, 128, 0, h2, 128, M, true, false, 0, nc, 0, st);
+    fc(ctx, ctx->top[2], h2, 128, 0, l32, 32, M, false, false, 0, nc, 0, st);
+    ctx->last_macs += (int64_t)M * MAC_HABIT;
+    return 0;
+}
+
+struct CoreIO {
+    const float* x0;          // [R][16] = [pi | s0 | 0 0]
+    int R, D, S, mean_mode, carry_mean;
+    uint32_t k0, k1, stage0, row_offset;
+    const float* eps;         // nullable, per stage [3S][R][10]
+    // trajectory mode (D == 1, S == 1): T1 is given
+    const float* given_ps1 = nullptr; const float* given_mean = nullptr; const float* given_logvar = nullptr;
+    float *G = nullptr, *terms = nullptr, *ps1 = nullptr, *ps1_mean = nullptr, *po1 = nullptr, *t2parts = nullptr;
+};
+
+// calculate_G for D chained stages (torchmodel.py:236-243, 270-300)
+int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
+    const int R = io.R, D = io.D, S = io.S;
+    float* tr_all = ctx->allocT<float>((size_t)D * 2 * S * R * 32);
+    float* dec_in = ctx->allocT<float>((size_t)D * 3 * S * R * 16);
+    float* xbuf = ctx->allocT<float>((size_t)2 * R * 16);
+    float* val = ctx->allocT<float>((size_t)D * 3 * S * R);
+    float* po_store = ctx->allocT<float>((size_t)D * S * R * 4096);
+    float* enc = ctx->allocT<float>((size_t)D * S * R * 32);
+    float* terms_tmp = io.terms ? nullptr : ctx->allocT<float>((size_t)3 * R);
+    if (!tr_all || !dec_in || !xbuf || !val || !po_store || !enc) return 1;
+
+    const float* x = io.x0;
+    for (int t = 0; t < D; ++t) {
+        float* tr = tr_all + (size_t)t * 2 * S * R * 32;
+        NoiseCfg nc; nc.k0 = io.k0; nc.k1 = io.k1; nc.rows_per_group = R; nc.row_offset = io.row_offset;
+        if (io.given_mean) {
+            // trajectory mode: group T1 is supplied, only the loop-2 transition runs
+            launch_fill_tr(io.given_mean, io.given_logvar, tr, R, st);
+            nc.gm = GroupMap{1, 1, {PASS_T2, 0, 0}, io.stage0 + (uint32_t)t, 0};
+            if (run_mid(ctx, x, R, R, tr + (size_t)R * 32, nc, st)) return 1;
+        } else {
+            nc.gm = GroupMap{2 * S, S, {PASS_T1, PASS_T2, 0}, io.stage0 + (uint32_t)t, 0};
+            if (run_mid(ctx, x, R, 2 * S * R, tr, nc, st)) return 1;
+        }
+        TransPostArgs p{};
+        p.tr = tr; p.x = x; p.eps_inj = io.eps ? io.eps + (size_t)t * 3 * S * R * 10 : nullptr;
+        p.given_ps1 = io.given_ps1;
+        p.dec_in = dec_in + (size_t)t * 3 * S * R * 16;
+        float* nx = xbuf + (size_t)(t & 1) * R * 16;
+        p.next_x = (t + 1 < D) ? nx : nullptr;
+        p.ps1_last = (t + 1 == D) ? io.ps1 : nullptr;
+        p.ps1_mean_last = (t + 1 == D) ? io.ps1_mean : nullptr;
+        p.S = S; p.R = R; p.mean_mode = io.mean_mode; p.carry_mean = io.carry_mean;
+        p.k0 = io.k0; p.k1 = io.k1; p.stage = io.stage0 + t; p.row_offset = io.row_offset;
+        launch_trans_post(p, st);
+        x = nx;
+    }
+    {   // one batched decoder pass over D x 3S groups
+        NoiseCfg nc; nc.k0 = io.k0; nc.k1 = io.k1; nc.rows_per_group = R; nc.row_offset = io.row_offset;
+        nc.gm = GroupMap{3 * S, S, {PASS_D1, PASS_D2A, PASS_D2B}, io.stage0, 0};
+        if (run_decoder(ctx, dec_in, D * 3 * S * R, nc, 1, 1, val, po_store, st)) return 1;
+    }
+    {   // one batched encoder pass over the D x S loop-1 images
+        NoiseCfg nc; nc.k0 = io.k0; nc.k1 = io.k1; nc.rows_per_group = R; nc.row_offset = io.row_offset;
+        nc.gm = GroupMap{S, S, {PASS_E1, 0, 0}, io.stage0, 0};
+        if (run_encoder(ctx, po_store, D * S * R, nc, enc, st)) return 1;
+    }
+    TermsArgs ta{};
+    ta.val = val; ta.tr = tr_all; ta.enc = enc; ta.D = D; ta.S = S; ta.R = R;
+    ta.G = io.G; ta.terms = io.terms ? io.terms : terms_tmp; ta.t2parts = io.t2parts;
+    launch_terms(ta, st);
+    if (io.po1) {
+        if (hipMemcpyAsync(io.po1, po_store + ((size_t)(D - 1) * S + (S - 1)) * R * 4096, (size_t)R * 4096 * 4,
+                           hipMemcpyDeviceToDevice, st) != hipSuccess) return ctx->fail("po1 copy failed");
+    }
+    return 0;
+}
+
+int check_ready(efe_ctx* ctx) {
+    if (!ctx) return 1;
+    if (!ctx->committed) return ctx->fail("weights not committed");
+    if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail("hipSetDevice failed");
+    ctx->arena.reset();
+    ctx->last_macs = 0;
+    return 0;
+}
+
+int finish(efe_ctx* ctx) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ctx->fail(std::string("kernel launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+int efe_abi_version(void) { return 1; }
+
+int efe_create(efe_ctx** out, int device) {
+    if (!out) return 1;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return 2;
+    if (hipSetDevice(device) != hipSuccess) return 3;
+    efe_ctx* ctx = new efe_ctx();
+    ctx->device = device;
+    if (hipMalloc((void**)&ctx->zeros, 8192) != hipSuccess || hipMemset(ctx->zeros, 0, 8192) != hipSuccess) { delete ctx; return 4; }
+    ctx->owned.push_back(ctx->zeros);
+    *out = ctx;
+    return 0;
+}
+
+void efe_destroy(efe_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : ctx->owned) (void)hipFree(p);
+    for (auto& b : ctx->arena.blocks) (void)hipFree(b.first);
+    delete ctx;
+}
+
+const char* efe_last_error(efe_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const int64_t* shape, int ndim) {
+    if (!ctx || !key || !data_host || !shape || ndim < 1 || ndim > 4) return 1;
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(data_host, data_host + n);
+    ctx->raw[key] = std::move(t);
+    ctx->committed = false;
+    return 0;
+}
+
+int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return 1;
+    if (!strcmp(name, "dec_chunk")) { if (value < 1) return ctx->fail("dec_chunk < 1"); ctx->dec_chunk = value; return 0; }
+    if (!strcmp(name, "enc_chunk")) { if (value < 1) return ctx->fail("enc_chunk < 1"); ctx->enc_chunk = value; return 0; }
+    return ctx->fail(std::string("unknown option ") + name);
+}
+
+int efe_commit_weights(efe_ctx* ctx) {
+    if (!ctx) return 1;
+    HIPCHK(hipSetDevice(ctx->device));
+    // habit net (torchmodel.py:19-25)
+    if (pack_linear(ctx, ctx->top[0], "top.qpi_net.0", 128, 10, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->top[1], "top.qpi_net.2", 128, 128, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->top[2], "top.qpi_net.4", 4, 128, nullptr, nullptr)) return 1;
+    // transition net (torchmodel.py:41-52)
+    if (pack_linear(ctx, ctx->mid[0], "mid.ps_net.0", 512, 14, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->mid[1], "mid.ps_net.3", 512, 512, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->mid[2], "mid.ps_net.6", 512, 512, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->mid[3], "mid.ps_net.9", 20, 512, nullptr, nullptr)) return 1;
+    // encoder (torchmodel.py:84-104).  conv1 (Cin = 1) runs on the VALU: w1[tap][co]
+    {
+        const HostTensor* w = need(ctx, "down.qs_net.0.weight", {32, 1, 3, 3});
+        const HostTensor* b = need(ctx, "down.qs_net.0.bias", {32});
+        if (!w || !b) return 1;
+        std::vector<float> w1(288);
+        for (int t = 0; t < 9; ++t) for (int co = 0; co < 32; ++co) w1[t * 32 + co] = w->data[co * 9 + t];
+        HIPCHK(hipMalloc((void**)&ctx->enc_w1, 288 * 4)); ctx->owned.push_back(ctx->enc_w1);
+        HIPCHK(hipMalloc((void**)&ctx->enc_b1, 32 * 4)); ctx->owned.push_back(ctx->enc_b1);
+        HIPCHK(hipMemcpy(ctx->enc_w1, w1.data(), 288 * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ctx->enc_b1, b->data.data(), 32 * 4, hipMemcpyHostToDevice));
+    }
+    const char* ck[3] = {"down.qs_net.2", "down.qs_net.4", "down.qs_net.6"};
+    const int cci[3] = {32, 32, 64}, cco[3] = {32, 64, 64};
+    for (int i = 0; i < 3; ++i) {
+        const HostTensor* w = need(ctx, std::string(ck[i]) + ".weight", {cco[i], cci[i], 3, 3});
+        const HostTensor* b = need(ctx, std::string(ck[i]) + ".bias", {cco[i]});
+        if (!w || !b) return 1;
+        const float* W = w->data.data(); const int Cin = cci[i];
+        if (upload_packed(ctx, ctx->enc_conv[i], 9, cco[i], Cin,
+                          [&](int t, int co, int ci) { return W[((size_t)co * Cin + ci) * 9 + t]; }, b->data.data(), nullptr)) return 1;
+    }
+    {   // Flatten is channel-major c*9 + p (torchmodel.py:93); our conv4 output is NHWC p*64 + c
+        std::vector<int> colp(576);
+        for (int p = 0; p < 9; ++p) for (int c = 0; c < 64; ++c) colp[p * 64 + c] = c * 9 + p;
+        if (pack_linear(ctx, ctx->enc_fc[0], "down.qs_net.9", 256, 576, nullptr, colp.data())) return 1;
+    }
+    if (pack_linear(ctx, ctx->enc_fc[1], "down.qs_net.12", 256, 256, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->enc_fc[2], "down.qs_net.15", 256, 256, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->enc_fc[3], "down.qs_net.18", 20, 256, nullptr, nullptr)) return 1;
+    // decoder (torchmodel.py:106-128)
+    if (pack_linear(ctx, ctx->dec_fc[0], "down.po_net.0", 256, 10, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->dec_fc[1], "down.po_net.3", 256, 256, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->dec_fc[2], "down.po_net.6", 256, 256, nullptr, nullptr)) return 1;
+    {   // Unflatten(1,(64,16,16)) is channel-major c*256 + p (torchmodel.py:119); we emit NHWC p*64 + c directly
+        std::vector<int> rowp(16384);
+        for (int p = 0; p < 256; ++p) for (int c = 0; c < 64; ++c) rowp[p * 64 + c] = c * 256 + p;
+        if (pack_linear(ctx, ctx->dec_fc[3], "down.po_net.9", 16384, 256, rowp.data(), nullptr)) return 1;
+    }
+    const char* tk[3] = {"down.po_net.13", "down.po_net.15", "down.po_net.17"};
+    const int tci[3] = {64, 64, 64}, tco[3] = {64, 64, 32};
+    for (int i = 0; i < 3; ++i) {   // ConvTranspose2d weights are [Cin][Cout][kh][kw]
+        const HostTensor* w = need(ctx, std::string(tk[i]) + ".weight", {tci[i], tco[i], 3, 3});
+        const HostTensor* b = need(ctx, std::string(tk[i]) + ".bias", {tco[i]});
+        if (!w || !b) return 1;
+        const float* W = w->data.data(); const int Cout = tco[i];
+        if (upload_packed(ctx, ctx->dec_ct[i], 9, Cout, tci[i],
+                          [&](int t, int co, int ci) { return W[((size_t)ci * Cout + co) * 9 + t]; }, b->data.data(), nullptr)) return 1;
+    }
+    {
+        const HostTensor* w = need(ctx, "down.po_net.19.weight", {32, 1, 3, 3});
+        const HostTensor* b = need(ctx, "down.po_net.19.bias", {1});
+        if (!w || !b) return 1;
+        std::vector<float> wf(288);
+        for (int t = 0; t < 9; ++t) for (int ci = 0; ci < 32; ++ci) wf[t * 32 + ci] = w->data[ci * 9 + t];
+        HIPCHK(hipMalloc((void**)&ctx->dec_wf, 288 * 4)); ctx->owned.push_back(ctx->dec_wf);
+        HIPCHK(hipMemcpy(ctx->dec_wf, wf.data(), 288 * 4, hipMemcpyHostToDevice));
+        ctx->dec_bf = b->data[0];
+    }
+    ctx->raw.clear();
+    ctx->committed = true;
+    return 0;
+}
+
+int64_t efe_last_call_macs(efe_ctx* ctx) { return ctx ? ctx->last_macs : 0; }
+
+// ---- network level -------------------------------------------------------------------------------------
+int efe_transition(efe_ctx* ctx, const float* pi, const float* s0, int M, const efe_noise* nz, const float* eps,
+                   float* ps1, float* mean, float* logvar, void* stream) {
+    if (check_ready(ctx)) return 1;
+    if (!pi || !s0 || !nz || M < 1) return ctx->fail("efe_transition: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* x = ctx->allocT<float>((size_t)M * 16);
+    float* tr = ctx->allocT<float>((size_t)M * 32);
+    if (!x || !tr) return 1;
+    launch_pack_x(pi, s0, x, M, PI_DIM, S_DIM, st);
+    NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;
+    nc.gm = GroupMap{1, 1, {nz->pass, 0, 0}, nz->stage, nz->sample};
+    if (run_mid(ctx, x, 0, M, tr, nc, st)) return 1;
+    launch_split_enc(tr, mean, logvar, M, st);
+    if (ps1) launch_root_post(tr, nullptr, eps, nullptr, ps1, M, 0, nc.k0, nc.k1, nz->pass, nz->sample, nz->stage, nz->row_offset, st);
+    return finish(ctx);
+}
+
+int efe_decoder(efe_ctx* ctx, const float* s, int M, const efe_noise* nz, float* po, void* stream) {
+    if (check_ready(ctx)) return 1;
+    if (!s || !nz || !po || M < 1) return ctx->fail("efe_decoder: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* x = ctx->allocT<float>((size_t)M * 16);
+    float* val = ctx->allocT<float>((size_t)M);
+    if (!x || !val) return 1;
+    launch_pad16(s, x, M, S_DIM, st);
+    NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;
+    nc.gm = GroupMap{1, 1, {nz->pass, 0, 0}, nz->stage, nz->sample};
+    if (run_decoder(ctx, x, M, nc, 0, 1, val, po, st)) return 1;
+    return finish(ctx);
+}
+
+int efe_encoder(efe_ctx* ctx, const float* o, int M, const efe_noise* nz, const float* eps, float* s, float* mean, float* logvar, void* stream) {
+    if (check_ready(ctx)) return 1;
+    if (!o || !nz || M < 1) return ctx->fail("efe_encoder: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* enc = ctx->allocT<float>((size_t)M * 32);
+    if (!enc) return 1;
+    NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;
+    nc.gm = GroupMap{1, 1, {nz->pass, 0, 0}, nz->stage, nz->sample};
+    if (run_encoder(ctx, o, M, nc, enc, st)) return 1;
+    launch_split_enc(enc, mean, logvar, M, st);
+    if (s) launch_root_post(enc, nullptr, eps, nullptr, s, M, 0, nc.k0, nc.k1, nz->pass, nz->sample, nz->stage, nz->row_offset, st);
+    return finish(ctx);
+}
+
+int efe_habit(efe_ctx* ctx, const float* s, int M, float* logits, float* q, float* logq, void* stream) {
+    if (check_ready(ctx)) return 1;
+    if (!s || M < 1) return ctx->fail("efe_habit: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* x = ctx->allocT<float>((size_t)M * 16);
+    float* l32 = ctx->allocT<float>((size_t)M * 32);
+    if (!x || !l32) return 1;
+    launch_pad16(s, x, M, S_DIM, st);
+    if (run_habit(ctx, x, M, l32, st)) return 1;
+    launch_softmax4(l32, logits, q, logq, M, PI_DIM, st);
+    return finish(ctx);
+}
+
+// ---- EFE level -----------------------------------------------------------------------------------------
+int efe_calculate_g(efe_ctx* ctx, const float* s0, const float* pi0, int M, int samples, int mean_mode, const efe_noise* nz,
+                    const float* eps, float* G, float* terms, float* ps1, float* ps1_mean, float* po1, float* t2parts, void* stream) {
+    if (check_ready(ctx)) return 1;
+    if (!s0 || !pi0 || !nz || !G || M < 1 || samples < 1 || samples > 65535) return ctx->fail("efe_calculate_g: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    float* x = ctx->allocT<float>((size_t)M * 16);
+    if (!x) return 1;
+    launch_pack_x(pi0, s0, x, M, PI_DIM, S_DIM, st);
+    CoreIO io{};
+    io.x0 = x; io.R = M; io.D = 1; io.S = mean_mode ? 1 : samples; io.mean_mode = mean_mode; io.carry_mean = 0;
+    io.k0 = (uint32_t)nz->seed; io.k1 = (uint32_t)(nz->seed >> 32); io.stage0 = nz->stage; io.row_offset = nz->row_offset;
+    io.eps = eps; io.G = G; io.terms = terms; io.ps1 = ps1; io.ps1_mean = ps1_mean; io.po1 = po1; io.t2parts = t2parts;
+    if (run_core(ctx, io, st)) return 1;
+    return finish(ctx);
+}
+
+int efe_rollout(efe_ctx* ctx, const float* o, const float* pi, int M, int steps, int samples, int calc_mean, int per_stage_mean,
+                const efe_noise* nz, const float* eps, float* sum_G, float* sum_terms, float* po1, void* stream) {
+    if (check_ready(ctx)) return 1;
+    if (!o || !pi || !nz || !sum_G || M < 1 || steps < 1 || samples < 1 || samples > 65535) return ctx->fail("efe_rollout: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t k0 = (uint32_t)nz->seed, k1 = (uint32_t)(nz->seed >> 32);
+    float* enc0 = ctx->allocT<float>((size_t)M * 32);
+    float* x = ctx->allocT<float>((size_t)M * 16);
+    if (!enc0 || !x) return 1;
+    {   // root encode + reparameterize (torchmodel.py:228-234)
+        NoiseCfg nc; nc.k0 = k0; nc.k1 = k1; nc.rows_per_group = M; nc.row_offset = nz->row_offset;
+        nc.gm = GroupMap{1, 1, {PASS_ROOT, 0, 0}, nz->stage, 0};
+        if (run_encoder(ctx, o, M, nc, enc0, st)) return 1;
+        launch_root_post(enc0, pi, eps, x, nullptr, M, calc_mean ? 1 : 0, k0, k1, PASS_ROOT, 0, nz->stage, nz->row_offset, st);
+    }
+    const int mean_mode = (per_stage_mean && calc_mean) ? 1 : 0;
+    CoreIO io{};
+    io.x0 = x; io.R = M; io.D = steps; io.S = mean_mode ? 1 : samples; io.mean_mode = mean_mode; io.carry_mean = calc_mean ? 1 : 0;
+    io.k0 = k0; io.k1 = k1; io.stage0 = nz->stage; io.row_offset = nz->row_offset;
+    io.eps = eps ? eps + (size_t)M * 10 : nullptr;
+    io.G = sum_G; io.terms = sum_terms; io.po1 = po1;
+    if (run_core(ctx, io, st)) return 1;
+    return finish(ctx);
+}
+
+static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, const float* mean_traj, const float* lv_traj,
+                           const float* pi0_traj, int T, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t row_offset,
+                           const float* eps, float* G, hipStream_t st) {
+    float* x = ctx->allocT<float>((size_t)T * 16);
+    if (!x) return 1;
+    launch_pack_x(pi0_traj, s0_traj, x, T, PI_DIM, S_DIM, st);
+    CoreIO io{};
+    io.x0 = x; io.R = T; io.D = 1; io.S = 1; io.mean_mode = 0; io.carry_mean = 0;
+    io.k0 = k0; io.k1 = k1; io.stage0 = stage; io.row_offset = row_offset; io.eps = eps;
+    io.given_ps1 = ps1_traj; io.given_mean = mean_traj; io.given_logvar = lv_traj;
+    io.G = G;
+    return run_core(ctx, io, st);
+}
+
+int efe_trajectory(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, const float* ps1_mean_traj, const float* ps1_logvar_traj,
+                   const float* pi0_traj, int T, const efe_noise* nz, const float* eps, float* G, void* stream) {
+    if (check_ready(ctx)) return 1;
+    if (!s0_traj || !ps1_traj || !ps1_mean_traj || !ps1_logvar_traj || !pi0_traj || !nz || !G || T < 1)
+        return ctx->fail("efe_trajectory: bad arguments");
+    if (trajectory_impl(ctx, s0_traj, ps1_traj, ps1_mean_traj, ps1_logvar_traj, pi0_traj, T, (uint32_t)nz->seed,
+                        (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, eps, G, (hipStream_t)stream)) return 1;
+    return finish(ctx);
+}
+
+int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int use_means, const efe_noise* nz,
+                 float* G_mean, float* pi0, float* Qpi0, void* stream) {
+    if (check_ready(ctx)) return 1;
+    if (!starting_s || !nz || !G_mean || !pi0 || E < 1 || depth < 1 || depth > 65535) return ctx->fail("efe_simulate: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t k0 = (uint32_t)nz->seed, k1 = (uint32_t)(nz->seed >> 32);
+    const int T = depth;
+    float* s_cur = ctx->allocT<float>((size_t)2 * E * 10);
+    float* s0t = ctx->allocT<float>((size_t)E * T * 10);
+    float* ps1t = ctx->allocT<float>((size_t)E * T * 10);
+    float* mt = ctx->allocT<float>((size_t)E * T * 10);
+    float* lvt = ctx->allocT<float>((size_t)E * T * 10);
+    float* x16 = ctx->allocT<float>((size_t)E * 16);
+    float* l32 = ctx->allocT<float>((size_t)E * 32);
+    float* q = ctx->allocT<float>((size_t)E * 4);
+    float* pit = ctx->allocT<float>((size_t)E * 4);
+    float* tr = ctx->allocT<float>((size_t)E * 32);
+    float* Gt = ctx->allocT<float>((size_t)E * T);
+    if (!s_cur || !s0t || !ps1t || !mt || !lvt || !x16 || !l32 || !q || !pit || !tr || !Gt) return 1;
+    HIPCHK(hipMemcpyAsync(s_cur, starting_s, (size_t)E * 10 * 4, hipMemcpyDeviceToDevice, st));
+    float* cur = s_cur; float* nxt = s_cur + (size_t)E * 10;
+    for (int t = 0; t < T; ++t) {
+        const size_t mark_cur = ctx->arena.cur, mark_off = ctx->arena.off;   // per-step scratch is recycled
+        launch_pad16(cur, x16, E, S_DIM, st);
+        if (run_habit(ctx, x16, E, l32, st)) return 1;
+        launch_softmax4(l32, nullptr, q, nullptr, E, PI_DIM, st);
+        launch_sample_action(q, pit, (t == 0) ? Qpi0 : nullptr, E, PI_DIM, k0, k1, (uint32_t)t, nz->stage, nz->row_offset, nullptr, st);
+        launch_scatter_pi(pit, pi0, E, T, t, PI_DIM, st);
+        launch_pack_x(pit, cur, x16, E, PI_DIM, S_DIM, st);
+        NoiseCfg nc; nc.k0 = k0; nc.k1 = k1; nc.rows_per_group = E; nc.row_offset = nz->row_offset;
+        nc.gm = GroupMap{1, 1, {PASS_SIM, 0, 0}, nz->stage, (uint32_t)t};
+        if (run_mid(ctx, x16, 0, E, tr, nc, st)) return 1;
+        launch_sim_post(tr, nullptr, s0t, ps1t, mt, lvt, nxt, cur, E, T, t, use_means, k0, k1, nz->stage, nz->row_offset, st);
+        std::swap(cur, nxt);
+        ctx->arena.cur = mark_cur; ctx->arena.off = mark_off;
+    }
+    if (trajectory_impl(ctx, s0t, ps1t, mt, lvt, pi0, E * T, k0, k1, nz->stage, nz->row_offset * (uint32_t)T, nullptr, Gt, st)) return 1;
+    launch_mean_rows(Gt, G_mean, E, T, st);
+    return finish(ctx);
+}
+
+int efe_action_posterior(efe_ctx* ctx, const float* sum_G, int n_groups, int n, float temperature, float* P, float* logP, void* stream) {
+    if (!ctx) return 1;
+    if (!sum_G || !P || !logP || n_groups < 1 || n < 1 || n > 8) return ctx->fail("efe_action_posterior: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_posterior(sum_G, P, logP, n_groups, n, temperature, (hipStream_t)stream);
+    return finish(ctx);
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+// Device kernels of the EFE rollout engine (gfx950 / CDNA4 only).
+//
+// One MFMA "tap-GEMM" template covers every dense contraction on the hot path
+// (reference layers: /root/reference/src/torchmodel.py:41-52 ps_net, :84-104 qs_net, :106-128 po_net,
+//  :19-25 qpi_net):
+//
+//      Y^T[co, m] = act( bias[co] + sum_{tap} sum_{ci} Wtap[co, ci] * X[src(m, tap), ci] )
+//
+//   * MFMA rows  = output features (A operand = weights, pre-packed fragment-major so every
+//                  wave-level load is one fully coalesced 1 KiB global_load_dwordx4),
+//   * MFMA cols  = batch rows / output pixels (B operand = NHWC activations, 16 B per lane),
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD.
+//   * a lane owns ONE batch row / pixel and 16 features per 32x32 tile, so the MC-dropout mask of a
+//     row is one Philox call per 128 features, generated in the epilogue; no mask is ever stored.
+//
+// Small VALU kernels handle the Cin=1 / Cout=1 convolutions, reparameterisation and the EFE term
+// reductions (wavefront shuffles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "philox.h"
+
+namespace efe {
+
+enum GemmMode { MODE_FC = 0, MODE_CONVT_S1 = 1, MODE_CONVT_S2 = 2, MODE_CONV_S2 = 3 };
+
+// The batch of one launch is [group][row]: a group is one network evaluation ("pass") over the same
+// rows_per_group logical rows.  Group g of a multi-stage batch decomposes as t = g / per_stage (stage),
+// q = g % per_stage, pass = pass[q / S], sample = sample0 + q % S.
+struct GroupMap {
+    int per_stage, S;
+    uint32_t pass[3];
+    uint32_t stage0, sample0;
+};
+__host__ __device__ inline void group_decode(const GroupMap& gm, int g, int& t, int& pidx, int& samp) {
+    t = g / gm.per_stage;
+    const int q = g - t * gm.per_stage;
+    pidx = q / gm.S;
+    samp = q - pidx * gm.S;
+}
+__device__ __forceinline__ uint2 group_key(const GroupMap& gm, int g) {
+    int t, pidx, samp;
+    group_decode(gm, g, t, pidx, samp);
+    const uint32_t pass = pidx == 0 ? gm.pass[0] : pidx == 1 ? gm.pass[1] : gm.pass[2];
+    return make_uint2(stream_id(pass, gm.sample0 + (uint32_t)samp), gm.stage0 + (uint32_t)t);
+}
+
+struct GemmArgs {
+    const float* Wp;      // packed weights [tap][mtile][kc][64 lanes][4]
+    const float* bias;    // [mtiles*32]
+    const float* X;       // input activations
+    float* Y;             // output activations
+    const float* zeros;   // >= 4 KiB of zeros (source for padded taps / out-of-range rows)
+    int n_pix;            // GEMM columns in this launch (batch rows, or pixels of the m-grid)
+    int cin;              // K per tap (multiple of 8)
+    int cout;             // real output features (multiple of 4)
+    int mtiles;           // 32-feature tiles in the packed weights
+    int ldx, ldy;         // FC: row strides in floats
+    int x_mod;            // FC: if > 0 the input row is (m % x_mod)  (same input for every MC pass)
+    int geo_n;            // conv: input grid edge (ConvT s1: H; ConvT s2: n; Conv s2: Hin)
+    int geo_o;            // Conv s2: output grid edge
+    int relu;
+    // MC-dropout (FC only): keep-mask * 2.0 from Philox, keyed by (tag, global row, group key)
+    int dropout;
+    uint32_t tag, k0, k1;
+    GroupMap gm;          // group index -> (stream id, stage)
+    int rows_per_group;
+    uint32_t row_offset;  // global index of row 0 of a group on this rank
+    int m0;               // index of column 0 of this launch inside the [group][row] batch
+};
+
+struct FinalArgs {
+    const float* X;       // [rows][64][64][32] NHWC output of the 3rd transposed conv
+    const float* wf;      // [9][32] tap-major weights of ConvTranspose2d(32,1,3,1,1)
+    float bias;
+    int rows;             // decoder rows in this launch
+    int m0;               // index of row 0 inside the [group][row] batch
+    int rows_per_group;
+    GroupMap gm;
+    int reward0;          // groups with pidx == 0: 1 = reward log-likelihood, 0 = Bernoulli entropy sum (others: entropy)
+    int store0;           // groups with pidx == 0 store their image at slot t*S + sample
+    float* val;           // [batch] per-row scalar
+    float* po;            // [slots][rows_per_group][4096] stored images
+};
+
+void launch_tapgemm(int mode, int MT, int NT, const GemmArgs& a, hipStream_t st);
+void launch_final(const FinalArgs& a, hipStream_t st);
+void launch_enc_conv1(const float* o, const float* w1, const float* b1, float* y, int rows, hipStream_t st);
+
+struct TransPostArgs {
+    const float* tr;       // [2S][R][32] (mean 0..9, logvar 10..19); group order T1_0..T1_{S-1}, T2_0..T2_{S-1}
+    const float* x;        // [R][16] current [pi(4) | s0(10) | 0 0]
+    const float* eps_inj;  // nullable [3S][R][10]: T1_i, T2_j, D2B_j
+    const float* given_ps1;// nullable [R][10]: trajectory mode, D1 input
+    float* dec_in;         // [3S][R][16]: D1_i, D2A_j, D2B_j
+    float* next_x;         // nullable [R][16]
+    float* ps1_last;       // nullable [R][10]
+    float* ps1_mean_last;  // nullable [R][10]
+    int S, R, mean_mode, carry_mean;
+    uint32_t k0, k1, stage, row_offset;
+};
+void launch_trans_post(const TransPostArgs& a, hipStream_t st);
+
+struct TermsArgs {
+    const float* val;      // [D][3S][R] decoder scalars (D1_i reward, D2A_j / D2B_j entropy sums)
+    const float* tr;       // [D][2S][R][32]
+    const float* enc;      // [D][S][R][32]
+    int D, S, R;
+    float* G;              // [R] summed over stages
+    float* terms;          // [3][R] summed over stages
+    float* t2parts;        // nullable [2][R]: term2_1, term2_2 (last stage; diagnostics)
+};
+void launch_terms(const TermsArgs& a, hipStream_t st);
+
+void launch_pack_x(const float* pi, const float* s, float* x, int R, int pi_dim, int s_dim, hipStream_t st);
+void launch_pad16(const float* s, float* x, int R, int s_dim, hipStream_t st);
+void launch_root_post(const float* enc, const float* pi, const float* eps_inj, float* x, float* s_out, int R, int use_mean,
+                      uint32_t k0, uint32_t k1, uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, hipStream_t st);
+void launch_split_enc(const float* enc, float* mean, float* logvar, int R, hipStream_t st);
+void launch_softmax4(const float* logits32, float* logits, float* q, float* logq, int R, int n, hipStream_t st);
+void launch_sample_action(const float* q, float* pi_onehot, float* q_ret, int R, int n, uint32_t k0, uint32_t k1,
+                          uint32_t sample, uint32_t stage, uint32_t row_offset, const float* u_inj, hipStream_t st);
+void launch_sim_post(const float* tr, const float* eps_inj, float* s0_traj, float* ps1_traj, float* mean_traj, float* lv_traj,
+                     float* s_next, const float* s_cur, int E, int T, int t, int use_means, uint32_t k0, uint32_t k1, uint32_t stage,
+                     uint32_t row_offset, hipStream_t st);
+void launch_scatter_pi(const float* pi_t, float* pi_traj, int E, int T, int t, int n, hipStream_t st);
+void launch_mean_rows(const float* G, float* out, int E, int T, hipStream_t st);
+void launch_fill_tr(const float* mean, const float* logvar, float* tr, int R, hipStream_t st);
+void launch_posterior(const float* sumG, float* P, float* logP, int n_groups, int n, float temperature, hipStream_t st);
+
+}  // namespace efe

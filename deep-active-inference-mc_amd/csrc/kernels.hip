@@ -1,0 +1,557 @@
+// gfx950 (MI355X / CDNA4) kernels of the EFE rollout engine.  See kernels.h for the layout contract.
+#include "kernels.h"
+
+namespace efe {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// tap-GEMM:  Y^T[co, m] = act(bias[co] + sum_tap sum_ci Wtap[co,ci] * X[src(m,tap), ci])
+//
+// One wave owns MT x NT tiles of 32x32 (features x pixels); a workgroup is 4 independent waves
+// laid out along the pixel axis (they share the weight fragments through L1).  Operands go
+// straight from L1/L2 to VGPRs: weights are pre-packed so that lane l of (tile, k-chunk) finds
+// its 4 k-values W[co = l&31][ci = 8*kc + 4*(l>>5) + s] in one 16-byte word; activations are NHWC
+// so the same 4 ci of a pixel are 16 contiguous bytes.  MFMA step s of a chunk contracts the
+// ci pair {8*kc + s, 8*kc + 4 + s}: lanes 0-31 carry the first, lanes 32-63 the second
+// (v_mfma_f32_32x32x2_f32: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]).
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int MT, int NT>
+__global__ void __launch_bounds__(256) k_tapgemm(const GemmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 31, h = lane >> 5;
+    const int KC = a.cin >> 3;
+    const int mt0 = blockIdx.y * MT;
+    const int pix0 = (blockIdx.x * 4 + wave) * (NT * 32);
+    if (pix0 >= a.n_pix) return;                      // wave-uniform
+
+    int img[NT], py[NT], px[NT];
+    bool pv[NT];
+    const int grid = (MODE == MODE_CONV_S2) ? a.geo_o : a.geo_n;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int m = pix0 + nt * 32 + j;
+        pv[nt] = m < a.n_pix;
+        const int mm = pv[nt] ? m : 0;
+        if (MODE == MODE_FC) {
+            img[nt] = mm; py[nt] = 0; px[nt] = 0;
+        } else {
+            const int P = grid * grid;
+            img[nt] = mm / P;
+            const int rem = mm - img[nt] * P;
+            py[nt] = rem / grid;
+            px[nt] = rem - py[nt] * grid;
+        }
+    }
+
+    constexpr int NPAR = (MODE == MODE_CONVT_S2) ? 4 : 1;
+    for (int par = 0; par < NPAR; ++par) {
+        const int ph = par >> 1, pw = par & 1;
+        const int ntaps = (MODE == MODE_FC) ? 1 : (MODE == MODE_CONVT_S2) ? (1 + ph) * (1 + pw) : 9;
+
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.0f;
+
+        for (int t = 0; t < ntaps; ++t) {
+            int wtap = 0, kh = 0, kw = 0, da = 0, db = 0;
+            if (MODE == MODE_CONVT_S1 || MODE == MODE_CONV_S2) {
+                kh = t / 3; kw = t - kh * 3; wtap = t;
+            } else if (MODE == MODE_CONVT_S2) {
+                // oh = 2*ih - 1 + kh: even rows take kh=1 (ih=a); odd rows take kh=0 (ih=a+1) and kh=2 (ih=a)
+                const int th = t / (1 + pw), tw = t - th * (1 + pw);
+                kh = ph ? (th ? 2 : 0) : 1; da = (ph && th == 0) ? 1 : 0;
+                kw = pw ? (tw ? 2 : 0) : 1; db = (pw && tw == 0) ? 1 : 0;
+                wtap = kh * 3 + kw;
+            }
+            const float* xp[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bool ok = pv[nt];
+                size_t off;
+                if (MODE == MODE_FC) {
+                    const int r = (a.x_mod > 0) ? (img[nt] % a.x_mod) : img[nt];
+                    off = (size_t)r * a.ldx;
+                } else {
+                    int sy, sx;
+                    if (MODE == MODE_CONVT_S1) { sy = py[nt] + 1 - kh; sx = px[nt] + 1 - kw; }      // ih = oh + 1 - kh
+                    else if (MODE == MODE_CONVT_S2) { sy = py[nt] + da; sx = px[nt] + db; }
+                    else { sy = 2 * py[nt] + kh; sx = 2 * px[nt] + kw; }                         // valid conv, stride 2
+                    ok = ok && sy >= 0 && sy < a.geo_n && sx >= 0 && sx < a.geo_n;
+                    off = (((size_t)img[nt] * a.geo_n + sy) * a.geo_n + sx) * a.cin;
+                }
+                xp[nt] = (ok ? a.X + off : a.zeros) + 4 * h;
+            }
+            const float4* wp = reinterpret_cast<const float4*>(a.Wp) + ((size_t)(wtap * a.mtiles + mt0) * KC) * 64 + lane;
+
+#pragma unroll 2
+            for (int kc = 0; kc < KC; ++kc) {
+                float4 av[MT], bv[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = wp[(size_t)(mt * KC + kc) * 64];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(xp[nt] + kc * 8);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
+                    }
+            }
+        }
+
+        // ---- epilogue: C/D layout col = lane&31 (pixel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (feature)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (!pv[nt]) continue;
+            const int m = pix0 + nt * 32 + j;
+            size_t yoff;
+            if (MODE == MODE_FC) yoff = (size_t)m * a.ldy;
+            else if (MODE == MODE_CONVT_S2)
+                yoff = (((size_t)img[nt] * (2 * a.geo_n) + 2 * py[nt] + ph) * (2 * a.geo_n) + 2 * px[nt] + pw) * a.cout;
+            else yoff = (size_t)m * a.cout;
+
+            uint4 rnd = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (MODE == MODE_FC && a.dropout) {
+                const int mg = a.m0 + m;
+                const int g = mg / a.rows_per_group;
+                const uint32_t r = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
+                const uint2 key = group_key(a.gm, g);
+                rnd = noise_words(a.k0, a.k1, a.tag, (uint32_t)((mt0 * 32) >> 7), r, key.x, key.y);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int co = (mt0 + mt) * 32 + 8 * g4 + 4 * h;
+                    if (co < a.cout) {
+                        const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
+                        float v[4] = {acc[mt][nt][4 * g4 + 0] + bb.x, acc[mt][nt][4 * g4 + 1] + bb.y,
+                                      acc[mt][nt][4 * g4 + 2] + bb.z, acc[mt][nt][4 * g4 + 3] + bb.w};
+                        if (a.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                        }
+                        if (MODE == MODE_FC && a.dropout) {
+                            const uint32_t word = ((co >> 5) & 3) == 0 ? rnd.x : ((co >> 5) & 3) == 1 ? rnd.y
+                                                : ((co >> 5) & 3) == 2 ? rnd.z : rnd.w;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = ((word >> ((co + e) & 31)) & 1u) ? v[e] * 2.0f : 0.0f;
+                        }
+                        *reinterpret_cast<float4*>(a.Y + yoff + co) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, int MT, int NT>
+static void launch_tg(const GemmArgs& a, hipStream_t st) {
+    const int pix_per_wg = 4 * NT * 32;
+    dim3 grid((a.n_pix + pix_per_wg - 1) / pix_per_wg, (a.mtiles + MT - 1) / MT);
+    hipLaunchKernelGGL((k_tapgemm<MODE, MT, NT>), grid, dim3(256), 0, st, a);
+}
+
+void launch_tapgemm(int mode, int MT, int NT, const GemmArgs& a, hipStream_t st) {
+#define EFE_CASE(MD, M_, N_) if (mode == MD && MT == M_ && NT == N_) { launch_tg<MD, M_, N_>(a, st); return; }
+    EFE_CASE(MODE_FC, 1, 2)
+    EFE_CASE(MODE_FC, 2, 2)
+    EFE_CASE(MODE_FC, 4, 2)
+    EFE_CASE(MODE_CONVT_S1, 2, 2)
+    EFE_CASE(MODE_CONVT_S2, 2, 2)
+    EFE_CASE(MODE_CONVT_S2, 1, 4)
+    EFE_CASE(MODE_CONV_S2, 1, 2)
+    EFE_CASE(MODE_CONV_S2, 2, 2)
+#undef EFE_CASE
+    abort();
+}
+
+// ---------------------------------------------------------------------------------------------
+// ConvTranspose2d(32,1,3,1,1) + Sigmoid (torchmodel.py:126-127) fused with the per-row reductions
+// that consume it: Bernoulli entropy sum (torchutils.py:26-27, torchmodel.py:289,292) or the reward
+// log-likelihood (torchutils.py:30-37, torchmodel.py:210-212).  One workgroup per decoder row.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
+    __shared__ float4 swf[72];
+    __shared__ float sred[4];
+    const int row = blockIdx.x;
+    if (threadIdx.x < 72) swf[threadIdx.x] = reinterpret_cast<const float4*>(a.wf)[threadIdx.x];
+    __syncthreads();
+    const int mg = a.m0 + row;
+    const int g = mg / a.rows_per_group;
+    const int r = mg - g * a.rows_per_group;
+    int gt, gp, gs;
+    group_decode(a.gm, g, gt, gp, gs);
+    int2 gi;
+    gi.x = (gp == 0 && a.reward0) ? 1 : 0;
+    gi.y = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
+    const float* X = a.X + (size_t)row * (64 * 64 * 32);
+    float* po = (gi.y >= 0) ? a.po + ((size_t)gi.y * a.rows_per_group + r) * 4096 : nullptr;
+
+    // fp32 constants of log_bernoulli / entropy_bernoulli: (1e-5 + 1) is rounded to fp32 first
+    const float D1 = 1.00001f, D0 = 0.00001f;
+    float part = 0.0f;
+    for (int it = 0; it < 16; ++it) {
+        const int p = it * 256 + threadIdx.x;
+        const int oh = p >> 6, ow = p & 63;
+        float s = a.bias;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh + 1 - kh;
+            if (ih < 0 || ih >= 64) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow + 1 - kw;
+                if (iw < 0 || iw >= 64) continue;
+                const float4* xp = reinterpret_cast<const float4*>(X + ((size_t)ih * 64 + iw) * 32);
+                const float4* wp = swf + (kh * 3 + kw) * 8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float4 x = xp[c], w = wp[c];
+                    s = fmaf(x.x, w.x, s); s = fmaf(x.y, w.y, s); s = fmaf(x.z, w.z, s); s = fmaf(x.w, w.w, s);
+                }
+            }
+        }
+        const float pr = 1.0f / (1.0f + expf(-s));
+        if (po) po[p] = pr;
+        if (gi.x == 0) {
+            part += -(1.0f - pr) * logf(D1 - pr) - pr * logf(D0 + pr);
+        } else {
+            // target = 1 for image rows h < 32, 0 below (NCHW broadcast of the port)
+            part += (oh < 32) ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f)
+                              : pr * logf(D0) + (1.0f - pr) * logf(D1);
+        }
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+        a.val[mg] = (gi.x == 0) ? tot : tot * (1.0f / 4096.0f) * 10.0f;
+    }
+}
+
+void launch_final(const FinalArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_final, dim3(a.rows), dim3(256), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder conv1: Conv2d(1,32,3,stride 2) + ReLU (torchmodel.py:85-86); Cin = 1 -> VALU.
+// o [rows][64][64] -> y [rows][31][31][32] (NHWC).  8 lanes per output pixel, 4 channels each.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_enc_conv1(const float* __restrict__ o, const float* __restrict__ w1,
+                                                   const float* __restrict__ b1, float* __restrict__ y, int rows) {
+    __shared__ float sw[9 * 32 + 32];
+    for (int i = threadIdx.x; i < 9 * 32 + 32; i += 256) sw[i] = (i < 288) ? w1[i] : b1[i - 288];
+    __syncthreads();
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long pix = gid >> 3;
+    const int cg = (int)(gid & 7);
+    if (pix >= (long)rows * 961) return;
+    const int img = (int)(pix / 961);
+    const int rem = (int)(pix - (long)img * 961);
+    const int oh = rem / 31, ow = rem - oh * 31;
+    const float* src = o + (size_t)img * 4096 + (2 * oh) * 64 + 2 * ow;
+    float acc[4] = {sw[288 + cg * 4], sw[288 + cg * 4 + 1], sw[288 + cg * 4 + 2], sw[288 + cg * 4 + 3]};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const float x = src[kh * 64 + kw];
+            const float* w = sw + (kh * 3 + kw) * 32 + cg * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(x, w[e], acc[e]);
+        }
+    *reinterpret_cast<float4*>(y + pix * 32 + cg * 4) =
+        make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
+}
+
+void launch_enc_conv1(const float* o, const float* w1, const float* b1, float* y, int rows, hipStream_t st) {
+    const long threads = (long)rows * 961 * 8;
+    hipLaunchKernelGGL(k_enc_conv1, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, o, w1, b1, y, rows);
+}
+
+// ---------------------------------------------------------------------------------------------
+// After the transition passes of one stage: reparameterise (torchmodel.py:54-56), build the three
+// decoder input groups of calculate_G (torchmodel.py:274-275, 288, 291) and the next stage's state
+// (torchmodel.py:243).  Thread = (group q in 0..3S-1, row r, k in 0..15).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_trans_post(const TransPostArgs a) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = (int)(gid & 15);
+    const long qr = gid >> 4;
+    const int S = a.S, R = a.R;
+    if (qr >= (long)3 * S * R) return;
+    const int q = (int)(qr / R);
+    const int r = (int)(qr - (long)q * R);
+    float out = 0.0f;
+    if (k < 10) {
+        int src_g; uint32_t pass, sample; bool use_mean = false;
+        if (q < S)            { src_g = q;     pass = PASS_T1;  sample = q;         use_mean = a.mean_mode; }
+        else if (q < 2 * S)   { src_g = q;     pass = PASS_T2;  sample = q - S;     use_mean = a.mean_mode; }
+        else                  { src_g = S - 1; pass = PASS_D2B; sample = q - 2 * S; }   // LAST loop-1 sample's (mean, logvar)
+        const float* tr = a.tr + ((size_t)src_g * R + r) * 32;
+        const float mean = tr[k], lv = tr[10 + k];
+        float eps;
+        if (a.eps_inj) eps = a.eps_inj[((size_t)q * R + r) * 10 + k];
+        else eps = normal_elem(a.k0, a.k1, a.row_offset + r, stream_id(pass, sample), a.stage, k);
+        const float samp = eps * expf(lv * 0.5f) + mean;
+        out = use_mean ? mean : samp;
+        if (q == S - 1) {
+            if (a.ps1_last) a.ps1_last[(size_t)r * 10 + k] = samp;
+            if (a.ps1_mean_last) a.ps1_mean_last[(size_t)r * 10 + k] = mean;
+            if (a.next_x) a.next_x[(size_t)r * 16 + 4 + k] = (a.carry_mean || a.mean_mode) ? mean : samp;
+            if (a.given_ps1) out = a.given_ps1[(size_t)r * 10 + k];
+        }
+    }
+    a.dec_in[qr * 16 + k] = out;
+    if (q == S - 1 && a.next_x) {
+        if (k < 4) a.next_x[(size_t)r * 16 + k] = a.x[(size_t)r * 16 + k];
+        if (k >= 14) a.next_x[(size_t)r * 16 + k] = 0.0f;
+    }
+}
+
+void launch_trans_post(const TransPostArgs& a, hipStream_t st) {
+    const long threads = (long)3 * a.S * a.R * 16;
+    hipLaunchKernelGGL(k_trans_post, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// EFE term combine (torchmodel.py:278-298).  Thread = batch row; the loops
+// over samples and stages run in the reference's order so fp32 rounding follows it.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_terms(const TermsArgs a) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.R) return;
+    const int S = a.S, R = a.R;
+    const float C = 2.8378770664093453f;   // log(2*pi*e), torchutils.py:19
+    float sG = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, p1 = 0.f, p2 = 0.f;
+    for (int t = 0; t < a.D; ++t) {
+        const float* val = a.val + (size_t)t * 3 * S * R;
+        float t0 = 0.f, t1 = 0.f, t21 = 0.f, t22 = 0.f;
+        for (int i = 0; i < S; ++i) {
+            t0 += val[(size_t)i * R + r];
+            const float* tr = a.tr + (((size_t)t * 2 * S + i) * R + r) * 32 + 10;
+            const float* en = a.enc + (((size_t)t * S + i) * R + r) * 32 + 10;
+            float h = 0.f;
+            for (int k = 0; k < 10; ++k) h += 0.5f * (C + tr[k]) + 0.5f * (C + en[k]);
+            t1 += -h;
+        }
+        t0 /= (float)S; t1 /= (float)S;
+        for (int jj = 0; jj < S; ++jj) {
+            t21 += val[(size_t)(S + jj) * R + r];
+            t22 += val[(size_t)(2 * S + jj) * R + r];
+        }
+        t21 /= (float)S; t22 /= (float)S;
+        const float t2 = t21 - t22;
+        const float G = -t0 + t1 + t2;
+        s0 += t0; s1 += t1; s2 += t2; sG += G; p1 = t21; p2 = t22;
+    }
+    a.G[r] = sG;
+    a.terms[r] = s0; a.terms[R + r] = s1; a.terms[2 * R + r] = s2;
+    if (a.t2parts) { a.t2parts[r] = p1; a.t2parts[R + r] = p2; }
+}
+
+void launch_terms(const TermsArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_terms, dim3((a.R + 127) / 128), dim3(128), 0, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// small plumbing kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pack_x(const float* pi, const float* s, float* x, int R, int pi_dim, int s_dim) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = gid >> 4, k = gid & 15;
+    if (r >= R) return;
+    float v = 0.f;
+    if (k < pi_dim) v = pi[(size_t)r * pi_dim + k];                       // torch.cat([pi, s0]) torchmodel.py:59
+    else if (k < pi_dim + s_dim) v = s[(size_t)r * s_dim + (k - pi_dim)];
+    x[gid] = v;
+}
+void launch_pack_x(const float* pi, const float* s, float* x, int R, int pi_dim, int s_dim, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_x, dim3((R * 16 + 255) / 256), dim3(256), 0, st, pi, s, x, R, pi_dim, s_dim);
+}
+
+__global__ void k_pad16(const float* s, float* x, int R, int s_dim) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = gid >> 4, k = gid & 15;
+    if (r >= R) return;
+    x[gid] = (k < s_dim) ? s[(size_t)r * s_dim + k] : 0.f;
+}
+void launch_pad16(const float* s, float* x, int R, int s_dim, hipStream_t st) {
+    hipLaunchKernelGGL(k_pad16, dim3((R * 16 + 255) / 256), dim3(256), 0, st, s, x, R, s_dim);
+}
+
+// root encode -> s0 (torchmodel.py:228-234): x[r] = [pi | (use_mean ? mean : eps*exp(lv/2)+mean) | 0 0]
+__global__ void k_root_post(const float* enc, const float* pi, const float* eps_inj, float* x, float* s_out, int R, int use_mean,
+                            uint32_t k0, uint32_t k1, uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = gid >> 4, k = gid & 15;
+    if (r >= R) return;
+    float v = 0.f;
+    if (k < 4) v = pi ? pi[(size_t)r * 4 + k] : 0.f;
+    else if (k < 14) {
+        const int kk = k - 4;
+        const float mean = enc[(size_t)r * 32 + kk], lv = enc[(size_t)r * 32 + 10 + kk];
+        if (use_mean) v = mean;
+        else {
+            const float eps = eps_inj ? eps_inj[(size_t)r * 10 + kk]
+                                      : normal_elem(k0, k1, row_offset + r, stream_id(pass, sample), stage, kk);
+            v = eps * expf(lv * 0.5f) + mean;
+        }
+        if (s_out) s_out[(size_t)r * 10 + kk] = v;
+    }
+    if (x) x[gid] = v;
+}
+void launch_root_post(const float* enc, const float* pi, const float* eps_inj, float* x, float* s_out, int R, int use_mean,
+                      uint32_t k0, uint32_t k1, uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, hipStream_t st) {
+    hipLaunchKernelGGL(k_root_post, dim3((R * 16 + 255) / 256), dim3(256), 0, st, enc, pi, eps_inj, x, s_out, R, use_mean,
+                       k0, k1, pass, sample, stage, row_offset);
+}
+
+__global__ void k_split_enc(const float* enc, float* mean, float* logvar, int R) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= R * 10) return;
+    const int r = gid / 10, k = gid - r * 10;
+    if (mean) mean[gid] = enc[(size_t)r * 32 + k];
+    if (logvar) logvar[gid] = enc[(size_t)r * 32 + 10 + k];
+}
+void launch_split_enc(const float* enc, float* mean, float* logvar, int R, hipStream_t st) {
+    hipLaunchKernelGGL(k_split_enc, dim3((R * 10 + 255) / 256), dim3(256), 0, st, enc, mean, logvar, R);
+}
+
+// ModelTop.encode_s tail (torchmodel.py:28-30): softmax + log(q + 1e-20)
+__global__ void k_softmax4(const float* l32, float* logits, float* q, float* logq, int R, int n) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float mx = -INFINITY;
+    for (int k = 0; k < n; ++k) mx = fmaxf(mx, l32[(size_t)r * 32 + k]);
+    float e[8], sum = 0.f;
+    for (int k = 0; k < n; ++k) { e[k] = expf(l32[(size_t)r * 32 + k] - mx); sum += e[k]; }
+    for (int k = 0; k < n; ++k) {
+        const float qq = e[k] / sum;
+        if (logits) logits[(size_t)r * n + k] = l32[(size_t)r * 32 + k];
+        if (q) q[(size_t)r * n + k] = qq;
+        if (logq) logq[(size_t)r * n + k] = logf(qq + 1e-20f);
+    }
+}
+void launch_softmax4(const float* l32, float* logits, float* q, float* logq, int R, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_softmax4, dim3((R + 127) / 128), dim3(128), 0, st, l32, logits, q, logq, R, n);
+}
+
+// torch.multinomial(q, 1) stand-in (torchmodel.py:364,379): inverse CDF on a Philox uniform; invalid
+// probabilities -> action 0 (the reference's bare-except fallback).
+__global__ void k_sample_action(const float* q, float* pi_onehot, float* q_ret, int R, int n, uint32_t k0, uint32_t k1,
+                                uint32_t sample, uint32_t stage, uint32_t row_offset, const float* u_inj) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float tot = 0.f; bool bad = false;
+    for (int k = 0; k < n; ++k) { const float v = q[(size_t)r * n + k]; if (!(v >= 0.f) || isinf(v)) bad = true; tot += v; }
+    int act = 0;
+    if (!bad && tot > 0.f) {
+        const float u = u_inj ? u_inj[r]
+                              : u01(noise_words(k0, k1, TAG_ACT, 0u, row_offset + r, stream_id(PASS_HABIT, sample), stage).x);
+        const float thr = u * tot;
+        float acc = 0.f; act = n - 1;
+        for (int k = 0; k < n; ++k) { acc += q[(size_t)r * n + k]; if (thr < acc) { act = k; break; } }
+    } else bad = true;
+    for (int k = 0; k < n; ++k) {
+        const float oh = (k == act) ? 1.f : 0.f;
+        pi_onehot[(size_t)r * n + k] = oh;
+        if (q_ret) q_ret[(size_t)r * n + k] = bad ? oh : q[(size_t)r * n + k];
+    }
+}
+void launch_sample_action(const float* q, float* pi_onehot, float* q_ret, int R, int n, uint32_t k0, uint32_t k1,
+                          uint32_t sample, uint32_t stage, uint32_t row_offset, const float* u_inj, hipStream_t st) {
+    hipLaunchKernelGGL(k_sample_action, dim3((R + 127) / 128), dim3(128), 0, st, q, pi_onehot, q_ret, R, n, k0, k1,
+                       sample, stage, row_offset, u_inj);
+}
+
+// mcts_step_simulate inner step (torchmodel.py:368-376,382-390): reparameterise the transition of step t and
+// scatter it into the trajectory arrays [E][T][10]; carry the next state.
+__global__ void k_sim_post(const float* tr, const float* eps_inj, float* s0_traj, float* ps1_traj, float* mean_traj, float* lv_traj,
+                           float* s_next, const float* s_cur, int E, int T, int t, int use_means, uint32_t k0, uint32_t k1,
+                           uint32_t stage, uint32_t row_offset) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= E * 10) return;
+    const int e = gid / 10, k = gid - e * 10;
+    const float mean = tr[(size_t)e * 32 + k], lv = tr[(size_t)e * 32 + 10 + k];
+    const float eps = eps_inj ? eps_inj[gid] : normal_elem(k0, k1, row_offset + e, stream_id(PASS_SIM, (uint32_t)t), stage, k);
+    const float samp = eps * expf(lv * 0.5f) + mean;
+    const size_t o = ((size_t)e * T + t) * 10 + k;
+    s0_traj[o] = s_cur[gid];
+    ps1_traj[o] = samp; mean_traj[o] = mean; lv_traj[o] = lv;
+    s_next[gid] = use_means ? mean : samp;
+}
+void launch_sim_post(const float* tr, const float* eps_inj, float* s0_traj, float* ps1_traj, float* mean_traj, float* lv_traj,
+                     float* s_next, const float* s_cur, int E, int T, int t, int use_means, uint32_t k0, uint32_t k1, uint32_t stage,
+                     uint32_t row_offset, hipStream_t st) {
+    hipLaunchKernelGGL(k_sim_post, dim3((E * 10 + 255) / 256), dim3(256), 0, st, tr, eps_inj, s0_traj, ps1_traj, mean_traj, lv_traj,
+                       s_next, s_cur, E, T, t, use_means, k0, k1, stage, row_offset);
+}
+
+__global__ void k_scatter_pi(const float* pi_t, float* pi_traj, int E, int T, int t, int n) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= E * n) return;
+    const int e = gid / n, k = gid - e * n;
+    pi_traj[((size_t)e * T + t) * n + k] = pi_t[gid];
+}
+void launch_scatter_pi(const float* pi_t, float* pi_traj, int E, int T, int t, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_scatter_pi, dim3((E * n + 255) / 256), dim3(256), 0, st, pi_t, pi_traj, E, T, t, n);
+}
+
+// torch.mean(G_traj) per episode (torchmodel.py:392)
+__global__ void k_mean_rows(const float* G, float* out, int E, int T) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += G[(size_t)e * T + t];
+    out[e] = s / (float)T;
+}
+void launch_mean_rows(const float* G, float* out, int E, int T, hipStream_t st) {
+    hipLaunchKernelGGL(k_mean_rows, dim3((E + 127) / 128), dim3(128), 0, st, G, out, E, T);
+}
+
+__global__ void k_fill_tr(const float* mean, const float* logvar, float* tr, int R) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = gid >> 5, k = gid & 31;
+    if (r >= R) return;
+    tr[gid] = (k < 10) ? mean[(size_t)r * 10 + k] : (k < 20) ? logvar[(size_t)r * 10 + (k - 10)] : 0.f;
+}
+void launch_fill_tr(const float* mean, const float* logvar, float* tr, int R, hipStream_t st) {
+    hipLaunchKernelGGL(k_fill_tr, dim3((R * 32 + 255) / 256), dim3(256), 0, st, mean, logvar, tr, R);
+}
+
+// softmax_multi_with_log(-sum_G, n) (util.py:46-53, temperature 10; logSM is not log(SM) -- as is)
+__global__ void k_posterior(const float* sumG, float* P, float* logP, int n_groups, int n, float temperature) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    float x[8], mx = -INFINITY;
+    for (int k = 0; k < n; ++k) { x[k] = -sumG[(size_t)g * n + k]; mx = fmaxf(mx, x[k]); }
+    float e[8], sum = 0.f;
+    for (int k = 0; k < n; ++k) { x[k] -= mx; e[k] = expf(x[k] / temperature); sum += e[k]; }
+    for (int k = 0; k < n; ++k) {
+        P[(size_t)g * n + k] = e[k] / sum;
+        logP[(size_t)g * n + k] = x[k] - logf(sum + 1e-20f);
+    }
+}
+void launch_posterior(const float* sumG, float* P, float* logP, int n_groups, int n, float temperature, hipStream_t st) {
+    hipLaunchKernelGGL(k_posterior, dim3((n_groups + 127) / 128), dim3(128), 0, st, sumG, P, logP, n_groups, n, temperature);
+}
+
+}  // namespace efe

@@ -1,0 +1,165 @@
+"""Single-episode MCTS planner over the engine: same public API as /root/reference/src/mcts.py
+(`Node`, `MCTS_Params`, `active_inference_mcts`) so existing callers keep working.  The tree is tiny
+host-side bookkeeping (pi_dim floats per node); every network evaluation goes to the HIP engine through
+`model.calculate_G[_mean]` / `model.mcts_step_simulate`.
+"""
+import torch
+
+_OPPOSITE = {4: {(0, 1), (1, 0), (2, 3), (3, 2)}, 3: {(1, 2), (2, 1)}}
+
+
+def calc_threshold(P, axis):
+    """max - mean of a distribution (mcts.py:130-131)"""
+    return torch.max(P, dim=axis).values - torch.mean(P, dim=axis)
+
+
+def normalization(x, tau=1):
+    """x / sum(x) (mcts.py:133-135)"""
+    return x / x.sum(dim=0)
+
+
+class MCTS_Params:
+    """Planner knobs with the reference's names and defaults (mcts.py:137-148)."""
+
+    def __init__(self):
+        self.C = 1.0
+        self.threshold = 0.5
+        self.repeats = 300
+        self.simulation_repeats = 1
+        self.simulation_depth = 3
+        self.use_habit = False
+        self.use_means = True
+        self.verbose = False
+        self.method = 'ai'
+        self.using_prior_for_exploration = False
+        self.samples = 1          # extension: MC samples per expansion (reference always expands with 1)
+
+
+class Node:
+    """One tree node = one latent state, replicated pi_dim times so an expansion is a pi_dim-row batch
+    (mcts.py:11-34)."""
+    _next_id = 0
+
+    def __init__(self, s, model, C, pi_dim=4, verbose=False, using_prior_for_exploration=False):
+        self.pi_dim = pi_dim
+        self.s = s.reshape(1, -1).repeat(pi_dim, 1)
+        self.model = model
+        self.verbose = verbose
+        self.using_prior_for_exploration = using_prior_for_exploration
+        self.visited = False
+        self.NODE_ID = Node._next_id
+        Node._next_id += 1
+        self.W = torch.zeros(pi_dim)       # accumulated -G per edge
+        self.N = torch.zeros(pi_dim)       # visit count per edge
+        self.Qpi = torch.zeros(pi_dim)     # habit prior
+        self.children_nodes = [None] * pi_dim
+        self.C = C
+        self.in_progress = -1
+
+    def Q(self):
+        return self.W / self.N
+
+    def probs_for_selection(self):
+        """Q normalised to a distribution plus the C/N exploration bonus (mcts.py:39-47)."""
+        q = self.Q()
+        q = q - q.min()
+        q = q / q.sum()
+        bonus = self.C / self.N
+        return q + (self.Qpi * bonus if self.using_prior_for_exploration else bonus)
+
+    def _pick(self, scores, deterministic):
+        return int(torch.argmax(scores)) if deterministic else int(torch.multinomial(scores, 1))
+
+    def select(self, deterministic=True):
+        """Walk down to a leaf following the tree policy (mcts.py:49-62)."""
+        path, actions = [], []
+        node = self
+        while True:
+            node.in_progress = node._pick(node.probs_for_selection(), deterministic)
+            actions.append(node.in_progress)
+            node = node.children_nodes[node.in_progress]
+            path.append(node)
+            if any(c is None for c in node.children_nodes):
+                return path, actions
+
+    def expand(self, use_means=False, samples=1):
+        """Evaluate all actions of a leaf in one engine call (mcts.py:64-86)."""
+        if self.pi_dim == 4:
+            pi_hot = self.model.pi_one_hot
+        elif self.pi_dim == 3:
+            pi_hot = self.model.pi_one_hot_3
+        else:
+            raise ValueError(f'unsupported pi_dim {self.pi_dim}')
+        if use_means:
+            G, _, ps_next, _ = self.model.calculate_G_mean(self.s, pi_hot)
+        else:
+            G, _, ps_next, _, _ = self.model.calculate_G(self.s, pi_hot, samples=samples)
+        self.W -= G.detach().to('cpu')
+        self.N += 1.0
+        for a in range(self.pi_dim):
+            self.children_nodes[a] = Node(ps_next[a], self.model, self.C, self.pi_dim,
+                                          using_prior_for_exploration=self.using_prior_for_exploration)
+
+    def backpropagate(self, path, G):
+        """Credit -G to the edge taken at every node on the path (mcts.py:88-96)."""
+        for node in path:
+            if node.in_progress < 0:
+                raise ValueError('back-propagation through a node with no edge in progress')
+            node.W[node.in_progress] -= G
+            node.N[node.in_progress] += 1
+            node.in_progress = -2
+
+    def action_selection(self, deterministic=True):
+        """Most-visited path to a leaf, minus its last action, with back-and-forth pairs removed
+        (mcts.py:98-128)."""
+        visited = []
+        node = self
+        while True:
+            a = node._pick(node.N if deterministic else node.N.float(), deterministic)
+            visited.append(a)
+            node = node.children_nodes[a]
+            if any(c is None for c in node.children_nodes):
+                break
+        if self.pi_dim not in _OPPOSITE:
+            raise ValueError(f'unknown pi_dim {self.pi_dim}')
+        cancel = _OPPOSITE[self.pi_dim]
+        trimmed, i = [], 0
+        while i < len(visited) - 1:
+            if (visited[i], visited[i + 1]) in cancel:
+                i += 2
+            else:
+                trimmed.append(visited[i])
+                i += 1
+        return trimmed
+
+
+def active_inference_mcts(model, frame, params, o_shape=(64, 64, 1)):
+    """One planning decision (mcts.py:150-195) -> (path, repeats_done, states_explored, all_paths, all_paths_G)."""
+    states_explored, all_paths, all_paths_G = 0, [], []
+    if frame is None or (isinstance(frame, (list, tuple)) and len(frame) == 0):
+        return [0], 0, states_explored, all_paths, all_paths_G
+
+    qs0_mean, _ = model.model_down.encoder(torch.as_tensor(frame).reshape(1, *o_shape))
+    root = Node(qs0_mean[0], model, params.C, model.pi_dim, using_prior_for_exploration=params.using_prior_for_exploration)
+    root.Qpi = model.model_top.encode_s(qs0_mean)[1][0].to('cpu')
+
+    if params.use_habit and calc_threshold(root.Qpi, axis=0) > params.threshold:
+        return [int(torch.multinomial(root.Qpi, 1))], 0, states_explored, all_paths, all_paths_G
+
+    samples = getattr(params, 'samples', 1)
+    root.expand(use_means=params.use_means, samples=samples)
+    for repeat in range(params.repeats):
+        if calc_threshold(normalization(root.N), axis=0) > params.threshold:
+            return root.action_selection(deterministic=True), repeat, states_explored, all_paths, all_paths_G
+        path, actions_path = root.select(deterministic=True)
+        leaf = path[-1]
+        leaf.expand(use_means=params.use_means, samples=samples)
+        sims = torch.zeros(params.simulation_repeats)
+        for k in range(params.simulation_repeats):
+            states_explored += params.simulation_depth
+            sims[k], _, qpi = model.mcts_step_simulate(leaf.s[0], params.simulation_depth, use_means=False)
+            leaf.Qpi = qpi.to('cpu')
+        leaf.backpropagate([root] + path[:-1], sims.mean())
+        all_paths.append(actions_path)
+        all_paths_G.append(sims.mean().item())
+    return root.action_selection(deterministic=True), params.repeats, states_explored, all_paths, all_paths_G

@@ -1,0 +1,448 @@
+"""Host-side mirror of the reference's `ActiveInferenceModel` (/root/reference/src/torchmodel.py:149-393)
+for the EFE hot path, backed by the HIP engine through the C ABI of include/efe_engine.h.
+
+Same attribute names, method names, argument meaning and return tuples as the reference, so
+`src/mcts.py` / `src/util.py`-style callers are drop-in.  PyTorch is used only for device memory
+and streams; every network evaluation and every EFE reduction runs in libefe_mi355x.so.
+There is no CPU fallback: constructing a model without a HIP device raises.
+
+Noise: the reference draws MC-dropout masks and normals from torch's unseeded global generator; here
+every draw is a pure function of (seed, stage, pass, sample, global row, element) -- csrc/philox.h.
+`stage` is a per-model call counter (one `calculate_G` call = one stage), overridable per call with
+`stage=` for reproducible parity tests; `row_offset` is the global index of local row 0 (multi-GPU).
+"""
+import ctypes as C
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import _lib
+
+PASS_T1, PASS_D1, PASS_E1, PASS_T2, PASS_D2A, PASS_D2B, PASS_ROOT, PASS_HABIT, PASS_SIM = range(9)
+
+_SHAPES = {
+    'top': {'qpi_net.0': (128, 10), 'qpi_net.2': (128, 128), 'qpi_net.4': (4, 128)},
+    'mid': {'ps_net.0': (512, 14), 'ps_net.3': (512, 512), 'ps_net.6': (512, 512), 'ps_net.9': (20, 512)},
+    'down': {'qs_net.0': (32, 1, 3, 3), 'qs_net.2': (32, 32, 3, 3), 'qs_net.4': (64, 32, 3, 3), 'qs_net.6': (64, 64, 3, 3),
+             'qs_net.9': (256, 576), 'qs_net.12': (256, 256), 'qs_net.15': (256, 256), 'qs_net.18': (20, 256),
+             'po_net.0': (256, 10), 'po_net.3': (256, 256), 'po_net.6': (256, 256), 'po_net.9': (16384, 256),
+             'po_net.13': (64, 64, 3, 3), 'po_net.15': (64, 64, 3, 3), 'po_net.17': (64, 32, 3, 3), 'po_net.19': (32, 1, 3, 3)},
+}
+_CONVT = ('po_net.13', 'po_net.15', 'po_net.17', 'po_net.19')
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class _Engine:
+    """Owns one efe_ctx on one device."""
+
+    def __init__(self, device_index):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError('deep-active-inference-mc_amd needs a HIP device (MI355X); there is no CPU fallback')
+        self.device = torch.device('cuda', device_index)
+        self.ctx = C.c_void_p()
+        rc = self.lib.efe_create(C.byref(self.ctx), device_index)
+        if rc != 0:
+            raise RuntimeError(f'efe_create failed with code {rc}')
+
+    def check(self, rc):
+        if rc != 0:
+            raise RuntimeError('efe engine: ' + self.lib.efe_last_error(self.ctx).decode())
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def tensor(self, x, shape=None):
+        t = torch.as_tensor(x)
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if shape is not None:
+            t = t.reshape(shape)
+        return t
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        try:
+            if self.ctx:
+                self.lib.efe_destroy(self.ctx)
+                self.ctx = C.c_void_p()
+        except Exception:
+            pass
+
+
+class _Module:
+    """state_dict holder with the reference's key names (torchmodel.py:167-177)."""
+
+    def __init__(self, owner, part):
+        self._owner = owner
+        self._part = part
+        self._sd = {}
+
+    def state_dict(self):
+        return {k: v.clone() for k, v in self._sd.items()}
+
+    def load_state_dict(self, sd):
+        want = _SHAPES[self._part]
+        new = {}
+        for name, shape in want.items():
+            for suffix in ('weight', 'bias'):
+                key = f'{name}.{suffix}'
+                if key not in sd:
+                    raise KeyError(f'missing key {key} in {self._part} state_dict')
+                t = torch.as_tensor(sd[key]).detach().to('cpu', torch.float32).contiguous()
+                if suffix == 'weight':
+                    exp = shape
+                else:
+                    exp = (shape[1],) if name in _CONVT else (shape[0],)
+                if tuple(t.shape) != tuple(exp):
+                    hint = ''
+                    if key == 'qs_net.9.weight' and tuple(t.shape) == (256, 256):
+                        hint = (' (this is the shipped port defect torchmodel.py:94: the encoder emits 576 features; '
+                                'such a checkpoint cannot run the reference either)')
+                    raise ValueError(f'{self._part}.{key}: shape {tuple(t.shape)} != {tuple(exp)}{hint}')
+                new[key] = t
+        self._sd = new
+        self._owner._weights_dirty = True
+
+    def parameters(self):
+        return list(self._sd.values())
+
+    def to(self, *a, **k):
+        return self
+
+
+class ModelTop(_Module):
+    """torchmodel.py:10-31"""
+
+    def __init__(self, owner):
+        super().__init__(owner, 'top')
+        self.s_dim, self.pi_dim = owner.s_dim, owner.pi_dim
+
+    def encode_s(self, s0):
+        m = self._owner
+        e = m._ready()
+        s0 = e.tensor(s0, (-1, m.s_dim))
+        M = s0.shape[0]
+        logits, q, logq = e.empty(M, 4), e.empty(M, 4), e.empty(M, 4)
+        e.check(e.lib.efe_habit(e.ctx, _ptr(s0), M, _ptr(logits), _ptr(q), _ptr(logq), e.stream()))
+        return logits, q, logq
+
+
+class ModelMid(_Module):
+    """torchmodel.py:34-66"""
+
+    def __init__(self, owner):
+        super().__init__(owner, 'mid')
+        self.s_dim, self.pi_dim = owner.s_dim, owner.pi_dim
+
+    def reparameterize(self, mean, logvar):
+        eps = torch.randn_like(mean)
+        return eps * torch.exp(logvar * 0.5) + mean
+
+    def transition_with_sample(self, pi, s0, stage=None, pass_=PASS_T1, sample=0, eps=None, row_offset=None):
+        m = self._owner
+        e = m._ready()
+        pi = e.tensor(pi, (-1, m.pi_dim)); s0 = e.tensor(s0, (-1, m.s_dim))
+        M = s0.shape[0]
+        nz = m._noise(stage, pass_, sample, row_offset)
+        ps1, mean, logvar = e.empty(M, 10), e.empty(M, 10), e.empty(M, 10)
+        eps_t = e.tensor(eps, (M, 10)) if eps is not None else None
+        e.check(e.lib.efe_transition(e.ctx, _ptr(pi), _ptr(s0), M, C.byref(nz), _ptr(eps_t), _ptr(ps1), _ptr(mean), _ptr(logvar), e.stream()))
+        return ps1, mean, logvar
+
+    def transition(self, pi, s0, **kw):
+        _, mean, logvar = self.transition_with_sample(pi, s0, **kw)
+        return mean, logvar
+
+
+class ModelDown(_Module):
+    """torchmodel.py:69-146 (resolution 64, 1 colour channel; the first encoder Linear takes the 576
+    features the conv trunk actually emits -- SURVEY appendix C)."""
+
+    def __init__(self, owner):
+        super().__init__(owner, 'down')
+        self.s_dim, self.pi_dim = owner.s_dim, owner.pi_dim
+        self.colour_channels, self.resolution = 1, 64
+
+    def reparameterize(self, mean, logvar):
+        eps = torch.randn_like(mean)
+        return eps * torch.exp(logvar * 0.5) + mean
+
+    def encoder_with_sample(self, o, stage=None, pass_=PASS_E1, sample=0, eps=None, row_offset=None, _want_s=True):
+        m = self._owner
+        e = m._ready()
+        o = e.tensor(o, (-1, 1, 64, 64))
+        M = o.shape[0]
+        nz = m._noise(stage, pass_, sample, row_offset)
+        mean, logvar = e.empty(M, 10), e.empty(M, 10)
+        s = e.empty(M, 10) if _want_s else None
+        eps_t = e.tensor(eps, (M, 10)) if eps is not None else None
+        e.check(e.lib.efe_encoder(e.ctx, _ptr(o), M, C.byref(nz), _ptr(eps_t), _ptr(s), _ptr(mean), _ptr(logvar), e.stream()))
+        return s, mean, logvar
+
+    def encoder(self, o, **kw):
+        kw.setdefault('pass_', PASS_ROOT)
+        _, mean, logvar = self.encoder_with_sample(o, _want_s=False, **kw)
+        return mean, logvar
+
+    def decoder(self, s, stage=None, pass_=PASS_D1, sample=0, row_offset=None):
+        m = self._owner
+        e = m._ready()
+        s = e.tensor(s, (-1, m.s_dim))
+        M = s.shape[0]
+        nz = m._noise(stage, pass_, sample, row_offset)
+        po = e.empty(M, 1, 64, 64)
+        e.check(e.lib.efe_decoder(e.ctx, _ptr(s), M, C.byref(nz), _ptr(po), e.stream()))
+        return po
+
+
+class ActiveInferenceModel:
+    """Drop-in for the reference class on the EFE hot path.  Extra keyword-only arguments
+    (`device`, `seed`, `row_offset`) configure the engine; everything else follows torchmodel.py:150."""
+
+    def __init__(self, s_dim, pi_dim, gamma, beta_s, beta_o, colour_channels=1, resolution=64, *, device=None, seed=0,
+                 row_offset=0, init_weights=True):
+        if s_dim != 10 or pi_dim != 4 or colour_channels != 1 or resolution != 64:
+            raise ValueError('the engine implements the Dynamic-dSprites configuration of the reference '
+                             '(s_dim=10, pi_dim=4, 1x64x64); the Animal-AI branch of the reference is not runnable '
+                             '(calc_reward_animalai undefined, torchmodel.py:214)')
+        if device is None:
+            idx = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        else:
+            idx = torch.device(device).index or 0
+        self._engine = _Engine(idx)
+        self.device = self._engine.device
+        self.s_dim, self.pi_dim = s_dim, pi_dim
+        self.seed = int(seed)
+        self.row_offset = int(row_offset)
+        self._stage = 0
+        self._weights_dirty = True
+        self.precision = torch.float32
+        self.model_top = ModelTop(self)
+        self.model_mid = ModelMid(self)
+        self.model_down = ModelDown(self)
+        self.beta_s = torch.tensor(beta_s, device=self.device)
+        self.gamma = torch.tensor(gamma, device=self.device)
+        self.beta_o = torch.tensor(beta_o, device=self.device)
+        self.pi_one_hot = torch.eye(4, device=self.device)
+        self.pi_one_hot_3 = torch.eye(3, device=self.device)
+        if init_weights:
+            self._init_random(seed)
+
+    # ---- weights ----------------------------------------------------------------------------------
+    def _init_random(self, seed):
+        """He-uniform-like random init (the reference comments 'He Uniform', torchmodel.py:14)."""
+        g = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFF)
+        for part, mod in (('top', self.model_top), ('mid', self.model_mid), ('down', self.model_down)):
+            sd = {}
+            for name, shape in _SHAPES[part].items():
+                if len(shape) == 2:
+                    fan = shape[1]
+                elif name in _CONVT:
+                    fan = shape[0] * 9 / (4 if name in ('po_net.15', 'po_net.17') else 1)
+                else:
+                    fan = shape[1] * 9
+                bound = 1.15 * (3.0 / fan) ** 0.5
+                sd[f'{name}.weight'] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+                nb = shape[1] if name in _CONVT else shape[0]
+                sd[f'{name}.bias'] = (torch.rand(nb, generator=g) * 2 - 1) * 0.1
+            if part == 'mid':
+                sd['ps_net.9.bias'][10:] -= 2.0
+            if part == 'down':
+                sd['qs_net.18.bias'][10:] -= 2.0
+            mod.load_state_dict(sd)
+
+    def load_state_dicts(self, top, mid, down):
+        self.model_top.load_state_dict(top)
+        self.model_mid.load_state_dict(mid)
+        self.model_down.load_state_dict(down)
+
+    def load_flat_weights(self, weights):
+        """weights: dict '<top|mid|down>.<state_dict key>' -> array (oracle/synth.py naming)."""
+        parts = {'top': {}, 'mid': {}, 'down': {}}
+        for k, v in weights.items():
+            part, key = k.split('.', 1)
+            parts[part][key] = torch.as_tensor(np.asarray(v))
+        self.load_state_dicts(parts['top'], parts['mid'], parts['down'])
+
+    def _ready(self):
+        e = self._engine
+        if self._weights_dirty:
+            for part, mod in (('top', self.model_top), ('mid', self.model_mid), ('down', self.model_down)):
+                for key, t in mod._sd.items():
+                    shape = (C.c_int64 * t.dim())(*t.shape)
+                    e.check(e.lib.efe_set_weight(e.ctx, f'{part}.{key}'.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
+            e.check(e.lib.efe_commit_weights(e.ctx))
+            self._weights_dirty = False
+        return e
+
+    def set_option(self, name, value):
+        e = self._engine
+        e.check(e.lib.efe_set_option(e.ctx, name.encode(), int(value)))
+
+    def save_weights(self, folder_chp):
+        """torchmodel.py:167-171"""
+        torch.save(self.model_down.state_dict(), f'{folder_chp}/checkpoint_down.pth')
+        torch.save(self.model_top.state_dict(), f'{folder_chp}/checkpoint_top.pth')
+        torch.save(self.model_mid.state_dict(), f'{folder_chp}/checkpoint_mid.pth')
+
+    def load_weights(self, folder_chp):
+        """torchmodel.py:173-177"""
+        self.model_down.load_state_dict(torch.load(f'{folder_chp}/checkpoint_down.pth', map_location='cpu'))
+        self.model_top.load_state_dict(torch.load(f'{folder_chp}/checkpoint_top.pth', map_location='cpu'))
+        self.model_mid.load_state_dict(torch.load(f'{folder_chp}/checkpoint_mid.pth', map_location='cpu'))
+
+    def save_all(self, folder_chp, stats, script_file='', optimizers={}):
+        """torchmodel.py:179-189 (weights + stats; optimiser state is training-only and out of scope)."""
+        self.save_weights(folder_chp)
+        with open(f'{folder_chp}/stats.pkl', 'wb') as ff:
+            pickle.dump(stats, ff)
+
+    def load_all(self, folder_chp):
+        """torchmodel.py:191-208"""
+        self.load_weights(folder_chp)
+        stats = {}
+        if os.path.exists(f'{folder_chp}/stats.pkl'):
+            with open(f'{folder_chp}/stats.pkl', 'rb') as ff:
+                stats = pickle.load(ff)
+        if stats.get('var_beta_s'):
+            self.beta_s = torch.tensor(stats['var_beta_s'][-1], device=self.device)
+        if stats.get('var_gamma'):
+            self.gamma = torch.tensor(stats['var_gamma'][-1], device=self.device)
+        if stats.get('var_beta_o'):
+            self.beta_o = torch.tensor(stats['var_beta_o'][-1], device=self.device)
+        return stats, {}
+
+    def to(self, *a, **k):
+        return self
+
+    def parameters(self):
+        return self.model_top.parameters() + self.model_mid.parameters() + self.model_down.parameters()
+
+    # ---- noise bookkeeping --------------------------------------------------------------------------
+    def _take_stage(self, stage, n=1):
+        if stage is None:
+            stage = self._stage
+            self._stage += n
+        return int(stage)
+
+    def _noise(self, stage, pass_, sample, row_offset=None):
+        return _lib.EfeNoise(self.seed, self._take_stage(stage), pass_, sample,
+                             self.row_offset if row_offset is None else int(row_offset))
+
+    # ---- hot path -----------------------------------------------------------------------------------
+    def check_reward(self, o):
+        """torchmodel.py:210-212 via the oracle-pinned constants: a host-side convenience for callers that
+        hold an image; the rollout path computes this inside the fused decoder epilogue."""
+        o = self._engine.tensor(o, (-1, 1, 64, 64))
+        d1, d0 = np.float32(1.00001), np.float32(0.00001)
+        l_top = o * float(np.log(d1)) + (1 - o) * float(np.log(np.float32(d1 - np.float32(1.0))))
+        l_bot = o * float(np.log(d0)) + (1 - o) * float(np.log(d1))
+        h = torch.arange(64, device=o.device).reshape(1, 1, 64, 1)
+        return torch.where(h < 32, l_top, l_bot).mean(dim=[1, 2, 3]) * 10.0
+
+    def imagine_future_from_o(self, o0, pi):
+        """torchmodel.py:216-220"""
+        s0, _, _ = self.model_down.encoder_with_sample(o0, pass_=PASS_ROOT)
+        ps1, _, _ = self.model_mid.transition_with_sample(pi, s0)
+        return self.model_down.decoder(ps1)
+
+    def habitual_net(self, o):
+        """torchmodel.py:222-225"""
+        qs_mean, _ = self.model_down.encoder(o)
+        _, Qpi, _ = self.model_top.encode_s(qs_mean)
+        return Qpi
+
+    def calculate_G(self, s0, pi0, samples=10, *, stage=None, eps=None, row_offset=None, _mean_mode=False, _parts=None):
+        """torchmodel.py:270-300 -> (G, [term0, term1, term2], ps1, ps1_mean, po1)"""
+        e = self._ready()
+        s0 = e.tensor(s0, (-1, self.s_dim)); pi0 = e.tensor(pi0, (-1, self.pi_dim))
+        M = s0.shape[0]
+        nz = self._noise(stage, 0, 0, row_offset)
+        G, terms = e.empty(M), e.empty(3, M)
+        ps1, ps1_mean, po1 = e.empty(M, 10), e.empty(M, 10), e.empty(M, 1, 64, 64)
+        S = 1 if _mean_mode else int(samples)
+        eps_t = e.tensor(eps, (3 * S, M, 10)) if eps is not None else None
+        parts = e.empty(2, M) if _parts is not None else None
+        e.check(e.lib.efe_calculate_g(e.ctx, _ptr(s0), _ptr(pi0), M, S, 1 if _mean_mode else 0, C.byref(nz), _ptr(eps_t),
+                                      _ptr(G), _ptr(terms), _ptr(ps1), _ptr(ps1_mean), _ptr(po1), _ptr(parts), e.stream()))
+        if _parts is not None:
+            _parts.append(parts)
+        if _mean_mode:
+            return G, [terms[0], terms[1], terms[2]], ps1_mean, po1
+        return G, [terms[0], terms[1], terms[2]], ps1, ps1_mean, po1
+
+    def calculate_G_mean(self, s0, pi0, *, stage=None, eps=None, row_offset=None, _parts=None):
+        """torchmodel.py:302-327 -> (G, terms, ps1_mean, po1)"""
+        return self.calculate_G(s0, pi0, 1, stage=stage, eps=eps, row_offset=row_offset, _mean_mode=True, _parts=_parts)
+
+    def _rollout(self, o, pi, steps, calc_mean, samples, per_stage_mean, stage, eps, row_offset):
+        e = self._ready()
+        o = e.tensor(o, (-1, 1, 64, 64)); pi = e.tensor(pi, (-1, self.pi_dim))
+        M = o.shape[0]
+        if pi.shape[0] != M:
+            raise ValueError('o and pi must have the same number of rows')
+        nz = self._noise(self._take_stage(stage, steps), 0, 0, row_offset)
+        sum_G, sum_terms, po1 = e.empty(M), e.empty(3, M), e.empty(M, 1, 64, 64)
+        eps_t = e.tensor(eps).reshape(-1) if eps is not None else None
+        e.check(e.lib.efe_rollout(e.ctx, _ptr(o), _ptr(pi), M, int(steps), int(samples), 1 if calc_mean else 0,
+                                  1 if per_stage_mean else 0, C.byref(nz), _ptr(eps_t), _ptr(sum_G), _ptr(sum_terms), _ptr(po1),
+                                  e.stream()))
+        return sum_G, [sum_terms[0], sum_terms[1], sum_terms[2]], po1
+
+    def calculate_G_repeated(self, o, pi, steps=1, calc_mean=False, samples=10, *, stage=None, eps=None, row_offset=None):
+        """torchmodel.py:227-245 -> (sum_G, sum_terms, po1); one row = one EFE rollout."""
+        return self._rollout(o, pi, steps, calc_mean, samples, False, stage, eps, row_offset)
+
+    def calculate_G_4_repeated(self, o, steps=1, calc_mean=False, samples=10, *, stage=None, eps=None, row_offset=None):
+        """torchmodel.py:247-268 (4 rows, pi = eye(4); calc_mean switches every stage to calculate_G_mean)"""
+        o = self._engine.tensor(o, (-1, 1, 64, 64))
+        if o.shape[0] != 4:
+            raise ValueError('calculate_G_4_repeated expects 4 rows (torchmodel.py:251-252)')
+        return self._rollout(o, self.pi_one_hot, steps, calc_mean, samples, True, stage, eps, row_offset)
+
+    def calculate_G_given_trajectory(self, s0_traj, ps1_traj, ps1_mean_traj, ps1_logvar_traj, pi0_traj, *, stage=None,
+                                     eps=None, row_offset=None):
+        """torchmodel.py:329-352 -> G[T]"""
+        e = self._ready()
+        s0 = e.tensor(s0_traj, (-1, 10)); ps1 = e.tensor(ps1_traj, (-1, 10)); mean = e.tensor(ps1_mean_traj, (-1, 10))
+        lv = e.tensor(ps1_logvar_traj, (-1, 10)); pi0 = e.tensor(pi0_traj, (-1, 4))
+        T = s0.shape[0]
+        nz = self._noise(stage, 0, 0, row_offset)
+        G = e.empty(T)
+        eps_t = e.tensor(eps, (3, T, 10)) if eps is not None else None
+        e.check(e.lib.efe_trajectory(e.ctx, _ptr(s0), _ptr(ps1), _ptr(mean), _ptr(lv), _ptr(pi0), T, C.byref(nz), _ptr(eps_t), _ptr(G), e.stream()))
+        return G
+
+    def simulate_batch(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None):
+        """mcts_step_simulate for E lock-step episodes -> (G[E], pi0[E,depth,4], Qpi0[E,4])"""
+        e = self._ready()
+        s = e.tensor(starting_s, (-1, 10))
+        E = s.shape[0]
+        nz = self._noise(stage, 0, 0, row_offset)
+        G, pi0, q0 = e.empty(E), e.empty(E, depth, 4), e.empty(E, 4)
+        e.check(e.lib.efe_simulate(e.ctx, _ptr(s), E, int(depth), 1 if use_means else 0, C.byref(nz), _ptr(G), _ptr(pi0), _ptr(q0), e.stream()))
+        return G, pi0, q0
+
+    def mcts_step_simulate(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None):
+        """torchmodel.py:354-393 -> (float G, pi0[depth,4], Qpi[4])"""
+        G, pi0, q0 = self.simulate_batch(self._engine.tensor(starting_s, (1, 10)), depth, use_means, stage=stage, row_offset=row_offset)
+        return G[0].item(), pi0[0], q0[0]
+
+    def action_posterior(self, sum_G, single_values=4, temperature=10.0):
+        """softmax_multi_with_log(-sum_G, 4) (/root/reference/src/util.py:46-53,68) -> (P, logP) [n,4] on device"""
+        e = self._ready()
+        g = e.tensor(sum_G).reshape(-1)
+        n = g.numel() // single_values
+        P, logP = e.empty(n, single_values), e.empty(n, single_values)
+        e.check(e.lib.efe_action_posterior(e.ctx, _ptr(g), n, single_values, float(temperature), _ptr(P), _ptr(logP), e.stream()))
+        return P, logP
+
+    def last_call_macs(self):
+        return int(self._engine.lib.efe_last_call_macs(self._engine.ctx))

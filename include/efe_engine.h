@@ -1,0 +1,110 @@
+/* efe_engine.h -- C ABI of the MI355X expected-free-energy (EFE) rollout engine.
+ *
+ * Drop-in boundary for the Monte-Carlo EFE hot path of zfountas/deep-active-inference-mc.
+ * The reference has no FFI: its boundary is the Python object `ActiveInferenceModel`
+ * (/root/reference/src/torchmodel.py:149-393).  Each entry point below replaces one method of that
+ * object (cited per function); the Python mirror in deep-active-inference-mc_amd/model.py binds
+ * them with ctypes and keeps the reference's method names, argument meaning and return tuples.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  All tensor pointers are DEVICE pointers to
+ *     contiguous fp32 unless the name ends in _host.  Observations are NCHW [M,1,64,64].
+ *   - no ownership transfer: the caller allocates every input/output buffer; the engine owns only
+ *     its packed weights and a scratch arena.  Calls are stream-ordered on `stream` (a hipStream_t
+ *     passed as void*; NULL = default stream) and return without synchronising, unless the arena must
+ *     grow (first call at a new size).  One context per device per host thread.
+ *   - return value: 0 on success, non-zero on error (efe_last_error() gives the message).
+ *   - noise: MC-dropout masks / normals / action uniforms are a pure function of
+ *     (seed, stage, pass, sample, global row = row_offset + r, element) -- see csrc/philox.h --
+ *     so results are independent of batching and of the number of GPUs.  `stage` is the caller's
+ *     call counter: one calculate_G call (or one stage of a rollout) consumes one stage value.
+ *     `eps` pointers are optional injected normals (NULL = generated on device).
+ */
+#ifndef EFE_ENGINE_H
+#define EFE_ENGINE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct efe_ctx efe_ctx;
+
+/* lifecycle ------------------------------------------------------------------------------------ */
+int efe_create(efe_ctx** out, int device);                       /* ActiveInferenceModel.__init__, torchmodel.py:150-165 */
+void efe_destroy(efe_ctx* ctx);
+const char* efe_last_error(efe_ctx* ctx);
+int efe_abi_version(void);
+
+/* weights: reference state_dict tensors (host, reference layout), key = "<top|mid|down>.<state_dict key>",
+ * e.g. "down.po_net.13.weight" (ConvTranspose2d [Cin,Cout,3,3]).  Replaces load_weights,
+ * torchmodel.py:173-177 (the .pth unpickling stays in Python).  efe_commit_weights packs them into the
+ * MFMA fragment-major device layout. */
+int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const int64_t* shape, int ndim);
+int efe_commit_weights(efe_ctx* ctx);
+
+/* options: "dec_chunk" (decoder rows per launch group), "enc_chunk". */
+int efe_set_option(efe_ctx* ctx, const char* name, int64_t value);
+
+typedef struct efe_noise {
+    uint64_t seed;
+    uint32_t stage;       /* call / stage counter */
+    uint32_t pass;        /* network-level calls only: which pass id keys the masks (csrc/philox.h) */
+    uint32_t sample;      /* network-level calls only */
+    uint32_t row_offset;  /* global index of local row 0 */
+} efe_noise;
+
+/* network level ---------------------------------------------------------------------------------- */
+/* ModelMid.transition_with_sample, torchmodel.py:58-66.  eps: optional [M,10]. */
+int efe_transition(efe_ctx*, const float* pi /*[M,4]*/, const float* s0 /*[M,10]*/, int M, const efe_noise* nz,
+                   const float* eps, float* ps1, float* mean, float* logvar, void* stream);
+/* ModelDown.decoder, torchmodel.py:139-141.  po: [M,1,64,64]. */
+int efe_decoder(efe_ctx*, const float* s /*[M,10]*/, int M, const efe_noise* nz, float* po, void* stream);
+/* ModelDown.encoder / encoder_with_sample, torchmodel.py:134-137,143-146.  s may be NULL. */
+int efe_encoder(efe_ctx*, const float* o /*[M,1,64,64]*/, int M, const efe_noise* nz, const float* eps,
+                float* s, float* mean, float* logvar, void* stream);
+/* ModelTop.encode_s, torchmodel.py:27-31 (no dropout). */
+int efe_habit(efe_ctx*, const float* s /*[M,10]*/, int M, float* logits, float* q, float* logq, void* stream);
+
+/* EFE level -------------------------------------------------------------------------------------- */
+/* calculate_G (torchmodel.py:270-300) when mean_mode == 0; calculate_G_mean (torchmodel.py:302-327)
+ * when mean_mode == 1 (samples forced to 1).
+ * eps: optional [3*samples, M, 10] = T1_0..T1_{S-1}, T2_0..T2_{S-1}, D2B_0..D2B_{S-1}.
+ * outputs: G[M], terms[3,M], ps1[M,10] (last sample; NULL ok), ps1_mean[M,10], po1[M,1,64,64] (last sample; NULL ok),
+ * t2parts[2,M] (term2_1, term2_2; NULL ok). */
+int efe_calculate_g(efe_ctx*, const float* s0, const float* pi0, int M, int samples, int mean_mode,
+                    const efe_noise* nz, const float* eps,
+                    float* G, float* terms, float* ps1, float* ps1_mean, float* po1, float* t2parts, void* stream);
+
+/* calculate_G_repeated (torchmodel.py:227-245) when per_stage_mean == 0;
+ * calculate_G_4_repeated (torchmodel.py:247-268) semantics when per_stage_mean == 1 (calc_mean then
+ * switches every stage to calculate_G_mean).  One row = one "EFE rollout".
+ * nz->stage = stage0; stage t uses stage0 + t; the root encode uses (stage0, PASS_ROOT).
+ * eps: optional [M*10 (root)] followed by per stage [3*S, M, 10].
+ * outputs: sum_G[M], sum_terms[3,M], po1[M,1,64,64] (NULL ok). */
+int efe_rollout(efe_ctx*, const float* o, const float* pi, int M, int steps, int samples, int calc_mean,
+                int per_stage_mean, const efe_noise* nz, const float* eps,
+                float* sum_G, float* sum_terms, float* po1, void* stream);
+
+/* calculate_G_given_trajectory (torchmodel.py:329-352): rows are trajectory steps. G[T]. */
+int efe_trajectory(efe_ctx*, const float* s0_traj, const float* ps1_traj, const float* ps1_mean_traj,
+                   const float* ps1_logvar_traj, const float* pi0_traj, int T, const efe_noise* nz, const float* eps,
+                   float* G, void* stream);
+
+/* mcts_step_simulate (torchmodel.py:354-393) for E lock-step episodes: habit-policy rollout of `depth`
+ * steps from starting_s[E,10], then G over each trajectory.  Noise rows: steps use global row
+ * row_offset+e (sample = t); trajectory rows use (row_offset+e)*depth + t.
+ * outputs: G_mean[E], pi0[E,depth,4] one-hot, Qpi0[E,4] (habit posterior of the first step). */
+int efe_simulate(efe_ctx*, const float* starting_s, int E, int depth, int use_means, const efe_noise* nz,
+                 float* G_mean, float* pi0, float* Qpi0, void* stream);
+
+/* softmax_multi_with_log(-sum_G, n) (/root/reference/src/util.py:46-53,68): action posterior. */
+int efe_action_posterior(efe_ctx*, const float* sum_G /*[n_groups*n]*/, int n_groups, int n, float temperature,
+                         float* P, float* logP, void* stream);
+
+/* introspection for benches: algorithmic MACs of the last EFE-level call. */
+int64_t efe_last_call_macs(efe_ctx*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

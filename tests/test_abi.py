@@ -1,0 +1,66 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/efe_engine.h declares; the Python mirror exposes the reference's method names."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, 'include', 'efe_engine.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(efe_[a-z_0-9]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from daimc_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in efe_engine.h but not exported'
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_create_fails_cleanly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from daimc_amd import _lib
+    lib = _lib.load()
+    ctx = ctypes.c_void_p()
+    assert lib.efe_create(ctypes.byref(ctx), 0) != 0
+    import daimc_amd
+    with pytest.raises(RuntimeError):
+        daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0)
+
+
+def test_python_mirror_has_reference_api():
+    import daimc_amd
+    M = daimc_amd.ActiveInferenceModel
+    for name in ('calculate_G', 'calculate_G_mean', 'calculate_G_repeated', 'calculate_G_4_repeated',
+                 'calculate_G_given_trajectory', 'mcts_step_simulate', 'check_reward', 'habitual_net',
+                 'imagine_future_from_o', 'save_weights', 'load_weights', 'save_all', 'load_all'):
+        assert callable(getattr(M, name))
+    for name in ('encoder', 'encoder_with_sample', 'decoder', 'reparameterize'):
+        assert callable(getattr(daimc_amd.ModelDown, name))
+    for name in ('transition', 'transition_with_sample', 'reparameterize'):
+        assert callable(getattr(daimc_amd.ModelMid, name))
+    assert callable(daimc_amd.ModelTop.encode_s)
+    p = daimc_amd.MCTS_Params()
+    assert (p.C, p.threshold, p.repeats, p.simulation_repeats, p.simulation_depth, p.use_habit, p.use_means) == \
+        (1.0, 0.5, 300, 1, 3, False, True)
+
+
+def test_host_softmax_matches_golden(golden):
+    import numpy as np
+    from daimc_amd import softmax_multi_with_log
+    g = golden('rollout_m8d2s2')
+    P, logP = softmax_multi_with_log(-g['sum_G'], 4)
+    np.testing.assert_allclose(P, g['Ppi'], rtol=1e-6)
+    np.testing.assert_allclose(logP, g['logPpi'], rtol=1e-6, atol=1e-6)

@@ -1,0 +1,252 @@
+"""GPU parity tests (-m gpu): the HIP engine, called through the C ABI via the Python mirror, against
+(1) the fixtures captured from the shimmed reference and (2) the CPU oracle on fresh seeded inputs.
+
+Tolerances (fp32, stated per SURVEY 8c): network outputs rtol 1e-5 / atol 2e-6 (+ sigmoid outputs atol 1e-5);
+term0/term1 atol 1e-3; term2 and G: atol = 5e-6 * max(|term2_1|, 1) + 1e-3 (term2 is a cancelling
+difference of two 4096-pixel sums)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import eps_calcG, eps_rollout
+from oracle import philox as PX
+from oracle import synth
+from oracle import efe_oracle as EO
+
+pytestmark = pytest.mark.gpu
+GAINS = ['g100', 'g115', 'g135']
+
+
+@pytest.fixture(scope='module')
+def models(weights_cache):
+    import daimc_amd
+    cache = {}
+
+    def get(wseed, gain, seed):
+        key = (int(wseed), float(gain))
+        if key not in cache:
+            m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=int(seed), init_weights=False)
+            m.load_flat_weights(weights_cache(wseed, gain))
+            cache[key] = m
+        m = cache[key]
+        m.seed = int(seed)
+        m.row_offset = 0
+        return m
+    return get
+
+
+def _model(g, models):
+    return models(g['wseed'], g['gain'], g['nseed'])
+
+
+def c(t):
+    return t.detach().cpu().numpy()
+
+
+def gtol(t21):
+    return 5e-6 * max(float(np.max(np.abs(t21))), 1.0) + 1e-3
+
+
+@pytest.mark.parametrize('gain', GAINS)
+def test_networks_vs_golden(golden, models, gain):
+    g = golden(f'nets_{gain}')
+    m = _model(g, models)
+    st, seed, M = int(g['stage']), int(g['nseed']), len(g['s'])
+    eps_t = PX.normals(seed, M, 10, PX.PASS_T1, 0, st)
+    ps1, mean, lv = m.model_mid.transition_with_sample(g['pi'], g['s'], stage=st, pass_=PX.PASS_T1, eps=eps_t)
+    np.testing.assert_allclose(c(mean), g['t_mean'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(lv), g['t_lv'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(ps1), g['t_ps1'], rtol=1e-5, atol=2e-6)
+    # device-generated normals (Box-Muller on Philox) agree with the numpy mirror to fp32 libm accuracy
+    ps1_dev, _, _ = m.model_mid.transition_with_sample(g['pi'], g['s'], stage=st, pass_=PX.PASS_T1)
+    np.testing.assert_allclose(c(ps1_dev), g['t_ps1'], rtol=1e-4, atol=1e-5)
+
+    po = m.model_down.decoder(g['s'], stage=st, pass_=PX.PASS_D1)
+    assert po.shape == (M, 1, 64, 64)
+    np.testing.assert_allclose(c(po), g['d_po'], rtol=1e-5, atol=1e-5)
+
+    eps_e = PX.normals(seed, M, 10, PX.PASS_E1, 0, st)
+    s, emean, elv = m.model_down.encoder_with_sample(g['frames'], stage=st, pass_=PX.PASS_E1, eps=eps_e)
+    np.testing.assert_allclose(c(emean), g['e_mean'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(elv), g['e_lv'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(s), g['e_s'], rtol=1e-5, atol=2e-6)
+
+    logits, q, logq = m.model_top.encode_s(g['s'])
+    np.testing.assert_allclose(c(logits), g['h_logits'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(q), g['h_q'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c(logq), g['h_logq'], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('gain', GAINS)
+@pytest.mark.parametrize('case', ['m4s1', 'm6s3'])
+def test_calculate_G_vs_golden(golden, models, gain, case):
+    g = golden(f'calcG_{case}_{gain}')
+    m = _model(g, models)
+    S, st, M = int(g['samples']), int(g['stage']), len(g['s0'])
+    eps = eps_calcG(int(g['nseed']), M, S, st)
+    parts = []
+    G, terms, ps1, ps1_mean, po1 = m.calculate_G(g['s0'], g['pi0'], samples=S, stage=st, eps=eps, _parts=parts)
+    np.testing.assert_allclose(c(ps1), g['ps1'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(ps1_mean), g['ps1_mean'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(po1), g['po1'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=1e-3)
+    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=1e-3)
+    np.testing.assert_allclose(c(parts[0][0]), g['t2_1'], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(c(parts[0][1]), g['t2_2'], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(c(terms[2]), g['t2'], atol=gtol(g['t2_1']))
+    np.testing.assert_allclose(c(G), g['G'], atol=gtol(g['t2_1']))
+
+
+@pytest.mark.parametrize('gain', GAINS)
+def test_calculate_G_mean_vs_golden(golden, models, gain):
+    g = golden(f'calcGmean_{gain}')
+    m = _model(g, models)
+    st = int(g['stage'])
+    eps = eps_calcG(int(g['nseed']), 4, 1, st)
+    G, terms, ps1_mean, po1 = m.calculate_G_mean(g['s0'], m.pi_one_hot, stage=st, eps=eps)
+    np.testing.assert_allclose(c(ps1_mean), g['ps1_mean'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(po1), g['po1'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=1e-3)
+    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=1e-3)
+    np.testing.assert_allclose(c(G), g['G'], atol=gtol(g['t2_1']))
+
+
+@pytest.mark.parametrize('name', ['rollout_cfg1', 'rollout_m8d2s2', 'rollout_m8d2s2mean'])
+def test_rollout_vs_golden(golden, models, name):
+    g = golden(name)
+    m = _model(g, models)
+    D, S, st, M = int(g['steps']), int(g['samples']), int(g['stage']), len(g['o'])
+    eps = eps_rollout(int(g['nseed']), M, D, S, st)
+    sum_G, terms, po1 = m.calculate_G_repeated(g['o'], g['pi'], steps=D, calc_mean=bool(g['calc_mean']), samples=S, stage=st, eps=eps)
+    tol = D * gtol(np.array([2800.0]))
+    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=2e-3)
+    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=2e-3)
+    np.testing.assert_allclose(c(terms[2]), g['t2'], atol=tol)
+    np.testing.assert_allclose(c(sum_G), g['sum_G'], atol=tol)
+    np.testing.assert_allclose(c(po1), g['po1'], rtol=1e-5, atol=2e-5)
+    P, logP = m.action_posterior(sum_G)
+    # posterior from OUR sum_G vs the reference's posterior from ITS sum_G (temperature-10 softmax, util.py:46-53)
+    np.testing.assert_allclose(c(P), g['Ppi'], atol=5e-3)
+    P2, logP2 = m.action_posterior(torch.from_numpy(g['sum_G']))
+    np.testing.assert_allclose(c(P2), g['Ppi'], rtol=1e-5)
+    np.testing.assert_allclose(c(logP2), g['logPpi'], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['rollout4_s2', 'rollout4_mean'])
+def test_rollout4_vs_golden(golden, models, name):
+    g = golden(name)
+    m = _model(g, models)
+    D, S, st = int(g['steps']), int(g['samples']), int(g['stage'])
+    Seff = 1 if bool(g['calc_mean']) else S
+    eps = eps_rollout(int(g['nseed']), 4, D, Seff, st)
+    sum_G, terms, po1 = m.calculate_G_4_repeated(g['o'], steps=D, calc_mean=bool(g['calc_mean']), samples=S, stage=st, eps=eps)
+    tol = D * gtol(np.array([2800.0]))
+    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=2e-3)
+    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=2e-3)
+    np.testing.assert_allclose(c(sum_G), g['sum_G'], atol=tol)
+    np.testing.assert_allclose(c(po1), g['po1'], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', ['simulate_sample', 'simulate_means'])
+def test_simulate_vs_golden(golden, models, name):
+    g = golden(name)
+    m = _model(g, models)
+    G, pi0, q = m.mcts_step_simulate(g['start'], int(g['depth']), use_means=bool(g['use_means']), stage=int(g['stage']),
+                                     row_offset=int(g['episode']))
+    assert np.array_equal(c(pi0), g['pi0'])                 # same actions sampled (Philox uniform + habit posterior)
+    np.testing.assert_allclose(c(q), g['Qpi'], rtol=1e-5, atol=1e-6)
+    assert abs(G - float(g['G'])) < 0.05                    # device-generated normals (no injection on this path)
+
+
+@pytest.mark.parametrize('name', ['mcts_means', 'mcts_samples'])
+def test_mcts_vs_golden(golden, models, name):
+    import daimc_amd
+    g = golden(name)
+    m = _model(g, models)
+    p = daimc_amd.MCTS_Params()
+    p.repeats, p.simulation_depth, p.use_means, p.threshold = int(g['repeats']), int(g['simulation_depth']), bool(g['use_means']), float(g['threshold'])
+    m._stage = int(g['stage'])
+    path, reps, explored, all_paths, all_G = daimc_amd.active_inference_mcts(m, torch.from_numpy(g['frame']), p, o_shape=(1, 64, 64))
+    assert reps == int(g['repeats_done']) and explored == int(g['states_explored'])
+    ref_paths = [[int(a) for a in row if a >= 0] for row in g['all_paths']]
+    assert [[int(a) for a in pth] for pth in all_paths] == ref_paths
+    np.testing.assert_allclose(np.array(all_G), g['all_paths_G'], atol=0.05)
+    assert [int(a) for a in path] == [int(a) for a in g['final_path']]
+
+
+# ------------------------------------------------------------------------------------------------------
+# fresh seeded inputs vs the oracle (sizes the oracle finishes in seconds), ragged / edge cases
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,S', [(1, 1), (3, 2), (33, 1), (70, 2)])
+def test_calculate_G_vs_oracle_ragged(models, weights_cache, M, S):
+    seed, st, ro = 99, 5, 1000
+    w = weights_cache(1234, 1.15)
+    m = models(1234, 1.15, seed)
+    orc = EO.OracleModel(w, EO.PhiloxNoise(seed, row_offset=ro))
+    s0 = PX.uniform_fill(8, (M, 10), 300 + M, -1.0, 1.0)
+    pi0 = np.eye(4, dtype=np.float32)[np.arange(M) % 4]
+    with torch.no_grad():
+        oG, oT, ops1, ops1m, opo1 = orc.calculate_G(torch.from_numpy(s0), torch.from_numpy(pi0), S, st)
+    eps = eps_calcG(seed, M, S, st, ro)
+    G, terms, ps1, ps1m, po1 = m.calculate_G(s0, pi0, samples=S, stage=st, eps=eps, row_offset=ro)
+    np.testing.assert_allclose(c(ps1), ops1.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(po1), opo1.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c(G), oG.numpy(), atol=gtol(orc.last_term2_parts[0].numpy()))
+
+
+def test_row_offset_invariance(models):
+    """rows keyed globally: evaluating rows [0,8) at once == evaluating [0,4) and [4,8) separately
+    (what makes 1/2/4/8-GPU results identical)."""
+    m = models(1234, 1.15, 11)
+    o = synth.make_frames(31, 8)
+    pi = np.eye(4, dtype=np.float32)[np.arange(8) % 4]
+    G_all, _, _ = m.calculate_G_repeated(o, pi, steps=2, samples=2, stage=0, row_offset=0)
+    G_a, _, _ = m.calculate_G_repeated(o[:4], pi[:4], steps=2, samples=2, stage=0, row_offset=0)
+    G_b, _, _ = m.calculate_G_repeated(o[4:], pi[4:], steps=2, samples=2, stage=0, row_offset=4)
+    assert torch.equal(G_all, torch.cat([G_a, G_b]))
+
+
+def test_chunking_invariance(models):
+    m = models(1234, 1.15, 12)
+    o = synth.make_frames(32, 6)
+    pi = np.eye(4, dtype=np.float32)[np.arange(6) % 4]
+    G1, _, po1 = m.calculate_G_repeated(o, pi, steps=2, samples=3, stage=3)
+    m.set_option('dec_chunk', 7); m.set_option('enc_chunk', 5)
+    G2, _, po2 = m.calculate_G_repeated(o, pi, steps=2, samples=3, stage=3)
+    m.set_option('dec_chunk', 1024); m.set_option('enc_chunk', 4096)
+    assert torch.equal(G1, G2) and torch.equal(po1, po2)
+
+
+def test_full_size_properties(models):
+    """BASELINE cfg-2 shape (128 rows, S=10, D=5): size-independent properties -- determinism, finite
+    outputs, duplicate rows with equal global ids give equal results, action posterior sums to one."""
+    m = models(1234, 1.15, 1)
+    fr = synth.make_frames(41, 32)
+    o = np.repeat(fr, 4, axis=0)
+    pi = np.tile(np.eye(4, dtype=np.float32), (32, 1))
+    G1, t1, _ = m.calculate_G_repeated(o, pi, steps=5, samples=10, stage=0)
+    G2, t2, _ = m.calculate_G_repeated(o, pi, steps=5, samples=10, stage=0)
+    assert torch.equal(G1, G2)
+    assert torch.isfinite(G1).all()
+    np.testing.assert_allclose(c(-t1[0] + t1[1] + t1[2]), c(G1), rtol=1e-5, atol=1e-2)
+    P, logP = m.action_posterior(G1)
+    np.testing.assert_allclose(c(P.sum(1)), 1.0, rtol=1e-5)
+    # a different stage gives different MC noise, but a statistically similar G
+    G3, _, _ = m.calculate_G_repeated(o, pi, steps=5, samples=10, stage=100)
+    assert not torch.equal(G1, G3)
+
+
+def test_dropout_statistics(models):
+    """device-Philox mode validated statistically: mean of G over many noise stages vs the oracle's"""
+    seed = 5
+    m = models(1234, 1.0, seed)
+    s0 = np.tile(PX.uniform_fill(9, (1, 10), 77, -1, 1), (4, 1))
+    gs = []
+    for st in range(48):
+        G, _, _, _, _ = m.calculate_G(s0, m.pi_one_hot, samples=4, stage=st)
+        gs.append(c(G))
+    gs = np.stack(gs)
+    assert np.isfinite(gs).all()
+    se = gs.std(0) / np.sqrt(len(gs))
+    # rows differ only by the action; spread across stages is MC noise -> std error bounded
+    assert (se < 10).all()

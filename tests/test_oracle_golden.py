@@ -1,0 +1,134 @@
+"""CPU tests: the oracle (oracle/efe_oracle.py) against the fixtures captured from the shimmed reference
+(oracle/make_golden.py), plus known-answer tests of the Philox generator."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import philox as PX
+from oracle import synth
+from oracle import efe_oracle as EO
+
+GAINS = ['g100', 'g115', 'g135']
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    assert [int(x) for x in PX.philox4x32_10(0, 0, 0, 0, 0, 0)] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert [int(x) for x in PX.philox4x32_10(*([0xffffffff] * 4), 0xffffffff, 0xffffffff)] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert [int(x) for x in PX.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)] == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_noise_addressable():
+    a = PX.dropout_mask(5, PX.TAG_DEC + 3, 8, 16384, PX.PASS_D1, 2, 9, row_offset=0)
+    b = PX.dropout_mask(5, PX.TAG_DEC + 3, 4, 16384, PX.PASS_D1, 2, 9, row_offset=4)
+    assert np.array_equal(a[4:], b)                       # rows are keyed globally (multi-GPU invariance)
+    assert set(np.unique(a)) == {0.0, 2.0}
+    assert abs(a.mean() - 1.0) < 0.01
+    z = PX.normals(5, 4096, 10, PX.PASS_T1, 0, 0)
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    assert np.array_equal(PX.normals(5, 8, 10, 0, 0, 0)[3:], PX.normals(5, 5, 10, 0, 0, 0, row_offset=3))
+
+
+def test_helpers_vs_reference(golden):
+    g = golden('helpers')
+    p = torch.from_numpy(g['p'])
+    assert np.array_equal(EO.entropy_normal_from_logvar(torch.from_numpy(g['lv'])).numpy(), g['ent_normal'])
+    assert np.array_equal(EO.entropy_bernoulli(p).numpy(), g['ent_bern'])
+    assert np.array_equal(EO.check_reward(p).numpy(), g['reward'])
+    # restated closed form of the NCHW-broadcast reward
+    d1, d0 = np.float32(1.00001), np.float32(1e-5)
+    o = g['p'][:, 0]
+    top = o * np.log(d1) + (1 - o) * np.log(np.float32(d1 - np.float32(1)))
+    bot = o * np.log(d0) + (1 - o) * np.log(d1)
+    h = np.arange(64)[None, :, None]
+    r = np.where(h < 32, top, bot).reshape(len(o), -1).mean(1) * 10
+    np.testing.assert_allclose(r, g['reward'], rtol=2e-6)
+
+
+def test_softmax_multi_with_log(golden):
+    g = golden('rollout_m8d2s2')
+    P, logP = EO.softmax_multi_with_log(-g['sum_G'], 4)
+    np.testing.assert_allclose(P, g['Ppi'], rtol=1e-6)
+    np.testing.assert_allclose(logP, g['logPpi'], rtol=1e-6, atol=1e-6)
+
+
+def _oracle(g, weights_cache):
+    w = weights_cache(g['wseed'], g['gain'])
+    return EO.OracleModel(w, EO.PhiloxNoise(int(g['nseed'])))
+
+
+@pytest.mark.parametrize('gain', GAINS)
+def test_networks_vs_reference(golden, weights_cache, gain):
+    g = golden(f'nets_{gain}')
+    m = _oracle(g, weights_cache)
+    st = int(g['stage'])
+    with torch.no_grad():
+        ps1, mean, lv = m.transition_with_sample(torch.from_numpy(g['pi']), torch.from_numpy(g['s']), PX.PASS_T1, 0, st)
+        po = m.decoder(torch.from_numpy(g['s']), PX.PASS_D1, 0, st)
+        es, em, elv = m.encoder_with_sample(torch.from_numpy(g['frames']), PX.PASS_E1, 0, st)
+        hl, hq, hlq = m.encode_s(torch.from_numpy(g['s']))
+    for a, b in ((ps1, 't_ps1'), (mean, 't_mean'), (lv, 't_lv'), (po, 'd_po'), (es, 'e_s'), (em, 'e_mean'), (elv, 'e_lv'),
+                 (hl, 'h_logits'), (hq, 'h_q'), (hlq, 'h_logq')):
+        np.testing.assert_allclose(a.numpy(), g[b], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('gain', GAINS)
+@pytest.mark.parametrize('case', ['m4s1', 'm6s3'])
+def test_calculate_G_vs_reference(golden, weights_cache, gain, case):
+    g = golden(f'calcG_{case}_{gain}')
+    m = _oracle(g, weights_cache)
+    with torch.no_grad():
+        G, terms, ps1, ps1m, po1 = m.calculate_G(torch.from_numpy(g['s0']), torch.from_numpy(g['pi0']), int(g['samples']), int(g['stage']))
+    np.testing.assert_allclose(G.numpy(), g['G'], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(ps1.numpy(), g['ps1'], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(po1.numpy(), g['po1'], rtol=1e-6, atol=1e-6)
+
+
+def test_rollouts_vs_reference(golden, weights_cache):
+    for name, four in (('rollout_cfg1', False), ('rollout_m8d2s2', False), ('rollout_m8d2s2mean', False),
+                       ('rollout4_s2', True), ('rollout4_mean', True)):
+        g = golden(name)
+        m = _oracle(g, weights_cache)
+        with torch.no_grad():
+            if four:
+                G, T, po1 = m.calculate_G_4_repeated(torch.from_numpy(g['o']), int(g['steps']), bool(g['calc_mean']), int(g['samples']), int(g['stage']))
+            else:
+                G, T, po1 = m.calculate_G_repeated(torch.from_numpy(g['o']), torch.from_numpy(g['pi']), int(g['steps']),
+                                                   bool(g['calc_mean']), int(g['samples']), int(g['stage']))
+        np.testing.assert_allclose(G.numpy(), g['sum_G'], rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(po1.numpy(), g['po1'], rtol=1e-6, atol=1e-6)
+
+
+def test_simulate_vs_reference(golden, weights_cache):
+    for name in ('simulate_sample', 'simulate_means'):
+        g = golden(name)
+        m = _oracle(g, weights_cache)
+        with torch.no_grad():
+            G, pi0, q = m.mcts_step_simulate(torch.from_numpy(g['start']), int(g['depth']), bool(g['use_means']), int(g['stage']),
+                                             episode=int(g['episode']))
+        assert abs(G - float(g['G'])) < 1e-3
+        assert np.array_equal(pi0.numpy(), g['pi0'])
+        np.testing.assert_allclose(q.numpy(), g['Qpi'], rtol=1e-6)
+
+
+def test_convtranspose_subpixel_restatement():
+    """independent numpy restatement of ConvTranspose2d(k3,s2,p1,op1) in the 4-parity form the HIP kernel
+    uses against torch's conv_transpose2d."""
+    rng = np.random.default_rng(0)
+    n, ci, co = 5, 3, 4
+    x = rng.standard_normal((1, ci, n, n)).astype(np.float32)
+    w = rng.standard_normal((ci, co, 3, 3)).astype(np.float32)
+    ref = torch.nn.functional.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(w), stride=2, padding=1, output_padding=1).numpy()
+    out = np.zeros((1, co, 2 * n, 2 * n), dtype=np.float64)
+    xp = np.zeros((ci, n + 1, n + 1)); xp[:, :n, :n] = x[0]
+    for ph in (0, 1):
+        for pw in (0, 1):
+            khs = [(1, 0)] if ph == 0 else [(0, 1), (2, 0)]
+            kws = [(1, 0)] if pw == 0 else [(0, 1), (2, 0)]
+            for kh, da in khs:
+                for kw, db in kws:
+                    src = xp[:, da:da + n, db:db + n]                      # in[a+da, b+db]
+                    out[0, :, ph::2, pw::2] += np.einsum('iab,io->oab', src, w[:, :, kh, kw])
+    np.testing.assert_allclose(out, ref, atol=1e-5)
