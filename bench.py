@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""EFE rollouts/sec on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch of synthetic input: calculate_G_repeated over 128
+rows (32 root frames x 4 actions) with 10 MC samples and depth 5 (BASELINE configs[1]), followed by
+the action posterior; at N > 1 every rank runs its own 128 rows (episodes shard with no data-path
+collective, weak scaling) and one all_gather of the [32,4] action posteriors per step is the only RCCL
+traffic.  Inputs are resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MAC_ROLLOUT = 6_739_934_560          # 51 encoder + 100 transition + 150 decoder passes
+MAC_CT3_ROW = 18_874_368             # ConvTranspose2d(64,32,3,s2) per decoder row: 32*32*9*64*32
+PEAK_FP32_MFMA_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, fp32 in / fp32 acc
+CLASS_MACS_PER_ROW = {               # algorithmic MACs per network row, by kernel class
+    'dec_dense_16384': 256 * 16384, 'convT1_64x64_s1': 256 * 9 * 64 * 64, 'convT2_64x64_s2': 256 * 9 * 64 * 64,
+    'convT3_64x32_s2': MAC_CT3_ROW, 'final_conv_sigmoid_reduce': 4096 * 9 * 32,
+}
+
+
+def synth_frames(n, device, seed=0):
+    """dSprites-like frames: one filled square + the reward bar of game_environment.py:44-54,70-71."""
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(n, 4, generator=g)
+    fr = torch.zeros(n, 1, 64, 64)
+    for i in range(n):
+        side = 6 + int(u[i, 0] * 18); y = 3 + int(u[i, 1] * (61 - side)); x = int(u[i, 2] * (64 - side))
+        fr[i, 0, y:y + side, x:x + side] = 1.0
+        r = 2 * float(u[i, 3]) - 1
+        if r > 0:
+            fr[i, 0, 0:3, 0:32] = r
+        else:
+            fr[i, 0, 0:3, 32:64] = -r
+    return fr.to(device)
+
+
+def cpu_baseline(depth, samples, target_s=15.0):
+    """The oracle (CPU restatement of the reference's own torch op sequence, torch RNG like the reference)
+    timed on this host's cores on a bounded sample of the same workload."""
+    from oracle import synth
+    from oracle.efe_oracle import OracleModel, TorchNoise
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    m = OracleModel(synth.make_weights(1234, 1.15), TorchNoise())
+
+    def run(rows):
+        o = torch.from_numpy(np.repeat(synth.make_frames(5, (rows + 3) // 4), 4, axis=0)[:rows])
+        pi = torch.eye(4).repeat((rows + 3) // 4, 1)[:rows]
+        t = time.perf_counter()
+        with torch.no_grad():
+            m.calculate_G_repeated(o, pi, depth, False, samples, 0)
+        return time.perf_counter() - t
+    run(4)                                   # warm-up (thread pools, oneDNN primitives)
+    t4 = run(4)
+    rows = int(min(128, max(4, 4 * round(target_s / max(t4, 1e-3)))))
+    rows -= rows % 4
+    dt = run(rows)
+    return {'value': rows / dt, 'unit': 'rollouts/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{rows} rows x depth {depth} x {samples} MC samples, 1 timed pass after warm-up, torch-CPU eager '
+                      f'oracle (oracle/efe_oracle.py, torch RNG), {dt:.2f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--rows', type=int, default=128)
+    ap.add_argument('--samples', type=int, default=10)
+    ap.add_argument('--depth', type=int, default=5)
+    ap.add_argument('--dec-chunk', type=int, default=0)
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-prof', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    import daimc_amd
+    R, S, D = a.rows, a.samples, a.depth
+    model = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device=device, seed=1, row_offset=rank * R)
+    if a.dec_chunk:
+        model.set_option('dec_chunk', a.dec_chunk)
+    frames = synth_frames(R // 4, device, seed=100 + rank)
+    o = frames.repeat_interleave(4, dim=0).contiguous()          # row 4i+a = (root i, action a), util.py:56-60
+    pi = torch.eye(4, device=device).repeat(R // 4, 1).contiguous()
+    gathered = torch.empty(world * (R // 4), 4, device=device) if world > 1 else None
+
+    def step(k):
+        G, _, _ = model.calculate_G_repeated(o, pi, steps=D, samples=S, stage=k * D)
+        P, _ = model.action_posterior(G)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, P)
+        return G
+
+    for k in range(a.warmup):
+        step(k)
+    macs = model.last_call_macs() if False else None
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not a.no_prof:
+        model.prof_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        G = step(a.warmup + k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(G).all()
+    prof = model.prof_read() if not a.no_prof else {}
+    model.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        value = world * R * a.steps / dt
+        out = {
+            'metric': 'EFE rollouts/sec (64x64 dSprites, 10 MC-samples, depth 5)', 'value': value, 'unit': 'rollouts/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'calculate_G_repeated: {R} rows ({R // 4} roots x 4 actions) x depth {D} x {S} MC samples per GPU '
+                                   f'(BASELINE configs[1]) + action posterior' + (' + all_gather of posteriors' if world > 1 else ''),
+                       'rows_per_gpu': R, 'samples': S, 'depth': D, 'parallelism': f'episodes sharded x{world}, weights replicated'},
+            'achieved_tflops_total': value * 2 * MAC_ROLLOUT / 1e12,
+        }
+        if prof:
+            name = 'convT3_64x32_s2'
+            ms, n = prof[name]
+            rows_per_launch = (a.steps * D * 3 * S * R) / max(n, 1)
+            ach = (2 * MAC_CT3_ROW * rows_per_launch) / (ms / max(n, 1) * 1e-3) / 1e12 if ms > 0 else 0.0
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'k_tapgemm<MODE_CONVT_S2,1,4> (ConvTranspose2d 64->32, 32x32->64x64)',
+                               'achieved': ach, 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TF,
+                               'traffic': None, 'launches': int(n), 'avg_launch_ms': ms / max(n, 1),
+                               'flops_per_launch': 2 * MAC_CT3_ROW * rows_per_launch}
+            tot = sum(v[0] for v in prof.values())
+            kern = {}
+            for k_, (ms_, n_) in prof.items():
+                e = {'ms': round(ms_, 3), 'launches': int(n_), 'share': round(ms_ / tot, 4) if tot else 0}
+                if k_ in CLASS_MACS_PER_ROW and ms_ > 0:
+                    e['tflops'] = round(2 * CLASS_MACS_PER_ROW[k_] * a.steps * D * 3 * S * R / (ms_ * 1e-3) / 1e12, 2)
+                kern[k_] = e
+            out['kernels'] = kern
+        if world == 1 and not a.no_cpu:
+            out['cpu_baseline'] = cpu_baseline(D, S)
+            out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

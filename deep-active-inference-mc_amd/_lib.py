@@ -8,7 +8,8 @@ LIB_PATH = os.path.join(HERE, 'libefe_mi355x.so')
 
 EXPORTS = ['efe_create', 'efe_destroy', 'efe_last_error', 'efe_abi_version', 'efe_set_weight', 'efe_commit_weights',
            'efe_set_option', 'efe_transition', 'efe_decoder', 'efe_encoder', 'efe_habit', 'efe_calculate_g',
-           'efe_rollout', 'efe_trajectory', 'efe_simulate', 'efe_action_posterior', 'efe_last_call_macs']
+           'efe_rollout', 'efe_trajectory', 'efe_simulate', 'efe_action_posterior', 'efe_last_call_macs',
+           'efe_prof_enable', 'efe_prof_classes', 'efe_prof_read']
 
 
 class EfeNoise(C.Structure):
@@ -47,5 +48,8 @@ def load():
     lib.efe_simulate.argtypes = [p, f32p, i, i, i, nzp, f32p, f32p, f32p, p]; lib.efe_simulate.restype = i
     lib.efe_action_posterior.argtypes = [p, f32p, i, i, C.c_float, f32p, f32p, p]; lib.efe_action_posterior.restype = i
     lib.efe_last_call_macs.argtypes = [p]; lib.efe_last_call_macs.restype = C.c_int64
+    lib.efe_prof_enable.argtypes = [p, i]; lib.efe_prof_enable.restype = i
+    lib.efe_prof_classes.argtypes = []; lib.efe_prof_classes.restype = i
+    lib.efe_prof_read.argtypes = [p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]; lib.efe_prof_read.restype = i
     _lib = lib
     return lib

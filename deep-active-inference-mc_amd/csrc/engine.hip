@@ -22,6 +22,9 @@ namespace {
 constexpr int S_DIM = 10, PI_DIM = 4;
 constexpr int64_t MAC_TRANS = 541696, MAC_DEC = 43256320, MAC_ENC = 3868960, MAC_HABIT = 18176;
 
+enum ProfClass { PROF_MID = 0, PROF_DEC_FC = 1, PROF_DEC_FC4 = 2, PROF_CT1 = 3, PROF_CT2 = 4, PROF_CT3 = 5, PROF_FINAL = 6,
+                 PROF_ENC = 7, PROF_OTHER = 8, PROF_NCLS = 9 };
+
 struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
 
 struct Layer {
@@ -51,6 +54,25 @@ struct efe_ctx {
     Arena arena;
     int64_t dec_chunk = 1024, enc_chunk = 4096;
     int64_t last_macs = 0;
+    // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
+    bool prof = false;
+    int cls = PROF_OTHER;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_spans;
+    hipEvent_t ev_get() {
+        if (ev_used == ev_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
+        return ev_pool[ev_used++];
+    }
+    hipEvent_t prof_begin(hipStream_t st) {
+        if (!prof) return nullptr;
+        hipEvent_t a = ev_get(); (void)hipEventRecord(a, st); return a;
+    }
+    void prof_end(hipEvent_t a, hipStream_t st) {
+        if (!prof) return;
+        hipEvent_t b = ev_get(); (void)hipEventRecord(b, st);
+        ev_spans.push_back({cls, {a, b}});
+    }
 
     int fail(const std::string& m) { err = m; return 1; }
 
@@ -131,14 +153,18 @@ void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float*
     a.n_pix = M; a.cin = L.cin; a.cout = L.cout; a.mtiles = L.mtiles; a.ldx = ldx; a.ldy = ldy; a.x_mod = x_mod;
     a.relu = relu; a.dropout = drop; a.tag = tag; a.k0 = nc.k0; a.k1 = nc.k1; a.gm = nc.gm;
     a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = m0;
+    hipEvent_t e0 = ctx->prof_begin(st);
     launch_tapgemm(MODE_FC, L.mtiles == 1 ? 1 : 2, 2, a, st);
+    ctx->prof_end(e0, st);
 }
 
 void conv(efe_ctx* ctx, int mode, int MT, int NT, const Layer& L, const float* X, float* Y, int n_pix, int geo_n, int geo_o, hipStream_t st) {
     GemmArgs a{};
     a.Wp = L.Wp; a.bias = L.bias; a.X = X; a.Y = Y; a.zeros = ctx->zeros;
     a.n_pix = n_pix; a.cin = L.cin; a.cout = L.cout; a.mtiles = L.mtiles; a.geo_n = geo_n; a.geo_o = geo_o; a.relu = 1;
+    hipEvent_t e0 = ctx->prof_begin(st);
     launch_tapgemm(mode, MT, NT, a, st);
+    ctx->prof_end(e0, st);
 }
 
 // ModelMid.ps_net over M = groups*R rows; X is [R][16], every group reads the same rows (x_mod).
@@ -146,10 +172,12 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
     float* h1 = ctx->allocT<float>((size_t)M * 512);
     float* h2 = ctx->allocT<float>((size_t)M * 512);
     if (!h1 || !h2) return 1;
+    ctx->cls = PROF_MID;
     fc(ctx, ctx->mid[0], X, 16, x_mod, h1, 512, M, true, true, TAG_MID + 0, nc, 0, st);
     fc(ctx, ctx->mid[1], h1, 512, 0, h2, 512, M, true, true, TAG_MID + 1, nc, 0, st);
     fc(ctx, ctx->mid[2], h2, 512, 0, h1, 512, M, true, true, TAG_MID + 2, nc, 0, st);
     fc(ctx, ctx->mid[3], h1, 512, 0, tr, 32, M, false, false, 0, nc, 0, st);
+    ctx->cls = PROF_OTHER;
     ctx->last_macs += (int64_t)M * MAC_TRANS;
     return 0;
 }
@@ -167,18 +195,27 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
     if (!hA || !hB || !x4 || !y1 || !y2 || !y3) return 1;
     for (int m0 = 0; m0 < N; m0 += C) {
         const int c = std::min(C, N - m0);
+        ctx->cls = PROF_DEC_FC;
         fc(ctx, ctx->dec_fc[0], dec_in + (size_t)m0 * 16, 16, 0, hA, 256, c, true, true, TAG_DEC + 0, nc, m0, st);
         fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, c, true, true, TAG_DEC + 1, nc, m0, st);
         fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, c, true, true, TAG_DEC + 2, nc, m0, st);
+        ctx->cls = PROF_DEC_FC4;
         fc(ctx, ctx->dec_fc[3], hA, 256, 0, x4, 16384, c, true, true, TAG_DEC + 3, nc, m0, st);
+        ctx->cls = PROF_CT1;
         conv(ctx, MODE_CONVT_S1, 2, 2, ctx->dec_ct[0], x4, y1, c * 256, 16, 0, st);
+        ctx->cls = PROF_CT2;
         conv(ctx, MODE_CONVT_S2, 2, 2, ctx->dec_ct[1], y1, y2, c * 256, 16, 0, st);
+        ctx->cls = PROF_CT3;
         conv(ctx, MODE_CONVT_S2, 1, 4, ctx->dec_ct[2], y2, y3, c * 1024, 32, 0, st);
+        ctx->cls = PROF_FINAL;
         FinalArgs f{};
         f.X = y3; f.wf = ctx->dec_wf; f.bias = ctx->dec_bf; f.rows = c; f.m0 = m0; f.rows_per_group = nc.rows_per_group;
         f.gm = nc.gm; f.reward0 = reward0; f.store0 = store0; f.val = val; f.po = po_store;
+        hipEvent_t e0 = ctx->prof_begin(st);
         launch_final(f, st);
+        ctx->prof_end(e0, st);
     }
+    ctx->cls = PROF_OTHER;
     ctx->last_macs += (int64_t)N * MAC_DEC;
     return 0;
 }
@@ -195,7 +232,10 @@ int run_encoder(efe_ctx* ctx, const float* o, int N, const NoiseCfg& nc, float* 
     if (!c1 || !c2 || !c3 || !c4 || !hA || !hB) return 1;
     for (int m0 = 0; m0 < N; m0 += C) {
         const int c = std::min(C, N - m0);
+        ctx->cls = PROF_ENC;
+        hipEvent_t e0 = ctx->prof_begin(st);
         launch_enc_conv1(o + (size_t)m0 * 4096, ctx->enc_w1, ctx->enc_b1, c1, c, st);
+        ctx->prof_end(e0, st);
         conv(ctx, MODE_CONV_S2, 1, 2, ctx->enc_conv[0], c1, c2, c * 225, 31, 15, st);
         conv(ctx, MODE_CONV_S2, 2, 2, ctx->enc_conv[1], c2, c3, c * 49, 15, 7, st);
         conv(ctx, MODE_CONV_S2, 2, 2, ctx->enc_conv[2], c3, c4, c * 9, 7, 3, st);
@@ -204,6 +244,7 @@ int run_encoder(efe_ctx* ctx, const float* o, int N, const NoiseCfg& nc, float* 
         fc(ctx, ctx->enc_fc[2], hB, 256, 0, hA, 256, c, true, true, TAG_ENC + 2, nc, m0, st);
         fc(ctx, ctx->enc_fc[3], hA, 256, 0, enc + (size_t)m0 * 32, 32, c, false, false, 0, nc, m0, st);
     }
+    ctx->cls = PROF_OTHER;
     ctx->last_macs += (int64_t)N * MAC_ENC;
     return 0;
 }
@@ -213,6 +254,7 @@ int run_habit(efe_ctx* ctx, const float* s16 /*[M][16]*/, int M, float* l32 /*[M
     float* h2 = ctx->allocT<float>((size_t)M * 128);
     if (!h1 || !h2) return 1;
     NoiseCfg nc;
+    ctx->cls = PROF_OTHER;
     fc(ctx, ctx->top[0], s16, 16, 0, h1, 128, M, true, false, 0, nc, 0, st);
     fc(ctx, ctx->top[1], h1, 128, 0, h2, 128, M, true, false, 0, nc, 0, st);
     fc(ctx, ctx->top[2], h2, 128, 0, l32, 32, M, false, false, 0, nc, 0, st);
@@ -331,6 +373,7 @@ void efe_destroy(efe_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (void* p : ctx->owned) (void)hipFree(p);
     for (auto& b : ctx->arena.blocks) (void)hipFree(b.first);
     delete ctx;
@@ -433,6 +476,31 @@ int efe_commit_weights(efe_ctx* ctx) {
 }
 
 int64_t efe_last_call_macs(efe_ctx* ctx) { return ctx ? ctx->last_macs : 0; }
+
+int efe_prof_enable(efe_ctx* ctx, int on) {
+    if (!ctx) return 1;
+    ctx->prof = on != 0;
+    ctx->ev_used = 0;
+    ctx->ev_spans.clear();
+    return 0;
+}
+
+int efe_prof_classes(void) { return PROF_NCLS; }
+
+int efe_prof_read(efe_ctx* ctx, double* ms, int64_t* launches) {
+    if (!ctx || !ms || !launches) return 1;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    for (int i = 0; i < PROF_NCLS; ++i) { ms[i] = 0.0; launches[i] = 0; }
+    for (auto& sp : ctx->ev_spans) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, sp.second.first, sp.second.second));
+        ms[sp.first] += t; launches[sp.first] += 1;
+    }
+    ctx->ev_used = 0;
+    ctx->ev_spans.clear();
+    return 0;
+}
 
 // ---- network level -------------------------------------------------------------------------------------
 int efe_transition(efe_ctx* ctx, const float* pi, const float* s0, int M, const efe_noise* nz, const float* eps,

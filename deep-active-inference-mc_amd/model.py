@@ -248,11 +248,12 @@ class ActiveInferenceModel:
                     fan = shape[0] * 9 / (4 if name in ('po_net.15', 'po_net.17') else 1)
                 else:
                     fan = shape[1] * 9
-                bound = 1.15 * (3.0 / fan) ** 0.5
+                bound = (1.0 if part == 'mid' else 1.15) * (3.0 / fan) ** 0.5
                 sd[f'{name}.weight'] = (torch.rand(shape, generator=g) * 2 - 1) * bound
                 nb = shape[1] if name in _CONVT else shape[0]
                 sd[f'{name}.bias'] = (torch.rand(nb, generator=g) * 2 - 1) * 0.1
             if part == 'mid':
+                sd['ps_net.9.weight'] *= 0.3       # keep the depth recursion of imagined states bounded
                 sd['ps_net.9.bias'][10:] -= 2.0
             if part == 'down':
                 sd['qs_net.18.bias'][10:] -= 2.0
@@ -443,6 +444,21 @@ class ActiveInferenceModel:
         P, logP = e.empty(n, single_values), e.empty(n, single_values)
         e.check(e.lib.efe_action_posterior(e.ctx, _ptr(g), n, single_values, float(temperature), _ptr(P), _ptr(logP), e.stream()))
         return P, logP
+
+    PROF_CLASSES = ('transition_mlp', 'dec_dense_small', 'dec_dense_16384', 'convT1_64x64_s1', 'convT2_64x64_s2',
+                    'convT3_64x32_s2', 'final_conv_sigmoid_reduce', 'encoder', 'other')
+
+    def prof_enable(self, on=True):
+        e = self._ready()
+        e.check(e.lib.efe_prof_enable(e.ctx, 1 if on else 0))
+
+    def prof_read(self):
+        """-> {class name: (milliseconds, launches)} since the last read (synchronises)."""
+        e = self._ready()
+        n = e.lib.efe_prof_classes()
+        ms = (C.c_double * n)(); cnt = (C.c_int64 * n)()
+        e.check(e.lib.efe_prof_read(e.ctx, ms, cnt))
+        return {self.PROF_CLASSES[i]: (ms[i], cnt[i]) for i in range(n)}
 
     def last_call_macs(self):
         return int(self._engine.lib.efe_last_call_macs(self._engine.ctx))

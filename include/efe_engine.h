@@ -104,6 +104,14 @@ int efe_action_posterior(efe_ctx*, const float* sum_G /*[n_groups*n]*/, int n_gr
 /* introspection for benches: algorithmic MACs of the last EFE-level call. */
 int64_t efe_last_call_macs(efe_ctx*);
 
+/* per-kernel-class timing with HIP events recorded on the launch stream (bench.py roofline leg).
+ * classes: 0 transition MLP, 1 decoder dense 10-256-256-256, 2 decoder dense 256->16384, 3 ConvT 64->64 s1,
+ * 4 ConvT 64->64 s2, 5 ConvT 64->32 s2, 6 final conv + sigmoid + reductions, 7 encoder, 8 other.
+ * efe_prof_read synchronises the device, returns summed milliseconds and launch counts per class, and clears. */
+int efe_prof_enable(efe_ctx*, int on);
+int efe_prof_classes(void);
+int efe_prof_read(efe_ctx*, double* ms /*[classes]*/, int64_t* launches /*[classes]*/);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,10 +41,12 @@ def make_weights(seed=1234, gain=1.0):
         fan = _fan_in(name, shape)
         # dropout(0.5) doubles the second moment of kept activations, so use sqrt(3/fan) for the
         # layers that follow a dropout and sqrt(6/fan) elsewhere; overall scale via `gain`.
-        bound = gain * np.sqrt(3.0 / fan)
+        g = 1.0 if name.startswith('mid.') else gain      # transition net: keep the depth recursion contractive
+        bound = g * np.sqrt(3.0 / fan)
         w[name + '.weight'] = PX.uniform_fill(seed, shape, 2 * i, -bound, bound)
         bshape = (shape[1],) if name in CONVT else (shape[0],)
         w[name + '.bias'] = PX.uniform_fill(seed, bshape, 2 * i + 1, -0.1, 0.1)
+    w['mid.ps_net.9.weight'] *= 0.3   # bounded imagined states over >= 7 chained stages
     # final logvar halves: keep them moderate so exp(0.5*logvar) stays O(0.3)
     for k in ('mid.ps_net.9', 'down.qs_net.18'):
         w[k + '.bias'][10:] -= 2.0
