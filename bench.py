@@ -47,30 +47,45 @@ def synth_frames(n, device, seed=0):
     return fr.to(device)
 
 
-def cpu_baseline(depth, samples, target_s=15.0):
+def usable_cores():
+    """cores this process may actually use: affinity mask, capped by the cgroup CPU quota (os.cpu_count() ignores both,
+    and oversubscribing torch's intra-op pool on a quota-limited container stalls it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(depth, samples, target_s=12.0):
     """The oracle (CPU restatement of the reference's own torch op sequence, torch RNG like the reference)
     timed on this host's cores on a bounded sample of the same workload."""
     from oracle import synth
     from oracle.efe_oracle import OracleModel, TorchNoise
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
+    cores = usable_cores()
+    torch.set_num_threads(cores)
     m = OracleModel(synth.make_weights(1234, 1.15), TorchNoise())
 
-    def run(rows):
+    def run(rows, d, s):
         o = torch.from_numpy(np.repeat(synth.make_frames(5, (rows + 3) // 4), 4, axis=0)[:rows])
         pi = torch.eye(4).repeat((rows + 3) // 4, 1)[:rows]
         t = time.perf_counter()
         with torch.no_grad():
-            m.calculate_G_repeated(o, pi, depth, False, samples, 0)
+            m.calculate_G_repeated(o, pi, d, False, s, 0)
         return time.perf_counter() - t
-    run(4)                                   # warm-up (thread pools, oneDNN primitives)
-    t4 = run(4)
-    rows = int(min(128, max(4, 4 * round(target_s / max(t4, 1e-3)))))
+    run(4, 1, 1)                                   # warm-up (thread pools, oneDNN primitives)
+    t_unit = run(8, 1, 1)                          # 8 rows x 1 stage x 1 sample
+    per_row_full = t_unit / 8 * depth * samples    # estimated seconds per full rollout row
+    rows = int(min(128, max(4, target_s / max(per_row_full, 1e-4))))
     rows -= rows % 4
-    dt = run(rows)
+    print(f'[bench] cpu_baseline: {cores} threads, unit pass {t_unit:.3f}s, timing {rows} rows', file=sys.stderr, flush=True)
+    dt = run(rows, depth, samples)
     return {'value': rows / dt, 'unit': 'rollouts/s', 'cores': cores, 'kind': 'port',
             'sample': f'{rows} rows x depth {depth} x {samples} MC samples, 1 timed pass after warm-up, torch-CPU eager '
-                      f'oracle (oracle/efe_oracle.py, torch RNG), {dt:.2f} s'}
+                      f'oracle (oracle/efe_oracle.py, torch RNG like the reference), {dt:.2f} s'}
 
 
 def main():
@@ -116,9 +131,9 @@ def main():
             dist.all_gather_into_tensor(gathered, P)
         return G
 
+    print(f'[bench] rank {rank}: model ready, warm-up', file=sys.stderr, flush=True)
     for k in range(a.warmup):
         step(k)
-    macs = model.last_call_macs() if False else None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -132,6 +147,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    print(f'[bench] rank {rank}: timed region {dt:.3f}s', file=sys.stderr, flush=True)
     assert torch.isfinite(G).all()
     prof = model.prof_read() if not a.no_prof else {}
     model.prof_enable(False)
