@@ -184,7 +184,7 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
 
 // ModelDown.po_net over N rows ([group][row] batch), chunked; fused final conv + sigmoid + reductions.
 int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const NoiseCfg& nc, int reward0, int store0,
-                float* val /*[N]*/, float* po_store, hipStream_t st) {
+                float* val /*[N][16]*/, float* po_store, hipStream_t st) {
     const int C = (int)std::min<int64_t>(ctx->dec_chunk, N);
     float* hA = ctx->allocT<float>((size_t)C * 256);
     float* hB = ctx->allocT<float>((size_t)C * 256);
@@ -278,7 +278,7 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
     float* tr_all = ctx->allocT<float>((size_t)D * 2 * S * R * 32);
     float* dec_in = ctx->allocT<float>((size_t)D * 3 * S * R * 16);
     float* xbuf = ctx->allocT<float>((size_t)2 * R * 16);
-    float* val = ctx->allocT<float>((size_t)D * 3 * S * R);
+    float* val = ctx->allocT<float>((size_t)D * 3 * S * R * 16);
     float* po_store = ctx->allocT<float>((size_t)D * S * R * 4096);
     float* enc = ctx->allocT<float>((size_t)D * S * R * 32);
     float* terms_tmp = io.terms ? nullptr : ctx->allocT<float>((size_t)3 * R);
@@ -525,7 +525,7 @@ int efe_decoder(efe_ctx* ctx, const float* s, int M, const efe_noise* nz, float*
     if (!s || !nz || !po || M < 1) return ctx->fail("efe_decoder: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     float* x = ctx->allocT<float>((size_t)M * 16);
-    float* val = ctx->allocT<float>((size_t)M);
+    float* val = ctx->allocT<float>((size_t)M * 16);
     if (!x || !val) return 1;
     launch_pad16(s, x, M, S_DIM, st);
     NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;

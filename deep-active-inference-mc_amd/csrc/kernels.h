@@ -79,7 +79,7 @@ struct FinalArgs {
     GroupMap gm;
     int reward0;          // groups with pidx == 0: 1 = reward log-likelihood, 0 = Bernoulli entropy sum (others: entropy)
     int store0;           // groups with pidx == 0 store their image at slot t*S + sample
-    float* val;           // [batch] per-row scalar
+    float* val;           // [batch][16] per-row partial sums (one per 4-row strip), raw pixel sums
     float* po;            // [slots][rows_per_group][4096] stored images
 };
 
@@ -102,7 +102,7 @@ struct TransPostArgs {
 void launch_trans_post(const TransPostArgs& a, hipStream_t st);
 
 struct TermsArgs {
-    const float* val;      // [D][3S][R] decoder scalars (D1_i reward, D2A_j / D2B_j entropy sums)
+    const float* val;      // [D][3S][R][16] decoder strip partials (D1_i reward log-lik sums, D2A_j / D2B_j entropy sums)
     const float* tr;       // [D][2S][R][32]
     const float* enc;      // [D][S][R][32]
     int D, S, R;
