@@ -23,11 +23,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MAC_ROLLOUT = 6_739_934_560          # 51 encoder + 100 transition + 150 decoder passes
-MAC_CT3_ROW = 18_874_368             # ConvTranspose2d(64,32,3,s2) per decoder row: 32*32*9*64*32
+MAC_DECB_ROW = 18_874_368 + 1_179_648   # k_dec_b: ConvTranspose2d(64,32,3,s2) 32*32*9*64*32 + ConvTranspose2d(32,1,3,s1) 64*64*9*32
 PEAK_FP32_MFMA_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, fp32 in / fp32 acc
 CLASS_MACS_PER_ROW = {               # algorithmic MACs per network row, by kernel class
-    'dec_dense_16384': 256 * 16384, 'convT1_64x64_s1': 256 * 9 * 64 * 64, 'convT2_64x64_s2': 256 * 9 * 64 * 64,
-    'convT3_64x32_s2': MAC_CT3_ROW, 'final_conv_sigmoid_reduce': 4096 * 9 * 32,
+    'dec_dense_16384': 256 * 16384, 'dec_a_convT1_convT2': 2 * 256 * 9 * 64 * 64, 'dec_b_convT3_final_reduce': MAC_DECB_ROW,
 }
 
 
@@ -168,14 +167,14 @@ def main():
             'achieved_tflops_total': value * 2 * MAC_ROLLOUT / 1e12,
         }
         if prof:
-            name = 'convT3_64x32_s2'
+            name = 'dec_b_convT3_final_reduce'
             ms, n = prof[name]
             rows_per_launch = (a.steps * D * 3 * S * R) / max(n, 1)
-            ach = (2 * MAC_CT3_ROW * rows_per_launch) / (ms / max(n, 1) * 1e-3) / 1e12 if ms > 0 else 0.0
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'k_tapgemm<MODE_CONVT_S2,1,4> (ConvTranspose2d 64->32, 32x32->64x64)',
+            ach = (2 * MAC_DECB_ROW * rows_per_launch) / (ms / max(n, 1) * 1e-3) / 1e12 if ms > 0 else 0.0
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'k_dec_b (ConvTranspose2d 64->32 s2 + ConvTranspose2d 32->1 + sigmoid + per-image reduction, fused)',
                                'achieved': ach, 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TF,
                                'traffic': None, 'launches': int(n), 'avg_launch_ms': ms / max(n, 1),
-                               'flops_per_launch': 2 * MAC_CT3_ROW * rows_per_launch}
+                               'flops_per_launch': 2 * MAC_DECB_ROW * rows_per_launch}
             tot = sum(v[0] for v in prof.values())
             kern = {}
             for k_, (ms_, n_) in prof.items():

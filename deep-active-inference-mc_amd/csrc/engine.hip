@@ -182,37 +182,39 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
     return 0;
 }
 
-// ModelDown.po_net over N rows ([group][row] batch), chunked; fused final conv + sigmoid + reductions.
+// ModelDown.po_net over N rows ([group][row] batch): the three small dense layers run once over all rows, then per
+// chunk: dense 256->16384 (+dropout) -> k_dec_a (two transposed convs through LDS) -> k_dec_b (third transposed conv,
+// final conv, sigmoid and the per-image reduction, all on chip).
 int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const NoiseCfg& nc, int reward0, int store0,
-                float* val /*[N][16]*/, float* po_store, hipStream_t st) {
+                float* val /*[N]*/, float* po_store, hipStream_t st) {
     const int C = (int)std::min<int64_t>(ctx->dec_chunk, N);
-    float* hA = ctx->allocT<float>((size_t)C * 256);
-    float* hB = ctx->allocT<float>((size_t)C * 256);
+    float* hA = ctx->allocT<float>((size_t)N * 256);
+    float* hB = ctx->allocT<float>((size_t)N * 256);
     float* x4 = ctx->allocT<float>((size_t)C * 16384);
-    float* y1 = ctx->allocT<float>((size_t)C * 16384);
     float* y2 = ctx->allocT<float>((size_t)C * 65536);
-    float* y3 = ctx->allocT<float>((size_t)C * 131072);
-    if (!hA || !hB || !x4 || !y1 || !y2 || !y3) return 1;
+    if (!hA || !hB || !x4 || !y2) return 1;
+    ctx->cls = PROF_DEC_FC;
+    fc(ctx, ctx->dec_fc[0], dec_in, 16, 0, hA, 256, N, true, true, TAG_DEC + 0, nc, 0, st);
+    fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, N, true, true, TAG_DEC + 1, nc, 0, st);
+    fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, N, true, true, TAG_DEC + 2, nc, 0, st);
     for (int m0 = 0; m0 < N; m0 += C) {
         const int c = std::min(C, N - m0);
-        ctx->cls = PROF_DEC_FC;
-        fc(ctx, ctx->dec_fc[0], dec_in + (size_t)m0 * 16, 16, 0, hA, 256, c, true, true, TAG_DEC + 0, nc, m0, st);
-        fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, c, true, true, TAG_DEC + 1, nc, m0, st);
-        fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, c, true, true, TAG_DEC + 2, nc, m0, st);
         ctx->cls = PROF_DEC_FC4;
-        fc(ctx, ctx->dec_fc[3], hA, 256, 0, x4, 16384, c, true, true, TAG_DEC + 3, nc, m0, st);
-        ctx->cls = PROF_CT1;
-        conv(ctx, MODE_CONVT_S1, 2, 2, ctx->dec_ct[0], x4, y1, c * 256, 16, 0, st);
+        fc(ctx, ctx->dec_fc[3], hA + (size_t)m0 * 256, 256, 0, x4, 16384, c, true, true, TAG_DEC + 3, nc, m0, st);
         ctx->cls = PROF_CT2;
-        conv(ctx, MODE_CONVT_S2, 2, 2, ctx->dec_ct[1], y1, y2, c * 256, 16, 0, st);
-        ctx->cls = PROF_CT3;
-        conv(ctx, MODE_CONVT_S2, 1, 4, ctx->dec_ct[2], y2, y3, c * 1024, 32, 0, st);
-        ctx->cls = PROF_FINAL;
-        FinalArgs f{};
-        f.X = y3; f.wf = ctx->dec_wf; f.bias = ctx->dec_bf; f.rows = c; f.m0 = m0; f.rows_per_group = nc.rows_per_group;
-        f.gm = nc.gm; f.reward0 = reward0; f.store0 = store0; f.val = val; f.po = po_store;
+        DecAArgs da{};
+        da.x4 = x4; da.y2 = y2; da.w1 = ctx->dec_ct[0].Wp; da.b1 = ctx->dec_ct[0].bias; da.w2 = ctx->dec_ct[1].Wp;
+        da.b2 = ctx->dec_ct[1].bias; da.rows = c;
         hipEvent_t e0 = ctx->prof_begin(st);
-        launch_final(f, st);
+        launch_dec_a(da, st);
+        ctx->prof_end(e0, st);
+        ctx->cls = PROF_CT3;
+        DecBArgs db{};
+        db.y2 = y2; db.w3 = ctx->dec_ct[2].Wp; db.b3 = ctx->dec_ct[2].bias; db.w4 = ctx->dec_wf; db.b4 = ctx->dec_bf;
+        db.rows = c; db.m0 = m0; db.rows_per_group = nc.rows_per_group; db.gm = nc.gm; db.reward0 = reward0; db.store0 = store0;
+        db.val = val; db.po = po_store;
+        e0 = ctx->prof_begin(st);
+        launch_dec_b(db, st);
         ctx->prof_end(e0, st);
     }
     ctx->cls = PROF_OTHER;
@@ -278,7 +280,7 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
     float* tr_all = ctx->allocT<float>((size_t)D * 2 * S * R * 32);
     float* dec_in = ctx->allocT<float>((size_t)D * 3 * S * R * 16);
     float* xbuf = ctx->allocT<float>((size_t)2 * R * 16);
-    float* val = ctx->allocT<float>((size_t)D * 3 * S * R * 16);
+    float* val = ctx->allocT<float>((size_t)D * 3 * S * R);
     float* po_store = ctx->allocT<float>((size_t)D * S * R * 4096);
     float* enc = ctx->allocT<float>((size_t)D * S * R * 32);
     float* terms_tmp = io.terms ? nullptr : ctx->allocT<float>((size_t)3 * R);
@@ -525,7 +527,7 @@ int efe_decoder(efe_ctx* ctx, const float* s, int M, const efe_noise* nz, float*
     if (!s || !nz || !po || M < 1) return ctx->fail("efe_decoder: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     float* x = ctx->allocT<float>((size_t)M * 16);
-    float* val = ctx->allocT<float>((size_t)M * 16);
+    float* val = ctx->allocT<float>((size_t)M);
     if (!x || !val) return 1;
     launch_pad16(s, x, M, S_DIM, st);
     NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;

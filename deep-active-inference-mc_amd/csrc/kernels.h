@@ -69,22 +69,31 @@ struct GemmArgs {
     int m0;               // index of column 0 of this launch inside the [group][row] batch
 };
 
-struct FinalArgs {
-    const float* X;       // [rows][64][64][32] NHWC output of the 3rd transposed conv
-    const float* wf;      // [9][32] tap-major weights of ConvTranspose2d(32,1,3,1,1)
-    float bias;
-    int rows;             // decoder rows in this launch
+// fused decoder, stage A: x4 [rows][16][16][64] -> ConvT(64,64,s1)+ReLU -> ConvT(64,64,s2)+ReLU -> y2 [rows][32][32][64]
+struct DecAArgs {
+    const float* x4; float* y2;
+    const float* w1; const float* b1;   // packed [9][2][8][64][4], bias [64]
+    const float* w2; const float* b2;
+    int rows;
+};
+// fused decoder, stage B: y2 -> ConvT(64,32,s2)+ReLU -> ConvT(32,1,s1)+Sigmoid -> per-image reduction (+ image store)
+struct DecBArgs {
+    const float* y2;
+    const float* w3; const float* b3;   // packed [9][1][8][64][4], bias [32]
+    const float* w4; float b4;          // [9 taps][32 ch], scalar bias
+    int rows;             // decoder rows (images) in this launch
     int m0;               // index of row 0 inside the [group][row] batch
     int rows_per_group;
     GroupMap gm;
     int reward0;          // groups with pidx == 0: 1 = reward log-likelihood, 0 = Bernoulli entropy sum (others: entropy)
     int store0;           // groups with pidx == 0 store their image at slot t*S + sample
-    float* val;           // [batch][16] per-row partial sums (one per 4-row strip), raw pixel sums
+    float* val;           // [batch] per-image pixel sum (entropy sum, or log-likelihood sum)
     float* po;            // [slots][rows_per_group][4096] stored images
 };
+void launch_dec_a(const DecAArgs& a, hipStream_t st);
+void launch_dec_b(const DecBArgs& a, hipStream_t st);
 
 void launch_tapgemm(int mode, int MT, int NT, const GemmArgs& a, hipStream_t st);
-void launch_final(const FinalArgs& a, hipStream_t st);
 void launch_enc_conv1(const float* o, const float* w1, const float* b1, float* y, int rows, hipStream_t st);
 
 struct TransPostArgs {
@@ -102,7 +111,7 @@ struct TransPostArgs {
 void launch_trans_post(const TransPostArgs& a, hipStream_t st);
 
 struct TermsArgs {
-    const float* val;      // [D][3S][R][16] decoder strip partials (D1_i reward log-lik sums, D2A_j / D2B_j entropy sums)
+    const float* val;      // [D][3S][R] decoder per-image pixel sums (D1_i reward log-lik, D2A_j / D2B_j entropy)
     const float* tr;       // [D][2S][R][32]
     const float* enc;      // [D][S][R][32]
     int D, S, R;

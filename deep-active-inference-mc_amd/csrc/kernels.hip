@@ -166,93 +166,10 @@ void launch_tapgemm(int mode, int MT, int NT, const GemmArgs& a, hipStream_t st)
     EFE_CASE(MODE_FC, 1, 2)
     EFE_CASE(MODE_FC, 2, 2)
     EFE_CASE(MODE_FC, 4, 2)
-    EFE_CASE(MODE_CONVT_S1, 2, 2)
-    EFE_CASE(MODE_CONVT_S2, 2, 2)
-    EFE_CASE(MODE_CONVT_S2, 1, 4)
     EFE_CASE(MODE_CONV_S2, 1, 2)
     EFE_CASE(MODE_CONV_S2, 2, 2)
 #undef EFE_CASE
     abort();
-}
-
-// ---------------------------------------------------------------------------------------------
-// ConvTranspose2d(32,1,3,1,1) + Sigmoid (torchmodel.py:126-127) fused with the per-row reductions
-// that consume it: Bernoulli entropy sum (torchutils.py:26-27, torchmodel.py:289,292) or the reward
-// log-likelihood (torchutils.py:30-37, torchmodel.py:210-212).  One workgroup per decoder row.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// LDS tile: 6 input rows (4 output rows + halo) x 66 columns (zero column each side) x 36 floats
-// (32 channels + 4 pad: 16-lane ds_read_b128 groups then hit 16 distinct 16-byte slots).
-constexpr int FIN_ROWS = 4, FIN_W = 66, FIN_PS = 36;
-__global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sx[];      // [6][66][36]
-    __shared__ float sred[4];
-    const int row = blockIdx.x >> 4, strip = blockIdx.x & 15;
-    const int mg = a.m0 + row;
-    const int g = mg / a.rows_per_group;
-    const int r = mg - g * a.rows_per_group;
-    int gt, gp, gs;
-    group_decode(a.gm, g, gt, gp, gs);
-    const int mode = (gp == 0 && a.reward0) ? 1 : 0;
-    const int slot = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
-    const float* X = a.X + (size_t)row * (64 * 64 * 32);
-
-    // ---- stage rows 4*strip-1 .. 4*strip+4 (zero outside the image), coalesced 16-byte loads
-    const int ih0 = strip * FIN_ROWS - 1;
-#pragma unroll
-    for (int it = 0; it < 12; ++it) {
-        const int idx = it * 256 + threadIdx.x;          // 0..3071 float4s = 6 rows x 64 px x 8
-        const int rl = idx >> 9, rem = idx & 511, px = rem >> 3, c4 = rem & 7;
-        const int ih = ih0 + rl;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ih >= 0 && ih < 64) v = *reinterpret_cast<const float4*>(X + ((size_t)ih * 64 + px) * 32 + c4 * 4);
-        *reinterpret_cast<float4*>(sx + ((rl * FIN_W) + px + 1) * FIN_PS + c4 * 4) = v;
-    }
-    if (threadIdx.x < 6 * 2 * 8) {                        // the two zero columns
-        const int rl = threadIdx.x / 16, rem = threadIdx.x % 16, side = rem >> 3, c4 = rem & 7;
-        *reinterpret_cast<float4*>(sx + ((rl * FIN_W) + (side ? FIN_W - 1 : 0)) * FIN_PS + c4 * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-
-    const int rr = threadIdx.x >> 6, ow = threadIdx.x & 63;
-    const int oh = strip * FIN_ROWS + rr;
-    float s = a.bias;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            // out[oh,ow] += X[oh+1-kh, ow+1-kw, :] . W[:,0,kh,kw]; tile row = (oh+1-kh) - ih0, tile col = (ow+1-kw) + 1
-            const float4* xp = reinterpret_cast<const float4*>(sx + (((rr + 2 - kh) * FIN_W) + (ow + 2 - kw)) * FIN_PS);
-            const float* wp = a.wf + (kh * 3 + kw) * 32;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float4 x = xp[c];
-                s = fmaf(x.x, wp[c * 4 + 0], s); s = fmaf(x.y, wp[c * 4 + 1], s);
-                s = fmaf(x.z, wp[c * 4 + 2], s); s = fmaf(x.w, wp[c * 4 + 3], s);
-            }
-        }
-    }
-    const float pr = 1.0f / (1.0f + expf(-s));
-    if (slot >= 0) a.po[((size_t)slot * a.rows_per_group + r) * 4096 + oh * 64 + ow] = pr;
-    // fp32 constants of log_bernoulli / entropy_bernoulli: (1e-5 + 1) is rounded to fp32 first
-    const float D1 = 1.00001f, D0 = 0.00001f;
-    float part;
-    if (mode == 0) part = -(1.0f - pr) * logf(D1 - pr) - pr * logf(D0 + pr);
-    else           // target = 1 for image rows h < 32, 0 below (NCHW broadcast of the port)
-        part = (oh < 32) ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f) : pr * logf(D0) + (1.0f - pr) * logf(D1);
-    part = wave_sum(part);
-    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = part;
-    __syncthreads();
-    if (threadIdx.x == 0) a.val[(size_t)mg * 16 + strip] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
-}
-
-void launch_final(const FinalArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_final, dim3(a.rows * 16), dim3(256), 6 * FIN_W * FIN_PS * sizeof(float), st, a);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -340,13 +257,6 @@ void launch_trans_post(const TransPostArgs& a, hipStream_t st) {
 // EFE term combine (torchmodel.py:278-298).  Thread = batch row; the loops
 // over samples and stages run in the reference's order so fp32 rounding follows it.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sum16(const float* p) {      // fixed-order sum of the 16 strip partials of one image
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s += p[i];
-    return s;
-}
-
 __global__ void k_terms(const TermsArgs a) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.R) return;
@@ -354,10 +264,10 @@ __global__ void k_terms(const TermsArgs a) {
     const float C = 2.8378770664093453f;   // log(2*pi*e), torchutils.py:19
     float sG = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, p1 = 0.f, p2 = 0.f;
     for (int t = 0; t < a.D; ++t) {
-        const float* val = a.val + (size_t)t * 3 * S * R * 16;
+        const float* val = a.val + (size_t)t * 3 * S * R;
         float t0 = 0.f, t1 = 0.f, t21 = 0.f, t22 = 0.f;
         for (int i = 0; i < S; ++i) {
-            t0 += sum16(val + ((size_t)i * R + r) * 16) * (1.0f / 4096.0f) * 10.0f;   // mean over pixels * 10 (torchmodel.py:212)
+            t0 += val[(size_t)i * R + r] * (1.0f / 4096.0f) * 10.0f;   // mean over pixels * 10 (torchmodel.py:212)
             const float* tr = a.tr + (((size_t)t * 2 * S + i) * R + r) * 32 + 10;
             const float* en = a.enc + (((size_t)t * S + i) * R + r) * 32 + 10;
             float h = 0.f;
@@ -366,8 +276,8 @@ __global__ void k_terms(const TermsArgs a) {
         }
         t0 /= (float)S; t1 /= (float)S;
         for (int jj = 0; jj < S; ++jj) {
-            t21 += sum16(val + ((size_t)(S + jj) * R + r) * 16);
-            t22 += sum16(val + ((size_t)(2 * S + jj) * R + r) * 16);
+            t21 += val[(size_t)(S + jj) * R + r];
+            t22 += val[(size_t)(2 * S + jj) * R + r];
         }
         t21 /= (float)S; t22 /= (float)S;
         const float t2 = t21 - t22;

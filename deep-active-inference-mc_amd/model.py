@@ -445,8 +445,8 @@ class ActiveInferenceModel:
         e.check(e.lib.efe_action_posterior(e.ctx, _ptr(g), n, single_values, float(temperature), _ptr(P), _ptr(logP), e.stream()))
         return P, logP
 
-    PROF_CLASSES = ('transition_mlp', 'dec_dense_small', 'dec_dense_16384', 'convT1_64x64_s1', 'convT2_64x64_s2',
-                    'convT3_64x32_s2', 'final_conv_sigmoid_reduce', 'encoder', 'other')
+    PROF_CLASSES = ('transition_mlp', 'dec_dense_small', 'dec_dense_16384', 'unused3', 'dec_a_convT1_convT2',
+                    'dec_b_convT3_final_reduce', 'unused6', 'encoder', 'other')
 
     def prof_enable(self, on=True):
         e = self._ready()

@@ -105,8 +105,9 @@ int efe_action_posterior(efe_ctx*, const float* sum_G /*[n_groups*n]*/, int n_gr
 int64_t efe_last_call_macs(efe_ctx*);
 
 /* per-kernel-class timing with HIP events recorded on the launch stream (bench.py roofline leg).
- * classes: 0 transition MLP, 1 decoder dense 10-256-256-256, 2 decoder dense 256->16384, 3 ConvT 64->64 s1,
- * 4 ConvT 64->64 s2, 5 ConvT 64->32 s2, 6 final conv + sigmoid + reductions, 7 encoder, 8 other.
+ * classes: 0 transition MLP, 1 decoder dense 10-256-256-256, 2 decoder dense 256->16384, 3 unused,
+ * 4 k_dec_a (ConvT 64->64 s1 + ConvT 64->64 s2), 5 k_dec_b (ConvT 64->32 s2 + final conv + sigmoid + reductions),
+ * 6 unused, 7 encoder, 8 other.
  * efe_prof_read synchronises the device, returns summed milliseconds and launch counts per class, and clears. */
 int efe_prof_enable(efe_ctx*, int on);
 int efe_prof_classes(void);
