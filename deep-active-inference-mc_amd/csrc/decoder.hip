@@ -17,6 +17,7 @@
 namespace efe {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: plain loads/stores, no struct memcpy
 
 #define MFMA4(ACC, AV, BV)                                                      \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, (BV).x, ACC, 0, 0, 0);   \
@@ -25,6 +26,53 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, (BV).w, ACC, 0, 0, 0);
 
 __device__ __forceinline__ int swz(int pix, int c4) { return pix * 16 + (c4 ^ (pix & 15)); }   // float4 index
+
+// Software-pipelined contraction over `ntaps` taps x 64 input channels (8 chunks of 8): the A fragments (weights,
+// L2) and B fragments (activations, LDS) of chunk i+1 are requested before the MFMAs of chunk i issue, so neither
+// latency is exposed (hipcc otherwise waits for each chunk's loads right before its first MFMA).
+// addr(t, base[NT], sw[NT], wtap): LDS float4 base + swizzle key of every pixel tile and the packed-weight tap index.
+template <int MT, int NT, class AddrFn>
+__device__ __forceinline__ void tap_loop(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
+                                         const float4* sm, const int h, AddrFn addr) {
+    int bs[NT], sw[NT], wt;
+    addr(0, bs, sw, wt);
+    float4 av[MT], bv[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) av[mt] = Wl[(size_t)((wt * MT + mt) * 8) * 64];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = sm[bs[nt] + (h ^ sw[nt])];
+    for (int t = 0; t < ntaps; ++t) {
+        int nbs[NT], nsw[NT], nwt;
+        addr((t + 1 < ntaps) ? t + 1 : t, nbs, nsw, nwt);
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            float4 an[MT], bn[NT];
+            if (kc < 7) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) an[mt] = Wl[(size_t)((wt * MT + mt) * 8 + kc + 1) * 64];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[bs[nt] + ((2 * (kc + 1) + h) ^ sw[nt])];
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) an[mt] = Wl[(size_t)((nwt * MT + mt) * 8) * 64];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[nbs[nt] + (h ^ nsw[nt])];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch loads AHEAD of this chunk's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { MFMA4(acc[mt][nt], av[mt], bv[nt]) }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = an[mt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { bs[nt] = nbs[nt]; sw[nt] = nsw[nt]; }
+        wt = nwt;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // k_dec_a: ConvTranspose2d(64,64,3,s1,p1)+ReLU then ConvTranspose2d(64,64,3,s2,p1,op1)+ReLU, one image per WG.
@@ -35,132 +83,126 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int img = blockIdx.x;
-
-    {   // stage the 16x16x64 input image (64 KiB), fully coalesced
-        const float4* X = reinterpret_cast<const float4*>(a.x4) + (size_t)img * 4096;
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int idx = it * 256 + tid;
-            const int pix = idx >> 4, c4 = idx & 15;
-            sm[swz(pix, c4)] = X[idx];
-        }
-        if (tid < 16) sm[256 * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
 
     // this wave's 64 pixels / input positions: image rows 4w .. 4w+3, two 32-pixel tiles of two rows each
-    int prow[2], pcol;
-    pcol = j & 15;
-    prow[0] = 4 * w + (j >> 4);
-    prow[1] = 4 * w + 2 + (j >> 4);
-
-    f32x16 acc[2][2];
-    // ---------------- layer 1: out[oh,ow] = sum_{kh,kw} in[oh+1-kh, ow+1-kw] . W[:, :, kh, kw] ------------------
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
-    {
-        const float4* W = reinterpret_cast<const float4*>(a.w1) + lane;
-        for (int t = 0; t < 9; ++t) {
-            const int kh = t / 3, kw = t - kh * 3;
-            int base[2], sw[2];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int sy = prow[nt] + 1 - kh, sx = pcol + 1 - kw;
-                const bool ok = sy >= 0 && sy < 16 && sx >= 0 && sx < 16;
-                const int sp = ok ? sy * 16 + sx : 256;
-                base[nt] = sp * 16; sw[nt] = sp & 15;
-            }
-            const float4* wt = W + (size_t)(t * 2) * 8 * 64;             // [tap][mtile 0..1][kc 0..7][lane]
-#pragma unroll 2
-            for (int kc = 0; kc < 8; ++kc) {
-                const float4 a0 = wt[(0 * 8 + kc) * 64], a1 = wt[(1 * 8 + kc) * 64];
-                const float4 b0 = sm[base[0] + ((2 * kc + h) ^ sw[0])];
-                const float4 b1 = sm[base[1] + ((2 * kc + h) ^ sw[1])];
-                MFMA4(acc[0][0], a0, b0) MFMA4(acc[0][1], a0, b1)
-                MFMA4(acc[1][0], a1, b0) MFMA4(acc[1][1], a1, b1)
-            }
-        }
-    }
-    __syncthreads();            // every wave is done reading the input image
-    // bias + ReLU, written back IN PLACE as the input image of layer 2 (same swizzled layout)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int pix = 64 * w + 32 * nt + j;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int c4 = mt * 8 + 2 * g4 + h;
-                const float4 bb = reinterpret_cast<const float4*>(a.b1)[c4];
-                float4 v;
-                v.x = fmaxf(acc[mt][nt][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[mt][nt][4 * g4 + 1] + bb.y, 0.f);
-                v.z = fmaxf(acc[mt][nt][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[mt][nt][4 * g4 + 3] + bb.w, 0.f);
-                sm[swz(pix, c4)] = v;
-            }
-    }
-    __syncthreads();
-
-    // ---------------- layer 2 (stride 2): 4 output parities, oh = 2*ih - 1 + kh --------------------------------
-    float* Y = a.y2 + (size_t)img * (32 * 32 * 64);
+    const int pcol = j & 15;
+    const int prow0 = 4 * w + (j >> 4);                                // tile nt covers rows prow0 + 2*nt
+    const float4* W1 = reinterpret_cast<const float4*>(a.w1) + lane;
     const float4* W2 = reinterpret_cast<const float4*>(a.w2) + lane;
-    for (int par = 0; par < 4; ++par) {
-        const int ph = par >> 1, pw = par & 1;
+
+    if ((int)blockIdx.x >= a.rows) return;
+    f32x4 pfa[8], pfb[8];                                              // next image, in flight during compute
+    f32x4* smv = reinterpret_cast<f32x4*>(sm);
+    {
+        const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)blockIdx.x * 4096;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) { pfa[it] = X[it * 256 + tid]; pfb[it] = X[(it + 8) * 256 + tid]; }
+    }
+    if (tid < 16) sm[256 * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
+        // stage the 16x16x64 input image (64 KiB) into the swizzled LDS layout
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tid, idx2 = idx + 2048;
+            smv[swz(idx >> 4, idx & 15)] = pfa[it];
+            smv[swz(idx2 >> 4, idx2 & 15)] = pfb[it];
+        }
+        __syncthreads();
+        const int nimg = img + gridDim.x;
+        const bool more = nimg < a.rows;
+        {   // request the next image now (clamped on the last pass: unconditional loads keep pf[] in registers)
+            const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)(more ? nimg : img) * 4096;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) { pfa[it] = X[it * 256 + tid]; pfb[it] = X[(it + 8) * 256 + tid]; }
+        }
+
+        f32x16 acc[2][2];
+        // ---------------- layer 1: out[oh,ow] = sum_{kh,kw} in[oh+1-kh, ow+1-kw] . W[:, :, kh, kw] --------------
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
-        const int ntaps = (1 + ph) * (1 + pw);
-        for (int t = 0; t < ntaps; ++t) {
-            const int th = t / (1 + pw), tw = t - th * (1 + pw);
-            const int kh = ph ? (th ? 2 : 0) : 1, da = (ph && th == 0) ? 1 : 0;
-            const int kw = pw ? (tw ? 2 : 0) : 1, db = (pw && tw == 0) ? 1 : 0;
-            int base[2], sw[2];
+        tap_loop<2, 2>(acc, 9, W1, sm, h, [&](int t, int (&bs)[2], int (&sw)[2], int& wt) {
+            const int kh = t / 3, kw = t - kh * 3;
+            wt = t;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int sy = prow[nt] + da, sx = pcol + db;
-                const bool ok = sy < 16 && sx < 16;
+                const int sy = prow0 + 2 * nt + 1 - kh, sx = pcol + 1 - kw;
+                const bool ok = sy >= 0 && sy < 16 && sx >= 0 && sx < 16;
                 const int sp = ok ? sy * 16 + sx : 256;
-                base[nt] = sp * 16; sw[nt] = sp & 15;
+                bs[nt] = sp * 16; sw[nt] = sp & 15;
             }
-            const float4* wt = W2 + (size_t)((kh * 3 + kw) * 2) * 8 * 64;
-#pragma unroll 2
-            for (int kc = 0; kc < 8; ++kc) {
-                const float4 a0 = wt[(0 * 8 + kc) * 64], a1 = wt[(1 * 8 + kc) * 64];
-                const float4 b0 = sm[base[0] + ((2 * kc + h) ^ sw[0])];
-                const float4 b1 = sm[base[1] + ((2 * kc + h) ^ sw[1])];
-                MFMA4(acc[0][0], a0, b0) MFMA4(acc[0][1], a0, b1)
-                MFMA4(acc[1][0], a1, b0) MFMA4(acc[1][1], a1, b1)
-            }
-        }
+        });
+        __syncthreads();            // every wave is done reading the input image
+        // bias + ReLU, written back IN PLACE as the input image of layer 2 (same swizzled layout)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            float* yp = Y + ((size_t)(2 * prow[nt] + ph) * 32 + (2 * pcol + pw)) * 64;
+            const int pix = 64 * w + 32 * nt + j;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int c4 = mt * 8 + 2 * g4 + h;
-                    const float4 bb = reinterpret_cast<const float4*>(a.b2)[c4];
+                    const float4 bb = reinterpret_cast<const float4*>(a.b1)[c4];
                     float4 v;
                     v.x = fmaxf(acc[mt][nt][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[mt][nt][4 * g4 + 1] + bb.y, 0.f);
                     v.z = fmaxf(acc[mt][nt][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[mt][nt][4 * g4 + 3] + bb.w, 0.f);
-                    reinterpret_cast<float4*>(yp)[c4] = v;
+                    sm[swz(pix, c4)] = v;
                 }
         }
+        __syncthreads();
+
+        // ---------------- layer 2 (stride 2): 4 output parities, oh = 2*ih - 1 + kh ----------------------------
+        float* Y = a.y2 + (size_t)img * (32 * 32 * 64);
+#pragma unroll 1
+        for (int par = 0; par < 4; ++par) {
+            const int ph = par >> 1, pw = par & 1;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+            tap_loop<2, 2>(acc, (1 + ph) * (1 + pw), W2, sm, h, [&](int t, int (&bs)[2], int (&sw)[2], int& wt) {
+                const int th = t / (1 + pw), tw = t - th * (1 + pw);
+                const int kh = ph ? (th ? 2 : 0) : 1, da = (ph && th == 0) ? 1 : 0;
+                const int kw = pw ? (tw ? 2 : 0) : 1, db = (pw && tw == 0) ? 1 : 0;
+                wt = kh * 3 + kw;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int sy = prow0 + 2 * nt + da, sx = pcol + db;
+                    const int sp = (sy < 16 && sx < 16) ? sy * 16 + sx : 256;
+                    bs[nt] = sp * 16; sw[nt] = sp & 15;
+                }
+            });
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float* yp = Y + ((size_t)(2 * (prow0 + 2 * nt) + ph) * 32 + (2 * pcol + pw)) * 64;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int c4 = mt * 8 + 2 * g4 + h;
+                        const float4 bb = reinterpret_cast<const float4*>(a.b2)[c4];
+                        float4 v;
+                        v.x = fmaxf(acc[mt][nt][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[mt][nt][4 * g4 + 1] + bb.y, 0.f);
+                        v.z = fmaxf(acc[mt][nt][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[mt][nt][4 * g4 + 3] + bb.w, 0.f);
+                        reinterpret_cast<float4*>(yp)[c4] = v;
+                    }
+            }
+        }
+        __syncthreads();            // every wave is done reading layer-1's image before the next one overwrites it
     }
 }
 
 void launch_dec_a(const DecAArgs& a, hipStream_t st) {
     static bool once = false;
     if (!once) { (void)hipFuncSetAttribute((const void*)k_dec_a, hipFuncAttributeMaxDynamicSharedMemorySize, 257 * 16 * sizeof(float4)); once = true; }
-    hipLaunchKernelGGL(k_dec_a, dim3(a.rows), dim3(256), 257 * 16 * sizeof(float4), st, a);
+    const int grid = a.rows < 512 ? a.rows : 512;         // persistent: 2 workgroups per CU, images strided by the grid
+    hipLaunchKernelGGL(k_dec_a, dim3(grid), dim3(256), 257 * 16 * sizeof(float4), st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -213,19 +255,30 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
     const float4* W3 = reinterpret_cast<const float4*>(a.w3) + lane;
     const float D1 = 1.00001f, D0 = 0.00001f;      // fp32 constants of log_bernoulli / entropy_bernoulli
     float part = 0.f;
+    f32x4 pf[10];                                                      // input strip in flight
+    f32x4* smv = reinterpret_cast<f32x4*>(sm);
+    const f32x4* Xv = reinterpret_cast<const f32x4*>(X);
+#pragma unroll
+    for (int it = 0; it < 10; ++it) pf[it] = Xv[it * 256 + tid];       // strip 0 = rows 0..4 (contiguous)
 
     for (int s = 0; s < 8; ++s) {
-        // ---- stage input rows 4s .. 4s+4 (row 32 does not exist: zeros)
+        // ---- stage input rows 4s .. 4s+4 (row 32 does not exist: zeros); the data was requested one strip earlier
 #pragma unroll
         for (int it = 0; it < 10; ++it) {
             const int idx = it * 256 + tid;                            // 0..2559 = 5 rows x 32 px x 16 quads
-            const int rl = idx >> 9, rem = idx & 511, px = rem >> 4, c4 = rem & 15;
-            const int grow = 4 * s + rl;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (grow < 32) v = X[((size_t)grow * 32 + px) * 16 + c4];
-            sm[swz(rl * 32 + px, c4)] = v;
+            const int rl = idx >> 9, rem = idx & 511;
+            smv[swz(rl * 32 + (rem >> 4), rem & 15)] = (4 * s + rl < 32) ? pf[it] : (f32x4)(0.f);
         }
         __syncthreads();
+        {   // request strip s+1 now (it lands during the MFMA phase); rows >= 32 are clamped here and zeroed when staged
+            const int sn = (s < 7) ? s + 1 : 7;
+#pragma unroll
+            for (int it = 0; it < 10; ++it) {
+                const int idx = it * 256 + tid;
+                const int grow = min(4 * sn + (idx >> 9), 31);
+                pf[it] = Xv[(size_t)grow * 512 + (idx & 511)];
+            }
+        }
 
         // ---- MFMA phase: wave (rp, pg) owns local rows 2rp, 2rp+1 and two of the four output parities
 #pragma unroll 1
@@ -237,27 +290,19 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
-            const int ntaps = (1 + ph) * (1 + pw);
-            for (int t = 0; t < ntaps; ++t) {
+            f32x16 (&acc1)[1][2] = reinterpret_cast<f32x16 (&)[1][2]>(acc);
+            tap_loop<1, 2>(acc1, (1 + ph) * (1 + pw), W3, sm, h, [&](int t, int (&bs)[2], int (&sw)[2], int& wt) {
                 const int th = t / (1 + pw), tw = t - th * (1 + pw);
                 const int kh = ph ? (th ? 2 : 0) : 1, da = (ph && th == 0) ? 1 : 0;
                 const int kw = pw ? (tw ? 2 : 0) : 1, db = (pw && tw == 0) ? 1 : 0;
-                int base[2], sw[2];
+                wt = kh * 3 + kw;
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
                     const int sx = j + db;
                     const int sp = (sx < 32) ? (2 * rp + nt + da) * 32 + sx : DB_ZERO;
-                    base[nt] = sp * 16; sw[nt] = sp & 15;
+                    bs[nt] = sp * 16; sw[nt] = sp & 15;
                 }
-                const float4* wt = W3 + (size_t)(kh * 3 + kw) * 8 * 64;      // [tap][kc][lane], one 32-channel tile
-#pragma unroll 4
-                for (int kc = 0; kc < 8; ++kc) {
-                    const float4 a0 = wt[kc * 64];
-                    const float4 b0 = sm[base[0] + ((2 * kc + h) ^ sw[0])];
-                    const float4 b1 = sm[base[1] + ((2 * kc + h) ^ sw[1])];
-                    MFMA4(acc[0], a0, b0) MFMA4(acc[1], a0, b1)
-                }
-            }
+            });
             // ---- bias + ReLU in registers, then contract channels against the 9 taps of the final conv
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
