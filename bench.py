@@ -96,6 +96,7 @@ def main():
     ap.add_argument('--samples', type=int, default=10)
     ap.add_argument('--depth', type=int, default=5)
     ap.add_argument('--dec-chunk', type=int, default=0)
+    ap.add_argument('--opt', action='append', default=[], help='engine option name=value')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-prof', action='store_true')
     a = ap.parse_args()
@@ -118,16 +119,18 @@ def main():
     model = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device=device, seed=1, row_offset=rank * R)
     if a.dec_chunk:
         model.set_option('dec_chunk', a.dec_chunk)
+    for kv in a.opt:
+        k_, v_ = kv.split('=')
+        model.set_option(k_, int(v_))
     frames = synth_frames(R // 4, device, seed=100 + rank)
     o = frames.repeat_interleave(4, dim=0).contiguous()          # row 4i+a = (root i, action a), util.py:56-60
     pi = torch.eye(4, device=device).repeat(R // 4, 1).contiguous()
-    gathered = torch.empty(world * (R // 4), 4, device=device) if world > 1 else None
 
     def step(k):
         G, _, _ = model.calculate_G_repeated(o, pi, steps=D, samples=S, stage=k * D)
         P, _ = model.action_posterior(G)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, P)
+            daimc_amd.gather_action_posteriors(P, world * (R // 4))      # the only RCCL traffic: [R/4, 4] floats per rank
         return G
 
     print(f'[bench] rank {rank}: model ready, warm-up', file=sys.stderr, flush=True)

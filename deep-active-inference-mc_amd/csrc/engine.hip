@@ -52,7 +52,7 @@ struct efe_ctx {
     float* zeros = nullptr;
     std::vector<void*> owned;
     Arena arena;
-    int64_t dec_chunk = 1024, enc_chunk = 4096;
+    int64_t dec_chunk = 8192, enc_chunk = 8192, fc4_mt = 2, dbg_a = 0, dbg_b = 0;
     int64_t last_macs = 0;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
     bool prof = false;
@@ -153,8 +153,16 @@ void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float*
     a.n_pix = M; a.cin = L.cin; a.cout = L.cout; a.mtiles = L.mtiles; a.ldx = ldx; a.ldy = ldy; a.x_mod = x_mod;
     a.relu = relu; a.dropout = drop; a.tag = tag; a.k0 = nc.k0; a.k1 = nc.k1; a.gm = nc.gm;
     a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = m0;
+    // tile shape by problem size: small launches (transition / habit / encoder head) use 32x32 wave tiles so that the
+    // grid still covers the 256 CUs; the big 256->16384 layer takes the largest feature tile (fewest activation re-reads)
+    int MT = L.mtiles == 1 ? 1 : 2, NT = 2;
+    if (L.mtiles >= 64) MT = (int)ctx->fc4_mt;
+    else {
+        const long tiles22 = (long)((L.mtiles + MT - 1) / MT) * ((M + 63) / 64);
+        if (tiles22 < 2048) { NT = 1; if (tiles22 * 2 < 2048) MT = 1; }
+    }
     hipEvent_t e0 = ctx->prof_begin(st);
-    launch_tapgemm(MODE_FC, L.mtiles == 1 ? 1 : 2, 2, a, st);
+    launch_tapgemm(MODE_FC, MT, NT, a, st);
     ctx->prof_end(e0, st);
 }
 
@@ -204,7 +212,7 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         ctx->cls = PROF_CT2;
         DecAArgs da{};
         da.x4 = x4; da.y2 = y2; da.w1 = ctx->dec_ct[0].Wp; da.b1 = ctx->dec_ct[0].bias; da.w2 = ctx->dec_ct[1].Wp;
-        da.b2 = ctx->dec_ct[1].bias; da.rows = c;
+        da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.dbg = (int)ctx->dbg_a;
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_dec_a(da, st);
         ctx->prof_end(e0, st);
@@ -212,7 +220,7 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         DecBArgs db{};
         db.y2 = y2; db.w3 = ctx->dec_ct[2].Wp; db.b3 = ctx->dec_ct[2].bias; db.w4 = ctx->dec_wf; db.b4 = ctx->dec_bf;
         db.rows = c; db.m0 = m0; db.rows_per_group = nc.rows_per_group; db.gm = nc.gm; db.reward0 = reward0; db.store0 = store0;
-        db.val = val; db.po = po_store;
+        db.val = val; db.po = po_store; db.dbg = (int)ctx->dbg_b;
         e0 = ctx->prof_begin(st);
         launch_dec_b(db, st);
         ctx->prof_end(e0, st);
@@ -397,6 +405,9 @@ int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const 
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return 1;
     if (!strcmp(name, "dec_chunk")) { if (value < 1) return ctx->fail("dec_chunk < 1"); ctx->dec_chunk = value; return 0; }
+    if (!strcmp(name, "fc4_mt")) { if (value != 2 && value != 4) return ctx->fail("fc4_mt must be 2 or 4"); ctx->fc4_mt = value; return 0; }
+    if (!strcmp(name, "dbg_a")) { ctx->dbg_a = value; return 0; }
+    if (!strcmp(name, "dbg_b")) { ctx->dbg_b = value; return 0; }
     if (!strcmp(name, "enc_chunk")) { if (value < 1) return ctx->fail("enc_chunk < 1"); ctx->enc_chunk = value; return 0; }
     return ctx->fail(std::string("unknown option ") + name);
 }

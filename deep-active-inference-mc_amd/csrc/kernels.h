@@ -75,6 +75,7 @@ struct DecAArgs {
     const float* w1; const float* b1;   // packed [9][2][8][64][4], bias [64]
     const float* w2; const float* b2;
     int rows;
+    int dbg;              // timing experiments only (0 in production): 1 = skip y2 stores, 2 = skip next-image prefetch
 };
 // fused decoder, stage B: y2 -> ConvT(64,32,s2)+ReLU -> ConvT(32,1,s1)+Sigmoid -> per-image reduction (+ image store)
 struct DecBArgs {
@@ -89,6 +90,7 @@ struct DecBArgs {
     int store0;           // groups with pidx == 0 store their image at slot t*S + sample
     float* val;           // [batch] per-image pixel sum (entropy sum, or log-likelihood sum)
     float* po;            // [slots][rows_per_group][4096] stored images
+    int dbg;              // timing experiments only: 1 = skip tap-plane MFMAs, 2 = skip gather/epilogue math
 };
 void launch_dec_a(const DecAArgs& a, hipStream_t st);
 void launch_dec_b(const DecBArgs& a, hipStream_t st);

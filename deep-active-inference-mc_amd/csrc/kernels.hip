@@ -163,6 +163,8 @@ static void launch_tg(const GemmArgs& a, hipStream_t st) {
 
 void launch_tapgemm(int mode, int MT, int NT, const GemmArgs& a, hipStream_t st) {
 #define EFE_CASE(MD, M_, N_) if (mode == MD && MT == M_ && NT == N_) { launch_tg<MD, M_, N_>(a, st); return; }
+    EFE_CASE(MODE_FC, 1, 1)
+    EFE_CASE(MODE_FC, 2, 1)
     EFE_CASE(MODE_FC, 1, 2)
     EFE_CASE(MODE_FC, 2, 2)
     EFE_CASE(MODE_FC, 4, 2)
