@@ -213,7 +213,7 @@ void launch_dec_a(const DecAArgs& a, hipStream_t st) {
 // 32(co) x 32(pixel) tile, 16 extra MFMAs contract the channel axis against the 9 taps,
 //     T[tap][q] = sum_co W4[co][tap] * relu(y3[q][co] + b3[co]),
 // using the accumulator register e of every lane directly as the B operand (lane (q,h) holds
-// co = (e&3) + 8*(e>>2) + 4h, which is exactly the k-pair the f32 MFMA expects).  The 9 planes go to an LDS ring
+// co = (e&3) + 8*(e>>2) + 4h; with the 4-block 16x16x1 MFMA each 16-lane block is one (pixel half, channel half)).  The 9 planes go to an LDS ring
 // and the 3x3 "gather"  out[oh,ow] = b4 + sum_{kh,kw} T[kh*3+kw][oh+1-kh][ow+1-kw]  is done once the rows
 // above and below exist.  y3 (512 KiB per image) never exists in memory.
 // ---------------------------------------------------------------------------------------------------------
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
     for (int e = 0; e < 16; ++e) {
         const int co = (e & 3) + 8 * (e >> 2) + 4 * h;
         b3[e] = a.b3[co];
-        w4f[e] = (j < 9) ? a.w4[j * 32 + co] : 0.f;                    // A[i = tap][k = h]
+        w4f[e] = ((lane & 15) < 9) ? a.w4[(lane & 15) * 32 + co] : 0.f;   // A_b[i = tap = lane&15], b>>1 = h
     }
     if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -303,7 +303,10 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
                     bs[nt] = sp * 16; sw[nt] = sp & 15;
                 }
             });
-            // ---- bias + ReLU in registers, then contract channels against the 9 taps of the final conv
+            // ---- bias + ReLU in registers, then contract channels against the 9 taps of the final conv with the
+            // 4-block form v_mfma_f32_16x16x1_4b_f32: block = lane>>4 = (channel half h)*2 + (pixel half), so the
+            // accumulator register e is again the B operand as it stands; A[i = lane&15] = W4[tap i][co(e, h)].
+            // 16 instructions x 32 cycles (half the cost of the 32x32x2 form, whose 32 tap rows would be 72 % padding).
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 f32x16 T;
@@ -312,17 +315,23 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
                 if (!(a.dbg & 1)) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        T = __builtin_amdgcn_mfma_f32_32x32x2f32(w4f[e], fmaxf(acc[nt][e] + b3[e], 0.f), T, 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 5; ++e) T[e] = acc[nt][e];
+                        T = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], fmaxf(acc[nt][e] + b3[e], 0.f), T, 0, 0, 0);
                 }
-                // lane (q = j, h) now holds taps 4h + (0..3) in T[0..3] and tap 8 in T[4] (h == 0 only)
-                const int orow = 2 * (4 * s + 2 * rp + nt) + ph, ocol = 2 * j + pw;
-                float* tp = sT + ((orow % DB_YROWS) * 9) * 64 + ocol;
-                tp[(4 * h + 0) * 64] = T[0]; tp[(4 * h + 1) * 64] = T[1];
-                tp[(4 * h + 2) * 64] = T[2]; tp[(4 * h + 3) * 64] = T[3];
-                if (h == 0) tp[8 * 64] = T[4];
+                // D layout: T[4b + r] = D_b[row = 4*(lane>>4) + r][col = lane&15]; pixel p = 16*(b&1) + col, and the two
+                // channel halves (b, b+2) of the same pixel sit in the same lane: add them.
+                const int tq = lane >> 4, c = lane & 15;               // this lane holds taps 4*tq + r
+                const int orow = 2 * (4 * s + 2 * rp + nt) + ph;
+                float* tp = sT + ((orow % DB_YROWS) * 9 + 4 * tq) * 64 + pw;
+                if (tq < 2) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        tp[r4 * 64 + 2 * c] = T[r4] + T[8 + r4];
+                        tp[r4 * 64 + 2 * (16 + c)] = T[4 + r4] + T[12 + r4];
+                    }
+                } else if (tq == 2) {
+                    tp[2 * c] = T[0] + T[8];
+                    tp[2 * (16 + c)] = T[4] + T[12];
+                }
             }
         }
         __syncthreads();
