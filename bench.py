@@ -87,6 +87,49 @@ def cpu_baseline(depth, samples, target_s=12.0):
                       f'oracle (oracle/efe_oracle.py, torch RNG like the reference), {dt:.2f} s'}
 
 
+def bench_mcts(a, model, device, world, rank, dist):
+    """BASELINE configs[2]/[3]: E episodes per GPU, each a full MCTS decision (50 expansions with S MC samples,
+    simulation depth 5, use_means=False, early stop disabled), planned in lock-step; the root visit distributions
+    are gathered across ranks.  One decision ~ 51 expansions x 4 rows x 2.694 GFLOP + 50 x 1.35 GFLOP ~ 617 GFLOP."""
+    import daimc_amd
+    E = a.episodes
+    p = daimc_amd.MCTS_Params()
+    p.repeats, p.simulation_depth, p.use_means, p.threshold, p.samples = 50, 5, False, 2.0, a.samples
+    frames = synth_frames(E, device, seed=200 + rank)
+
+    def step():
+        out, distn = daimc_amd.active_inference_mcts_batch(model, frames, p, o_shape=(1, 64, 64), episode_offset=rank * E)
+        if world > 1:
+            daimc_amd.gather_action_posteriors(distn.to(device), world * E)
+        return out
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        dec = world * E * a.steps / dt
+        gflop_dec = (51 * 4 * a.samples * 134_721_312 * 2 + 50 * (5 * (18_176 + 541_696) + 5 * 134_179_616) * 2) / 1e9
+        print(json.dumps({'metric': 'MCTS decisions/sec (50 expansions, %d MC samples, sim depth 5)' % a.samples, 'value': dec,
+                          'unit': 'decisions/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': f'lock-step MCTS, {E} episodes per GPU (BASELINE configs[2])', 'episodes_per_gpu': E},
+                          'rollout_equivalents_per_s': dec * gflop_dec / 13.480, 'achieved_tflops_total': dec * gflop_dec / 1e3}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -97,6 +140,9 @@ def main():
     ap.add_argument('--depth', type=int, default=5)
     ap.add_argument('--dec-chunk', type=int, default=0)
     ap.add_argument('--opt', action='append', default=[], help='engine option name=value')
+    ap.add_argument('--workload', default='rollout', choices=['rollout', 'mcts'],
+                    help="'mcts' = BASELINE configs[2]: full lock-step MCTS (50 expansions, 10 samples, sim depth 5) over 64 episodes/GPU (secondary metric)")
+    ap.add_argument('--episodes', type=int, default=64)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-prof', action='store_true')
     a = ap.parse_args()
@@ -122,6 +168,8 @@ def main():
     for kv in a.opt:
         k_, v_ = kv.split('=')
         model.set_option(k_, int(v_))
+    if a.workload == 'mcts':
+        return bench_mcts(a, model, device, world, rank, dist)
     frames = synth_frames(R // 4, device, seed=100 + rank)
     o = frames.repeat_interleave(4, dim=0).contiguous()          # row 4i+a = (root i, action a), util.py:56-60
     pi = torch.eye(4, device=device).repeat(R // 4, 1).contiguous()

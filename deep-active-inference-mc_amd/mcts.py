@@ -163,3 +163,165 @@ def active_inference_mcts(model, frame, params, o_shape=(64, 64, 1)):
         all_paths.append(actions_path)
         all_paths_G.append(sims.mean().item())
     return root.action_selection(deterministic=True), params.repeats, states_explored, all_paths, all_paths_G
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Lock-step planner over E independent episodes: the same algorithm as active_inference_mcts,
+# but every tree takes its select / expand / simulate / back-propagate step together, so one expansion is ONE
+# engine call over E x pi_dim rows (x MC samples) and one simulation is ONE call over E episodes.
+# Tree statistics are [E, nodes, pi_dim] host tensors; node states stay on the device.
+# ---------------------------------------------------------------------------------------------------------
+def _trim_path(visited, pi_dim):
+    cancel = _OPPOSITE[pi_dim]
+    trimmed, i = [], 0
+    while i < len(visited) - 1:
+        if (visited[i], visited[i + 1]) in cancel:
+            i += 2
+        else:
+            trimmed.append(visited[i])
+            i += 1
+    return trimmed
+
+
+class BatchedMCTS:
+    def __init__(self, model, n_episodes, params, episode_offset=0):
+        self.model, self.E, self.p = model, int(n_episodes), params
+        self.pi_dim = model.pi_dim
+        self.ep0 = int(episode_offset)
+        cap = 1 + self.pi_dim * (params.repeats + 2)
+        E, A = self.E, self.pi_dim
+        self.W = torch.zeros(E, cap, A)
+        self.N = torch.zeros(E, cap, A)
+        self.Qpi = torch.zeros(E, cap, A)
+        self.child = torch.full((E, cap, A), -1, dtype=torch.long)
+        self.S = torch.zeros(E, cap, model.s_dim, device=model.device)
+        self.n_nodes = [1] * E
+        self.ar = torch.arange(E)
+
+    def _scores(self, e_idx, nodes):
+        W, N = self.W[e_idx, nodes], self.N[e_idx, nodes]
+        q = W / N
+        q = q - q.min(dim=1, keepdim=True).values
+        q = q / q.sum(dim=1, keepdim=True)
+        bonus = self.p.C / N
+        if self.p.using_prior_for_exploration:
+            bonus = self.Qpi[e_idx, nodes] * bonus
+        return q + bonus
+
+    def select(self, active):
+        """-> per active episode: list of (node, action) from the root down, and the leaf node index"""
+        e_idx = torch.tensor(active, dtype=torch.long)
+        cur = torch.zeros(len(active), dtype=torch.long)
+        paths = [[] for _ in active]
+        live = list(range(len(active)))
+        while live:
+            li = torch.tensor(live, dtype=torch.long)
+            a = torch.argmax(self._scores(e_idx[li], cur[li]), dim=1)
+            nxt = self.child[e_idx[li], cur[li], a]
+            still = []
+            for k, i in enumerate(live):
+                paths[i].append((int(cur[i]), int(a[k])))
+                cur[i] = nxt[k]
+                if self.child[active[i], int(nxt[k]), 0] >= 0:
+                    still.append(i)
+            live = still
+        return paths, [int(c) for c in cur]
+
+    def expand(self, nodes, mask):
+        """one engine call over E x pi_dim rows; bookkeeping only for episodes with mask[e]"""
+        m, E, A = self.model, self.E, self.pi_dim
+        node_t = torch.tensor(nodes, dtype=torch.long)
+        s = self.S[self.ar.to(self.S.device), node_t.to(self.S.device)].repeat_interleave(A, dim=0)
+        pi = (m.pi_one_hot if A == 4 else m.pi_one_hot_3).repeat(E, 1)
+        ro = self.ep0 * A
+        if self.p.use_means:
+            G, _, ps_next, _ = m.calculate_G_mean(s, pi, row_offset=ro)
+        else:
+            G, _, ps_next, _, _ = m.calculate_G(s, pi, samples=getattr(self.p, 'samples', 1), row_offset=ro)
+        Gc = G.detach().to('cpu').reshape(E, A)
+        ps_next = ps_next.reshape(E, A, -1)
+        for e in range(E):
+            if not mask[e]:
+                continue
+            n = nodes[e]
+            self.W[e, n] -= Gc[e]
+            self.N[e, n] += 1.0
+            base = self.n_nodes[e]
+            self.child[e, n] = torch.arange(base, base + A)
+            self.S[e, base:base + A] = ps_next[e]
+            self.n_nodes[e] = base + A
+
+    def action_selection(self, e):
+        visited, node = [], 0
+        while True:
+            a = int(torch.argmax(self.N[e, node]))
+            visited.append(a)
+            node = int(self.child[e, node, a])
+            if self.child[e, node, 0] < 0:
+                break
+        return _trim_path(visited, self.pi_dim)
+
+    def run(self, frames, o_shape=(64, 64, 1)):
+        m, E, p = self.model, self.E, self.p
+        res = [None] * E
+        explored = [0] * E
+        all_paths = [[] for _ in range(E)]
+        all_G = [[] for _ in range(E)]
+        qs0_mean, _ = m.model_down.encoder(torch.as_tensor(frames).reshape(E, *o_shape), row_offset=self.ep0)
+        self.S[:, 0] = qs0_mean
+        self.Qpi[:, 0] = m.model_top.encode_s(qs0_mean)[1].to('cpu')
+        active = [True] * E
+        if p.use_habit:
+            for e in range(E):
+                if calc_threshold(self.Qpi[e, 0], axis=0) > p.threshold:
+                    res[e] = ([int(torch.multinomial(self.Qpi[e, 0], 1))], 0, 0, [], [])
+                    active[e] = False
+        self.expand([0] * E, active)
+        for repeat in range(p.repeats):
+            for e in range(E):
+                if active[e] and calc_threshold(normalization(self.N[e, 0]), axis=0) > p.threshold:
+                    res[e] = (self.action_selection(e), repeat, explored[e], all_paths[e], all_G[e])
+                    active[e] = False
+            act = [e for e in range(E) if active[e]]
+            if not act:
+                break
+            paths, leaves = self.select(act)
+            nodes = [0] * E
+            for k, e in enumerate(act):
+                nodes[e] = leaves[k]
+            self.expand(nodes, active)
+            sims = torch.zeros(E, p.simulation_repeats)
+            node_t = torch.tensor(nodes, dtype=torch.long).to(self.S.device)
+            for r in range(p.simulation_repeats):
+                G, _, q0 = m.simulate_batch(self.S[self.ar.to(self.S.device), node_t], p.simulation_depth, use_means=False,
+                                            row_offset=self.ep0)
+                sims[:, r] = G.to('cpu')
+                q0 = q0.to('cpu')
+                for e in act:
+                    explored[e] += p.simulation_depth
+                    self.Qpi[e, nodes[e]] = q0[e]
+            for k, e in enumerate(act):
+                g = sims[e].mean()
+                for node, a in paths[k]:
+                    self.W[e, node, a] -= g
+                    self.N[e, node, a] += 1
+                all_paths[e].append([a for _, a in paths[k]])
+                all_G[e].append(g.item())
+        for e in range(E):
+            if res[e] is None:
+                res[e] = (self.action_selection(e), p.repeats, explored[e], all_paths[e], all_G[e])
+        return res
+
+    def root_visit_distribution(self):
+        """N / sum N at the roots, [E, pi_dim]: the policy-value that multi-GPU runs gather (mcts.py:177)"""
+        n = self.N[:, 0]
+        return n / n.sum(dim=1, keepdim=True)
+
+
+def active_inference_mcts_batch(model, frames, params, o_shape=(64, 64, 1), episode_offset=0):
+    """E planning decisions in lock-step; returns a list of E tuples shaped like active_inference_mcts's result and
+    the [E, pi_dim] root visit distribution."""
+    frames = torch.as_tensor(frames)
+    planner = BatchedMCTS(model, frames.shape[0], params, episode_offset)
+    out = planner.run(frames, o_shape)
+    return out, planner.root_visit_distribution()

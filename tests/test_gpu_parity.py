@@ -250,3 +250,40 @@ def test_dropout_statistics(models):
     se = gs.std(0) / np.sqrt(len(gs))
     # rows differ only by the action; spread across stages is MC noise -> std error bounded
     assert (se < 10).all()
+
+
+@pytest.mark.parametrize('name', ['mcts_means', 'mcts_samples'])
+def test_batched_mcts_single_episode_equals_golden(golden, models, name):
+    """the lock-step planner with E = 1 reproduces the reference's single-episode decision"""
+    import daimc_amd
+    g = golden(name)
+    m = _model(g, models)
+    p = daimc_amd.MCTS_Params()
+    p.repeats, p.simulation_depth, p.use_means, p.threshold = int(g['repeats']), int(g['simulation_depth']), bool(g['use_means']), float(g['threshold'])
+    m._stage = int(g['stage'])
+    out, dist = daimc_amd.active_inference_mcts_batch(m, torch.from_numpy(g['frame'])[None], p, o_shape=(1, 64, 64))
+    path, reps, explored, all_paths, all_G = out[0]
+    assert reps == int(g['repeats_done']) and explored == int(g['states_explored'])
+    assert all_paths == [[int(a) for a in row if a >= 0] for row in g['all_paths']]
+    np.testing.assert_allclose(np.array(all_G), g['all_paths_G'], atol=0.05)
+    assert [int(a) for a in path] == [int(a) for a in g['final_path']]
+    np.testing.assert_allclose(dist.sum(1).numpy(), 1.0, rtol=1e-6)
+
+
+def test_batched_mcts_episode_invariance(models):
+    """episode e planned inside a batch of 3 == planned alone with episode_offset = e (global noise keys):
+    the property that lets episodes shard across GPUs with identical results"""
+    import daimc_amd
+    m = models(1234, 1.15, 21)
+    p = daimc_amd.MCTS_Params()
+    p.repeats, p.simulation_depth, p.use_means, p.threshold = 5, 3, False, 0.9
+    p.samples = 2
+    frames = torch.from_numpy(synth.make_frames(55, 3)[:, 0][:, None])
+    m._stage = 0
+    out3, dist3 = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
+    for e in range(3):
+        m._stage = 0
+        out1, dist1 = daimc_amd.active_inference_mcts_batch(m, frames[e:e + 1], p, o_shape=(1, 64, 64), episode_offset=e)
+        assert out1[0][0] == out3[e][0] and out1[0][3] == out3[e][3]
+        assert out1[0][4] == out3[e][4]
+        assert torch.equal(dist1[0], dist3[e])
