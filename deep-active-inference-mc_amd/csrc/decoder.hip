@@ -31,47 +31,92 @@ __device__ __forceinline__ int swz(int pix, int c4) { return pix * 16 + (c4 ^ (p
 // L2) and B fragments (activations, LDS) of chunk i+1 are requested before the MFMAs of chunk i issue, so neither
 // latency is exposed (hipcc otherwise waits for each chunk's loads right before its first MFMA).
 // addr(t, base[NT], sw[NT], wtap): LDS float4 base + swizzle key of every pixel tile and the packed-weight tap index.
-template <int MT, int NT, class AddrFn>
-__device__ __forceinline__ void tap_loop(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
-                                         const float4* sm, const int h, AddrFn addr) {
-    int bs[NT], sw[NT], wt;
-    addr(0, bs, sw, wt);
-    float4 av[MT], bv[NT];
+struct ConvWIdx {          // packed conv weights [tap][MT tiles][8 chunks][64 lanes]
+    template <int MT> __device__ __forceinline__ static size_t at(int wt, int mt, int kc) { return (size_t)((wt * MT + mt) * 8 + kc) * 64; }
+};
+struct DenseWIdx {         // packed dense weights [feature tile][32 chunks][64 lanes]; "tap" t = 64-channel slice of K = 256
+    int mt0;
+    template <int MT> __device__ __forceinline__ size_t at(int wt, int mt, int kc) const { return (size_t)((mt0 + mt) * 32 + wt * 8 + kc) * 64; }
+};
+
+// tap -> LDS source of the stride-2 transposed convs (oh = 2*ih - 1 + kh: even output rows use kh=1 (ih=a); odd rows use
+// kh=0 (ih=a+1) and kh=2 (ih=a)); `rows`/`cols` bound the staged image, `zero` is the zero-pixel slot.
+template <int NT>
+struct ConvT2Addr {
+    int ph, pw, row0, row_step, col, rows, cols, zero;
+    __device__ __forceinline__ void operator()(int t, int (&bs)[NT], int (&sw)[NT], int& wt) const {
+        const int th = t / (1 + pw), tw = t - th * (1 + pw);
+        const int kh = ph ? (th ? 2 : 0) : 1, da = (ph && th == 0) ? 1 : 0;
+        const int kw = pw ? (tw ? 2 : 0) : 1, db = (pw && tw == 0) ? 1 : 0;
+        wt = kh * 3 + kw;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) av[mt] = Wl[(size_t)((wt * MT + mt) * 8) * 64];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bv[nt] = sm[bs[nt] + (h ^ sw[nt])];
-    for (int t = 0; t < ntaps; ++t) {
-        int nbs[NT], nsw[NT], nwt;
-        addr((t + 1 < ntaps) ? t + 1 : t, nbs, nsw, nwt);
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            float4 an[MT], bn[NT];
-            if (kc < 7) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) an[mt] = Wl[(size_t)((wt * MT + mt) * 8 + kc + 1) * 64];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[bs[nt] + ((2 * (kc + 1) + h) ^ sw[nt])];
-            } else {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) an[mt] = Wl[(size_t)((nwt * MT + mt) * 8) * 64];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[nbs[nt] + (h ^ nsw[nt])];
-            }
-            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch loads AHEAD of this chunk's MFMAs (hipcc sinks them otherwise)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) { MFMA4(acc[mt][nt], av[mt], bv[nt]) }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = an[mt];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+        for (int nt = 0; nt < NT; ++nt) {
+            const int sy = row0 + row_step * nt + da, sx = col + db;
+            const int sp = (sy < rows && sx < cols) ? sy * cols + sx : zero;
+            bs[nt] = sp * 16; sw[nt] = sp & 15;
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { bs[nt] = nbs[nt]; sw[nt] = nsw[nt]; }
-        wt = nwt;
     }
+};
+
+template <int MT, int NT>
+struct TapPipe {
+    float4 av[MT], bv[NT];       // fragments of the NEXT chunk to be multiplied (already requested)
+    int bs[NT], sw[NT], wt;
+
+    // request the first chunk of a contraction; call it as early as the operands are valid (e.g. before the epilogue
+    // of the previous tile) so that its L2 / LDS latency is covered by that epilogue
+    template <class AddrFn, class WIdx>
+    __device__ __forceinline__ void begin(const float4* __restrict__ Wl, const float4* sm, const int h, AddrFn addr, WIdx widx) {
+        addr(0, bs, sw, wt);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = Wl[widx.template at<MT>(wt, mt, 0)];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = sm[bs[nt] + (h ^ sw[nt])];
+    }
+
+    template <class AddrFn, class WIdx>
+    __device__ __forceinline__ void run(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
+                                        const float4* sm, const int h, AddrFn addr, WIdx widx) {
+        for (int t = 0; t < ntaps; ++t) {
+            int nbs[NT], nsw[NT], nwt;
+            addr((t + 1 < ntaps) ? t + 1 : t, nbs, nsw, nwt);
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                float4 an[MT], bn[NT];
+                if (kc < 7) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) an[mt] = Wl[widx.template at<MT>(wt, mt, kc + 1)];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[bs[nt] + ((2 * (kc + 1) + h) ^ sw[nt])];
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) an[mt] = Wl[widx.template at<MT>(nwt, mt, 0)];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[nbs[nt] + (h ^ nsw[nt])];
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch loads AHEAD of this chunk's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { MFMA4(acc[mt][nt], av[mt], bv[nt]) }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = an[mt];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bs[nt] = nbs[nt]; sw[nt] = nsw[nt]; }
+            wt = nwt;
+        }
+    }
+};
+
+template <int MT, int NT, class AddrFn, class WIdx>
+__device__ __forceinline__ void tap_loop(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
+                                         const float4* sm, const int h, AddrFn addr, WIdx widx) {
+    TapPipe<MT, NT> p;
+    p.begin(Wl, sm, h, addr, widx);
+    p.run(acc, ntaps, Wl, sm, h, addr, widx);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -135,7 +180,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
                 const int sp = ok ? sy * 16 + sx : 256;
                 bs[nt] = sp * 16; sw[nt] = sp & 15;
             }
-        });
+        }, ConvWIdx{});
         __syncthreads();            // every wave is done reading the input image
         // bias + ReLU, written back IN PLACE as the input image of layer 2 (same swizzled layout)
 #pragma unroll
@@ -166,18 +211,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
-            tap_loop<2, 2>(acc, (1 + ph) * (1 + pw), W2, sm, h, [&](int t, int (&bs)[2], int (&sw)[2], int& wt) {
-                const int th = t / (1 + pw), tw = t - th * (1 + pw);
-                const int kh = ph ? (th ? 2 : 0) : 1, da = (ph && th == 0) ? 1 : 0;
-                const int kw = pw ? (tw ? 2 : 0) : 1, db = (pw && tw == 0) ? 1 : 0;
-                wt = kh * 3 + kw;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int sy = prow0 + 2 * nt + da, sx = pcol + db;
-                    const int sp = (sy < 16 && sx < 16) ? sy * 16 + sx : 256;
-                    bs[nt] = sp * 16; sw[nt] = sp & 15;
-                }
-            });
+            tap_loop<2, 2>(acc, (1 + ph) * (1 + pw), W2, sm, h, ConvT2Addr<2>{ph, pw, prow0, 2, pcol, 16, 16, 256}, ConvWIdx{});
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 float* yp = Y + ((size_t)(2 * (prow0 + 2 * nt) + ph) * 32 + (2 * pcol + pw)) * 64;
@@ -291,18 +325,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
             f32x16 (&acc1)[1][2] = reinterpret_cast<f32x16 (&)[1][2]>(acc);
-            tap_loop<1, 2>(acc1, (1 + ph) * (1 + pw), W3, sm, h, [&](int t, int (&bs)[2], int (&sw)[2], int& wt) {
-                const int th = t / (1 + pw), tw = t - th * (1 + pw);
-                const int kh = ph ? (th ? 2 : 0) : 1, da = (ph && th == 0) ? 1 : 0;
-                const int kw = pw ? (tw ? 2 : 0) : 1, db = (pw && tw == 0) ? 1 : 0;
-                wt = kh * 3 + kw;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int sx = j + db;
-                    const int sp = (sx < 32) ? (2 * rp + nt + da) * 32 + sx : DB_ZERO;
-                    bs[nt] = sp * 16; sw[nt] = sp & 15;
-                }
-            });
+            tap_loop<1, 2>(acc1, (1 + ph) * (1 + pw), W3, sm, h, ConvT2Addr<2>{ph, pw, 2 * rp, 1, j, 8, 32, DB_ZERO}, ConvWIdx{});
             // ---- bias + ReLU in registers, then contract channels against the 9 taps of the final conv with the
             // 4-block form v_mfma_f32_16x16x1_4b_f32: block = lane>>4 = (channel half h)*2 + (pixel half), so the
             // accumulator register e is again the B operand as it stands; A[i = lane&15] = W4[tap i][co(e, h)].
@@ -374,6 +397,95 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
 void launch_dec_b(const DecBArgs& a, hipStream_t st) {
     const size_t lds = DB_IN_F4 * sizeof(float4) + DB_YROWS * 9 * 64 * sizeof(float);
     hipLaunchKernelGGL(k_dec_b, dim3(a.rows), dim3(256), lds, st, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_fc4: Linear(256, 16384) + ReLU + Dropout(0.5) (torchmodel.py:116-118), output written NHWC (rows permuted at
+// pack time).  A workgroup stages 64 batch rows x K=256 in swizzled LDS once and sweeps FC4_STEPS x 256 features;
+// every wave owns 64 features x 64 rows per step.  Dropout mask = one Philox call per row per 128 features.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FC4_STEPS = 8;
+__global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 sm[];        // [64 rows][64 quads], quad ^= row & 15
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    // XCD-aware mapping (workgroup b runs on XCD b % 8): feature group = b & 7, so every XCD streams ONE 2 MiB weight slice
+    // (L2-resident, 4 MiB per XCD) across all row tiles instead of thrashing over all eight.
+    const int fgrp = blockIdx.x & 7;
+    const int row0 = (blockIdx.x >> 3) * 64;
+    f32x4* smv = reinterpret_cast<f32x4*>(sm);
+    {
+        const f32x4* X = reinterpret_cast<const f32x4*>(a.X);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = it * 256 + tid;                            // 64 rows x 64 quads
+            const int r = idx >> 6, c4 = idx & 63;
+            const int gr = row0 + r;
+            smv[r * 64 + (c4 ^ (r & 15))] = (gr < a.n_pix) ? X[(size_t)gr * 64 + c4] : (f32x4)(0.f);
+        }
+    }
+    __syncthreads();
+    const float4* Wl = reinterpret_cast<const float4*>(a.Wp) + lane;
+
+    // dropout keys of this lane's two rows
+    uint32_t krow[2], kstream[2], kstage[2];
+    bool rv[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int m = row0 + nt * 32 + j;
+        rv[nt] = m < a.n_pix;
+        const int mg = a.m0 + (rv[nt] ? m : 0);
+        const int g = mg / a.rows_per_group;
+        krow[nt] = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
+        const uint2 key = group_key(a.gm, g);
+        kstream[nt] = key.x; kstage[nt] = key.y;
+    }
+
+    auto xaddr = [&](int t, int (&bs)[2], int (&sw)[2], int& wt) {
+        wt = t;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) { bs[nt] = (nt * 32 + j) * 64 + t * 16; sw[nt] = j & 15; }
+    };
+#pragma unroll 1
+    for (int fs = 0; fs < FC4_STEPS; ++fs) {
+        const int mt0 = (fgrp * FC4_STEPS + fs) * 8 + 2 * w;           // this wave's first 32-feature tile
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+        tap_loop<2, 2>(acc, 4, Wl, sm, h, xaddr, DenseWIdx{mt0});
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            if (!rv[nt]) continue;
+            const uint4 rnd = noise_words(a.k0, a.k1, a.tag, (uint32_t)((mt0 * 32) >> 7), krow[nt], kstream[nt], kstage[nt]);
+            float* yp = a.Y + (size_t)(row0 + nt * 32 + j) * a.ldy;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int co = (mt0 + mt) * 32 + 8 * g4 + 4 * h;
+                    const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
+                    const uint32_t word = ((co >> 5) & 3) == 0 ? rnd.x : ((co >> 5) & 3) == 1 ? rnd.y : ((co >> 5) & 3) == 2 ? rnd.z : rnd.w;
+                    float v[4] = {acc[mt][nt][4 * g4 + 0] + bb.x, acc[mt][nt][4 * g4 + 1] + bb.y,
+                                  acc[mt][nt][4 * g4 + 2] + bb.z, acc[mt][nt][4 * g4 + 3] + bb.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ((word >> ((co + e) & 31)) & 1u) ? fmaxf(v[e], 0.f) * 2.0f : 0.0f;
+                    *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+        }
+    }
+}
+
+void launch_fc4(const GemmArgs& a, hipStream_t st) {
+    // grid: 64-row tiles x (512 feature tiles / (8 per step * FC4_STEPS)) feature groups
+    static_assert(FC4_STEPS == 8, "512 feature tiles = 8 groups x 8 steps x 8 tiles");
+    dim3 grid(((a.n_pix + 63) / 64) * 8);
+    hipLaunchKernelGGL(k_fc4, grid, dim3(256), 64 * 64 * sizeof(float4), st, a);
 }
 
 }  // namespace efe

@@ -55,7 +55,7 @@ struct efe_ctx {
     int64_t dec_chunk = 8192, enc_chunk = 8192, fc4_mt = 2, dbg_a = 0, dbg_b = 0;
     int64_t last_macs = 0;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
-    bool prof = false;
+    unsigned prof = 0;        // bitmask of ProfClass values to time
     int cls = PROF_OTHER;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -65,11 +65,11 @@ struct efe_ctx {
         return ev_pool[ev_used++];
     }
     hipEvent_t prof_begin(hipStream_t st) {
-        if (!prof) return nullptr;
+        if (!(prof & (1u << cls))) return nullptr;
         hipEvent_t a = ev_get(); (void)hipEventRecord(a, st); return a;
     }
     void prof_end(hipEvent_t a, hipStream_t st) {
-        if (!prof) return;
+        if (!a) return;
         hipEvent_t b = ev_get(); (void)hipEventRecord(b, st);
         ev_spans.push_back({cls, {a, b}});
     }
@@ -162,7 +162,8 @@ void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float*
         if (tiles22 < 2048) { NT = 1; if (tiles22 * 2 < 2048) MT = 1; }
     }
     hipEvent_t e0 = ctx->prof_begin(st);
-    launch_tapgemm(MODE_FC, MT, NT, a, st);
+    if (L.mtiles == 512 && L.cin == 256 && ldx == 256 && x_mod == 0 && relu && drop && ctx->fc4_mt == 2) { a.x_mod = (int)(ctx->dbg_a & 4); launch_fc4(a, st); }
+    else launch_tapgemm(MODE_FC, MT, NT, a, st);
     ctx->prof_end(e0, st);
 }
 
@@ -492,7 +493,7 @@ int64_t efe_last_call_macs(efe_ctx* ctx) { return ctx ? ctx->last_macs : 0; }
 
 int efe_prof_enable(efe_ctx* ctx, int on) {
     if (!ctx) return 1;
-    ctx->prof = on != 0;
+    ctx->prof = (on < 0) ? 0xFFFFFFFFu : (unsigned)on;       // < 0 = all classes, otherwise a bitmask (bit c = class c)
     ctx->ev_used = 0;
     ctx->ev_spans.clear();
     return 0;

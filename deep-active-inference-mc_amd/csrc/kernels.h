@@ -92,6 +92,7 @@ struct DecBArgs {
     float* po;            // [slots][rows_per_group][4096] stored images
     int dbg;              // timing experiments only: 1 = skip tap-plane MFMAs, 2 = skip gather/epilogue math
 };
+void launch_fc4(const GemmArgs& a, hipStream_t st);      // Linear(256,16384)+ReLU+Dropout with the batch tile staged in LDS
 void launch_dec_a(const DecAArgs& a, hipStream_t st);
 void launch_dec_b(const DecBArgs& a, hipStream_t st);
 

@@ -448,9 +448,14 @@ class ActiveInferenceModel:
     PROF_CLASSES = ('transition_mlp', 'dec_dense_small', 'dec_dense_16384', 'unused3', 'dec_a_convT1_convT2',
                     'dec_b_convT3_final_reduce', 'unused6', 'encoder', 'other')
 
-    def prof_enable(self, on=True):
+    def prof_enable(self, on=True, classes=None):
+        """time kernel classes with HIP events on the launch stream; `classes` = iterable of PROF_CLASSES names
+        (default: all)"""
         e = self._ready()
-        e.check(e.lib.efe_prof_enable(e.ctx, 1 if on else 0))
+        mask = 0
+        if on:
+            mask = -1 if classes is None else sum(1 << self.PROF_CLASSES.index(c) for c in classes)
+        e.check(e.lib.efe_prof_enable(e.ctx, mask))
 
     def prof_read(self):
         """-> {class name: (milliseconds, launches)} since the last read (synchronises)."""

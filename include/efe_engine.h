@@ -109,7 +109,7 @@ int64_t efe_last_call_macs(efe_ctx*);
  * 4 k_dec_a (ConvT 64->64 s1 + ConvT 64->64 s2), 5 k_dec_b (ConvT 64->32 s2 + final conv + sigmoid + reductions),
  * 6 unused, 7 encoder, 8 other.
  * efe_prof_read synchronises the device, returns summed milliseconds and launch counts per class, and clears. */
-int efe_prof_enable(efe_ctx*, int on);
+int efe_prof_enable(efe_ctx*, int on);   /* 0 = off, < 0 = every class, otherwise a bitmask (bit c = class c) */
 int efe_prof_classes(void);
 int efe_prof_read(efe_ctx*, double* ms /*[classes]*/, int64_t* launches /*[classes]*/);
 
