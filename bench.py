@@ -232,6 +232,17 @@ def main():
                                'achieved': ach, 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TF,
                                'traffic': None, 'launches': int(n), 'avg_launch_ms': ms / max(n, 1),
                                'flops_per_launch': 2 * MAC_DECB_ROW * rows_per_launch}
+            # HBM bytes of the dominant kernel from the committed PMC profile (tools/gpu_profile.sh -> profiles/*_summary.txt)
+            try:
+                import glob
+                import re
+                best = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*rocprof_summary.txt')))[-1]
+                m_ = re.search(r'== HBM traffic \(JSON\) ==\n(\{.*\})', open(best).read())
+                tj = json.loads(m_.group(1))['k_dec_b']
+                out['roofline']['traffic'] = (tj['hbm_read_bytes_per_image'] + tj['hbm_write_bytes_per_image']) * rows_per_launch
+                out['roofline']['traffic_source'] = os.path.basename(best) + ' (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, per image x images per launch)'
+            except Exception:
+                pass
             tot = sum(v[0] for v in breakdown.values())
             kern = {}
             for k_, (ms_, n_) in breakdown.items():

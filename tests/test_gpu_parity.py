@@ -287,3 +287,99 @@ def test_batched_mcts_episode_invariance(models):
         assert out1[0][0] == out3[e][0] and out1[0][3] == out3[e][3]
         assert out1[0][4] == out3[e][4]
         assert torch.equal(dist1[0], dist3[e])
+
+
+# ------------------------------------------------------------------------------------------------------
+# more oracle comparisons: tile-tail sizes, the 10-sample path, trajectory API, checkpoint round trip
+# ------------------------------------------------------------------------------------------------------
+def test_calculate_G_ten_samples_vs_oracle(models, weights_cache):
+    seed, st, M, S = 31, 2, 4, 10
+    w = weights_cache(1234, 1.15)
+    m = models(1234, 1.15, seed)
+    orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
+    s0 = np.tile(PX.uniform_fill(8, (1, 10), 901, -1.0, 1.0), (M, 1))
+    pi0 = np.eye(4, dtype=np.float32)
+    with torch.no_grad():
+        oG, oT, ops1, ops1m, opo1 = orc.calculate_G(torch.from_numpy(s0), torch.from_numpy(pi0), S, st)
+    G, terms, ps1, ps1m, po1 = m.calculate_G(s0, pi0, samples=S, stage=st, eps=eps_calcG(seed, M, S, st))
+    np.testing.assert_allclose(c(terms[0]), oT[0].numpy(), atol=1e-3)
+    np.testing.assert_allclose(c(terms[1]), oT[1].numpy(), atol=1e-3)
+    np.testing.assert_allclose(c(G), oG.numpy(), atol=gtol(orc.last_term2_parts[0].numpy()))
+    np.testing.assert_allclose(c(po1), opo1.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_decoder_encoder_tile_tails_vs_oracle(models, weights_cache):
+    """M = 257 rows: exercises the 64-row tiles of the dense kernels and the persistent image loops with a ragged tail"""
+    seed, st, M = 41, 9, 257
+    w = weights_cache(1234, 1.35)
+    m = models(1234, 1.35, seed)
+    orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
+    s = PX.uniform_fill(8, (M, 10), 902, -1.5, 1.5)
+    with torch.no_grad():
+        opo = orc.decoder(torch.from_numpy(s), PX.PASS_D1, 3, st)
+        omean, olv = orc.encoder(opo, PX.PASS_E1, 3, st)
+    po = m.model_down.decoder(s, stage=st, pass_=PX.PASS_D1, sample=3)
+    np.testing.assert_allclose(c(po), opo.numpy(), rtol=1e-5, atol=1e-5)
+    _, mean, lv = m.model_down.encoder_with_sample(opo.numpy(), stage=st, pass_=PX.PASS_E1, sample=3)
+    # gain 1.35 drives hidden activations to O(10): fp32 summation-order noise is ~1e-6 * that
+    np.testing.assert_allclose(c(mean), omean.numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(c(lv), olv.numpy(), rtol=1e-5, atol=2e-5)
+
+
+def test_given_trajectory_vs_oracle(models, weights_cache):
+    seed, st, T = 51, 4, 5
+    w = weights_cache(1234, 1.15)
+    m = models(1234, 1.15, seed)
+    orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
+    s0 = PX.uniform_fill(8, (T, 10), 903, -1, 1); ps1 = PX.uniform_fill(8, (T, 10), 904, -1, 1)
+    mean = PX.uniform_fill(8, (T, 10), 905, -1, 1); lv = PX.uniform_fill(8, (T, 10), 906, -2, 0)
+    pi0 = np.eye(4, dtype=np.float32)[[0, 3, 1, 2, 2]]
+    with torch.no_grad():
+        oG = orc.calculate_G_given_trajectory(*(torch.from_numpy(x) for x in (s0, ps1, mean, lv, pi0)), st)
+    eps = np.stack([np.zeros((T, 10), np.float32), PX.normals(seed, T, 10, PX.PASS_T2, 0, st), PX.normals(seed, T, 10, PX.PASS_D2B, 0, st)])
+    G = m.calculate_G_given_trajectory(s0, ps1, mean, lv, pi0, stage=st, eps=eps)
+    np.testing.assert_allclose(c(G), oG.numpy(), atol=gtol(np.array([2800.0])))
+
+
+def test_check_reward_and_helpers(models, golden):
+    g = golden('helpers')
+    m = models(1234, 1.15, 1)
+    np.testing.assert_allclose(c(m.check_reward(g['p'])), g['reward'], rtol=2e-6)
+    q = m.habitual_net(g['p'])
+    assert q.shape == (3, 4) and torch.allclose(q.sum(1), torch.ones(3, device=q.device), atol=1e-6)
+    fut = m.imagine_future_from_o(g['p'], np.eye(4, dtype=np.float32)[:3])
+    assert fut.shape == (3, 1, 64, 64) and torch.isfinite(fut).all()
+
+
+def test_checkpoint_round_trip(models, tmp_path):
+    """save_weights / load_weights with the reference's file names and state_dict keys (torchmodel.py:167-177)"""
+    import daimc_amd
+    m = models(1234, 1.15, 3)
+    m.save_weights(str(tmp_path))
+    for f in ('checkpoint_down.pth', 'checkpoint_top.pth', 'checkpoint_mid.pth'):
+        assert (tmp_path / f).exists()
+    sd = torch.load(tmp_path / 'checkpoint_down.pth')
+    assert sd['po_net.13.weight'].shape == (64, 64, 3, 3) and sd['qs_net.9.weight'].shape == (256, 576)
+    m2 = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=3, init_weights=False)
+    m2.load_weights(str(tmp_path))
+    s = PX.uniform_fill(8, (4, 10), 907, -1, 1)
+    a = m.model_down.decoder(s, stage=0)
+    b = m2.model_down.decoder(s, stage=0)
+    assert torch.equal(a, b)
+    bad = dict(sd); bad['qs_net.9.weight'] = torch.zeros(256, 256)
+    with pytest.raises(ValueError, match='torchmodel.py:94'):
+        m2.model_down.load_state_dict(bad)
+
+
+def test_api_errors_are_loud(models):
+    m = models(1234, 1.15, 1)
+    with pytest.raises(RuntimeError):
+        m.calculate_G(np.zeros((4, 10), np.float32), np.eye(4, dtype=np.float32), samples=0)
+    with pytest.raises(ValueError):
+        m.calculate_G_4_repeated(np.zeros((3, 1, 64, 64), np.float32))
+    with pytest.raises(ValueError):
+        import daimc_amd
+        daimc_amd.ActiveInferenceModel(10, 3, 0.0, 1.0, 1.0)
+    import daimc_amd
+    p = daimc_amd.MCTS_Params()
+    assert daimc_amd.active_inference_mcts(m, [], p) == ([0], 0, 0, [], [])

@@ -39,6 +39,32 @@ def main(d):
             if not k.startswith('k_'):
                 continue
             out.append(f'{k:62s} ' + ' '.join(f'{acc[k][n] / max(cnt[k][n], 1):22.4g}' for n in names))
+    # HBM traffic of the dominant kernel per decoder image: FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts
+    # 128-B requests at 64 B (MI355X_MICROARCH.md "HBM"), so it is doubled.  One k_dec_b workgroup = one image.
+    try:
+        import json
+        tr = {}
+        for sub, key in (('pmc_fetch', 'FETCH_SIZE'), ('pmc_write', 'WRITE_SIZE')):
+            cs = glob.glob(os.path.join(d, sub, '**', '*counter_collection.csv'), recursive=True)
+            for r in csv.DictReader(open(cs[0])):
+                k = short(r['Kernel_Name'])
+                if r['Counter_Name'] != key or not k.startswith('k_dec'):
+                    continue
+                e = tr.setdefault(k, {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0, 'images_f': 0, 'images_w': 0})
+                e[key] += float(r['Counter_Value'])
+                e['images_f' if key == 'FETCH_SIZE' else 'images_w'] += int(r['Grid_Size']) // int(r['Workgroup_Size'])
+        res = {}
+        for k, e in tr.items():
+            # k_dec_a is persistent (grid 512): images per dispatch are not visible from the grid; report k_dec_b only
+            if k != 'k_dec_b':
+                continue
+            res[k] = {'hbm_read_bytes_per_image': 2 * e['FETCH_SIZE'] * 1024 / max(e['images_f'], 1),
+                      'hbm_write_bytes_per_image': e['WRITE_SIZE'] * 1024 / max(e['images_w'], 1),
+                      'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH doubled per MI355X_MICROARCH.md'}
+        out.append('\n== HBM traffic (JSON) ==')
+        out.append(json.dumps(res))
+    except Exception as ex:      # summary stays usable without the PMC passes
+        out.append(f'(no traffic summary: {ex})')
     print('\n'.join(out))
 
 
