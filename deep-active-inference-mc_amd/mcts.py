@@ -135,6 +135,15 @@ class Node:
 
 def active_inference_mcts(model, frame, params, o_shape=(64, 64, 1)):
     """One planning decision (mcts.py:150-195) -> (path, repeats_done, states_explored, all_paths, all_paths_G)."""
+    prev = torch.get_num_threads()
+    torch.set_num_threads(1)        # pi_dim-sized host tensors: keep torch's intra-op pool out of it
+    try:
+        return _mcts_one(model, frame, params, o_shape)
+    finally:
+        torch.set_num_threads(prev)
+
+
+def _mcts_one(model, frame, params, o_shape):
     states_explored, all_paths, all_paths_G = 0, [], []
     if frame is None or (isinstance(frame, (list, tuple)) and len(frame) == 0):
         return [0], 0, states_explored, all_paths, all_paths_G
@@ -184,19 +193,26 @@ def _trim_path(visited, pi_dim):
 
 
 class BatchedMCTS:
+    """All tree statistics are [E, nodes, pi_dim] host tensors and every step is vectorised over the episodes
+    (no per-episode Python in the iteration loop); node states live on the device."""
+
     def __init__(self, model, n_episodes, params, episode_offset=0):
         self.model, self.E, self.p = model, int(n_episodes), params
         self.pi_dim = model.pi_dim
         self.ep0 = int(episode_offset)
-        cap = 1 + self.pi_dim * (params.repeats + 2)
-        E, A = self.E, self.pi_dim
+        self.cap = 1 + self.pi_dim * (params.repeats + 2)
+        self.max_depth = params.repeats + 2
+        E, A, cap = self.E, self.pi_dim, self.cap
         self.W = torch.zeros(E, cap, A)
         self.N = torch.zeros(E, cap, A)
         self.Qpi = torch.zeros(E, cap, A)
         self.child = torch.full((E, cap, A), -1, dtype=torch.long)
         self.S = torch.zeros(E, cap, model.s_dim, device=model.device)
-        self.n_nodes = [1] * E
+        self.n_nodes = torch.ones(E, dtype=torch.long)
         self.ar = torch.arange(E)
+        self.ar_dev = self.ar.to(model.device)
+        self.arA = torch.arange(A)
+        self.pi_hot = (model.pi_one_hot if A == 4 else model.pi_one_hot_3).repeat(E, 1)
 
     def _scores(self, e_idx, nodes):
         W, N = self.W[e_idx, nodes], self.N[e_idx, nodes]
@@ -209,47 +225,48 @@ class BatchedMCTS:
         return q + bonus
 
     def select(self, active):
-        """-> per active episode: list of (node, action) from the root down, and the leaf node index"""
-        e_idx = torch.tensor(active, dtype=torch.long)
-        cur = torch.zeros(len(active), dtype=torch.long)
-        paths = [[] for _ in active]
-        live = list(range(len(active)))
-        while live:
-            li = torch.tensor(live, dtype=torch.long)
-            a = torch.argmax(self._scores(e_idx[li], cur[li]), dim=1)
-            nxt = self.child[e_idx[li], cur[li], a]
-            still = []
-            for k, i in enumerate(live):
-                paths[i].append((int(cur[i]), int(a[k])))
-                cur[i] = nxt[k]
-                if self.child[active[i], int(nxt[k]), 0] >= 0:
-                    still.append(i)
-            live = still
-        return paths, [int(c) for c in cur]
+        """tree policy for every active episode at once -> (path_nodes [E,D], path_actions [E,D], path_len [E], leaf [E]);
+        rows of inactive episodes are zeros"""
+        E = self.E
+        path_nodes = torch.zeros(E, self.max_depth, dtype=torch.long)
+        path_act = torch.zeros(E, self.max_depth, dtype=torch.long)
+        path_len = torch.zeros(E, dtype=torch.long)
+        cur = torch.zeros(E, dtype=torch.long)
+        live = active.clone()
+        d = 0
+        while bool(live.any()):
+            e_idx = self.ar[live]
+            a = torch.argmax(self._scores(e_idx, cur[e_idx]), dim=1)
+            path_nodes[e_idx, d] = cur[e_idx]
+            path_act[e_idx, d] = a
+            path_len[e_idx] = d + 1
+            nxt = self.child[e_idx, cur[e_idx], a]
+            cur[e_idx] = nxt
+            live = live.clone()
+            live[e_idx] = self.child[e_idx, nxt, 0] >= 0          # keep walking while the reached node has children
+            d += 1
+        return path_nodes, path_act, path_len, cur
 
     def expand(self, nodes, mask):
-        """one engine call over E x pi_dim rows; bookkeeping only for episodes with mask[e]"""
+        """ONE engine call over E x pi_dim rows; tree bookkeeping only where mask[e]"""
         m, E, A = self.model, self.E, self.pi_dim
-        node_t = torch.tensor(nodes, dtype=torch.long)
-        s = self.S[self.ar.to(self.S.device), node_t.to(self.S.device)].repeat_interleave(A, dim=0)
-        pi = (m.pi_one_hot if A == 4 else m.pi_one_hot_3).repeat(E, 1)
+        s = self.S[self.ar_dev, nodes.to(self.S.device)].repeat_interleave(A, dim=0)
         ro = self.ep0 * A
         if self.p.use_means:
-            G, _, ps_next, _ = m.calculate_G_mean(s, pi, row_offset=ro)
+            G, _, ps_next, _ = m.calculate_G_mean(s, self.pi_hot, row_offset=ro)
         else:
-            G, _, ps_next, _, _ = m.calculate_G(s, pi, samples=getattr(self.p, 'samples', 1), row_offset=ro)
+            G, _, ps_next, _, _ = m.calculate_G(s, self.pi_hot, samples=getattr(self.p, 'samples', 1), row_offset=ro)
         Gc = G.detach().to('cpu').reshape(E, A)
-        ps_next = ps_next.reshape(E, A, -1)
-        for e in range(E):
-            if not mask[e]:
-                continue
-            n = nodes[e]
-            self.W[e, n] -= Gc[e]
-            self.N[e, n] += 1.0
-            base = self.n_nodes[e]
-            self.child[e, n] = torch.arange(base, base + A)
-            self.S[e, base:base + A] = ps_next[e]
-            self.n_nodes[e] = base + A
+        e_idx = self.ar[mask]
+        n = nodes[e_idx]
+        self.W[e_idx, n] -= Gc[e_idx]
+        self.N[e_idx, n] += 1.0
+        base = self.n_nodes[e_idx]
+        kids = base[:, None] + self.arA[None, :]
+        self.child[e_idx, n] = kids
+        dev = self.S.device
+        self.S[e_idx.to(dev)[:, None], kids.to(dev)] = ps_next.reshape(E, A, -1)[e_idx.to(dev)]
+        self.n_nodes[e_idx] = base + A
 
     def action_selection(self, e):
         visited, node = [], 0
@@ -262,54 +279,65 @@ class BatchedMCTS:
         return _trim_path(visited, self.pi_dim)
 
     def run(self, frames, o_shape=(64, 64, 1)):
+        # the tree statistics are tiny host tensors: one intra-op thread (torch's default pool = every core of the
+        # host, which turns each [E,4] reduction into a multi-millisecond fork/join on many-core boxes)
+        prev = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            return self._run(frames, o_shape)
+        finally:
+            torch.set_num_threads(prev)
+
+    def _run(self, frames, o_shape):
         m, E, p = self.model, self.E, self.p
         res = [None] * E
-        explored = [0] * E
-        all_paths = [[] for _ in range(E)]
-        all_G = [[] for _ in range(E)]
+        explored = torch.zeros(E, dtype=torch.long)
+        hist_paths, hist_G, hist_active = [], [], []          # per iteration: (path_act, path_len), G, active mask
         qs0_mean, _ = m.model_down.encoder(torch.as_tensor(frames).reshape(E, *o_shape), row_offset=self.ep0)
         self.S[:, 0] = qs0_mean
         self.Qpi[:, 0] = m.model_top.encode_s(qs0_mean)[1].to('cpu')
-        active = [True] * E
+        active = torch.ones(E, dtype=torch.bool)
+        stop_at = torch.full((E,), -1, dtype=torch.long)
         if p.use_habit:
             for e in range(E):
                 if calc_threshold(self.Qpi[e, 0], axis=0) > p.threshold:
                     res[e] = ([int(torch.multinomial(self.Qpi[e, 0], 1))], 0, 0, [], [])
                     active[e] = False
-        self.expand([0] * E, active)
+        self.expand(torch.zeros(E, dtype=torch.long), active)
         for repeat in range(p.repeats):
-            for e in range(E):
-                if active[e] and calc_threshold(normalization(self.N[e, 0]), axis=0) > p.threshold:
-                    res[e] = (self.action_selection(e), repeat, explored[e], all_paths[e], all_G[e])
-                    active[e] = False
-            act = [e for e in range(E) if active[e]]
-            if not act:
+            rootN = self.N[:, 0]
+            dist = rootN / rootN.sum(dim=1, keepdim=True)
+            done = active & ((dist.max(dim=1).values - dist.mean(dim=1)) > p.threshold)
+            if bool(done.any()):
+                for e in self.ar[done].tolist():
+                    stop_at[e] = repeat
+                active = active & ~done
+            if not bool(active.any()):
                 break
-            paths, leaves = self.select(act)
-            nodes = [0] * E
-            for k, e in enumerate(act):
-                nodes[e] = leaves[k]
-            self.expand(nodes, active)
+            path_nodes, path_act, path_len, leaves = self.select(active)
+            self.expand(leaves, active)
             sims = torch.zeros(E, p.simulation_repeats)
-            node_t = torch.tensor(nodes, dtype=torch.long).to(self.S.device)
+            leaf_states = self.S[self.ar_dev, leaves.to(self.S.device)]
+            e_idx = self.ar[active]
             for r in range(p.simulation_repeats):
-                G, _, q0 = m.simulate_batch(self.S[self.ar.to(self.S.device), node_t], p.simulation_depth, use_means=False,
-                                            row_offset=self.ep0)
+                G, _, q0 = m.simulate_batch(leaf_states, p.simulation_depth, use_means=False, row_offset=self.ep0)
                 sims[:, r] = G.to('cpu')
-                q0 = q0.to('cpu')
-                for e in act:
-                    explored[e] += p.simulation_depth
-                    self.Qpi[e, nodes[e]] = q0[e]
-            for k, e in enumerate(act):
-                g = sims[e].mean()
-                for node, a in paths[k]:
-                    self.W[e, node, a] -= g
-                    self.N[e, node, a] += 1
-                all_paths[e].append([a for _, a in paths[k]])
-                all_G[e].append(g.item())
+                self.Qpi[e_idx, leaves[e_idx]] = q0.to('cpu')[e_idx]
+            explored[e_idx] += p.simulation_depth * p.simulation_repeats
+            g = sims.mean(dim=1)
+            for d in range(int(path_len.max())):
+                sel = active & (path_len > d)
+                ei = self.ar[sel]
+                self.W[ei, path_nodes[ei, d], path_act[ei, d]] -= g[ei]
+                self.N[ei, path_nodes[ei, d], path_act[ei, d]] += 1
+            hist_paths.append((path_act, path_len)); hist_G.append(g); hist_active.append(active.clone())
         for e in range(E):
-            if res[e] is None:
-                res[e] = (self.action_selection(e), p.repeats, explored[e], all_paths[e], all_G[e])
+            if res[e] is not None:
+                continue
+            paths = [hist_paths[i][0][e, :int(hist_paths[i][1][e])].tolist() for i in range(len(hist_G)) if hist_active[i][e]]
+            Gs = [hist_G[i][e].item() for i in range(len(hist_G)) if hist_active[i][e]]
+            reps = int(stop_at[e]) if stop_at[e] >= 0 else p.repeats
+            res[e] = (self.action_selection(e), reps, int(explored[e]), paths, Gs)
         return res
 
     def root_visit_distribution(self):
