@@ -1,0 +1,199 @@
+// Fused encoder trunk for gfx950: the four Conv2d(k3, stride 2, no padding) + ReLU layers of
+// /root/reference/src/torchmodel.py:85-92 (qs_net.0..7), 64x64x1 -> 31x31x32 -> 15x15x32 -> 7x7x64 -> 3x3x64,
+// one image per workgroup, every intermediate in LDS; only the 576-vector (NHWC p*64+c order, the column order the
+// packed first dense layer expects) leaves the chip.
+//
+//   conv1 (Cin = 1) is never materialised: while the conv2 MFMAs run, the VALU recomputes the conv1 activations a
+//   lane needs for its next B fragment straight from the 16 KiB input image in LDS (9 FMAs per value, conv1 weights
+//   as broadcast LDS reads).  conv2..4 are MFMA tap contractions (v_mfma_f32_32x32x2_f32) over swizzled LDS images.
+#include "mfma_pipe.h"
+
+namespace efe {
+
+constexpr int EN_IMG = 0;                      // [64][64] input image                       (floats)
+constexpr int EN_C2 = 4096;                    // [225 px][32 ch] conv2 output, 8 quads/pixel, quad ^= px & 7
+constexpr int EN_C3 = EN_C2 + 225 * 32;        // [49 px][64 ch] conv3 output, 16 quads/pixel, quad ^= px & 15
+constexpr int EN_W1 = EN_C3 + 49 * 64;         // conv1 weights [9 taps][32 ch] + bias [32]
+constexpr int EN_END = EN_W1 + 320;            // 14752 floats = 59008 B
+constexpr int EN_RED = EN_IMG;                 // conv4 split-K partials alias the (dead) input image
+
+__global__ void __launch_bounds__(256, 2) k_enc_trunk(const EncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    float4* sm4 = reinterpret_cast<float4*>(smf);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+
+    // conv1 weights + bias live in LDS ([tap][32 ch] so a lane's 4 channels of a chunk are one broadcast ds_read_b128)
+    for (int i = tid; i < 320; i += 256) smf[EN_W1 + i] = (i < 288) ? a.w1[i] : a.b1[i - 288];
+    const float4* w1s = reinterpret_cast<const float4*>(smf + EN_W1);
+    const float4* W2 = reinterpret_cast<const float4*>(a.w2) + lane;      // [9][1][4][64]
+    const float4* W3 = reinterpret_cast<const float4*>(a.w3) + lane;      // [9][2][4][64]
+    const float4* W4 = reinterpret_cast<const float4*>(a.w4) + lane;      // [9][2][8][64]
+
+    for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
+        {   // stage the image (16 KiB)
+            const f32x4* X = reinterpret_cast<const f32x4*>(a.o) + (size_t)img * 1024;
+            f32x4* d = reinterpret_cast<f32x4*>(smf + EN_IMG);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) d[it * 256 + tid] = X[it * 256 + tid];
+        }
+        __syncthreads();
+
+        // ================= conv2 (with conv1 computed on the fly): 225 output pixels = 8 tiles of 32 ==================
+        {
+            int ibase[2]; bool pv[2]; int m[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                m[nt] = 32 * (w + 4 * nt) + j;
+                pv[nt] = m[nt] < 225;
+                const int mm = pv[nt] ? m[nt] : 0;
+                const int oy = mm / 15, ox = mm - oy * 15;
+                ibase[nt] = (4 * oy) * 64 + 4 * ox;            // image offset of conv1 position (2oy, 2ox)
+            }
+            f32x16 acc[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+            // B fragment generator: conv1 + ReLU of channels 8*kc + 4*h .. +3 at this lane's conv1 position of tap t
+            auto load_patch = [&](int t, float (&patch)[2][9]) {
+                const int kh = t / 3, kw = t - kh * 3;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float* ip = smf + EN_IMG + ibase[nt] + (2 * kh) * 64 + 2 * kw;   // conv1 position (2oy+kh, 2ox+kw)
+#pragma unroll
+                    for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+                        for (int bb = 0; bb < 3; ++bb) patch[nt][aa * 3 + bb] = ip[aa * 64 + bb];
+                }
+            };
+            auto gen_b = [&](const float (&patch)[2][9], int kc, int hq, float4 (&bv)[2]) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float4 x = w1s[72 + kc * 2 + hq];                         // bias
+#pragma unroll
+                    for (int ab = 0; ab < 9; ++ab) {
+                        const float4 ww = w1s[ab * 8 + kc * 2 + hq];
+                        const float p_ = patch[nt][ab];
+                        x.x = fmaf(p_, ww.x, x.x); x.y = fmaf(p_, ww.y, x.y); x.z = fmaf(p_, ww.z, x.z); x.w = fmaf(p_, ww.w, x.w);
+                    }
+                    bv[nt] = make_float4(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f), fmaxf(x.w, 0.f));
+                }
+            };
+            // software pipeline over the 36 (tap, chunk) steps: while the 8 MFMAs of step i issue, the VALU produces the B
+            // fragments of step i+1 and the A fragment of step i+1 is in flight
+            float patch[2][9];
+            float4 bcur[2], bnxt[2];
+            float4 av = W2[0];
+            load_patch(0, patch);
+            {
+                int hq = h; asm volatile("" : "+v"(hq));
+                gen_b(patch, 0, hq, bcur);
+            }
+#pragma unroll 1
+            for (int i = 0; i < 36; ++i) {
+                const int ni = (i + 1 < 36) ? i + 1 : 35;
+                const float4 an = W2[(size_t)ni * 64];
+                int hq = h; asm volatile("" : "+v"(hq));        // laundered per step: stops hipcc hoisting the weight reads into 160 registers
+                if ((ni & 3) == 0) load_patch(ni >> 2, patch);
+                gen_b(patch, ni & 3, hq, bnxt);
+                MFMA4(acc[0], av, bcur[0]) MFMA4(acc[1], av, bcur[1])
+                av = an; bcur[0] = bnxt[0]; bcur[1] = bnxt[1];
+            }
+            // bias + ReLU -> conv2 image in LDS
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (!pv[nt]) continue;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c4 = 2 * g4 + h;
+                    const float4 bb = reinterpret_cast<const float4*>(a.b2)[c4];
+                    float4 v;
+                    v.x = fmaxf(acc[nt][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[nt][4 * g4 + 1] + bb.y, 0.f);
+                    v.z = fmaxf(acc[nt][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[nt][4 * g4 + 3] + bb.w, 0.f);
+                    sm4[EN_C2 / 4 + m[nt] * 8 + (c4 ^ (m[nt] & 7))] = v;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ================= conv3: 49 pixels (2 tiles) x 64 channels (2 tiles): one (mt, nt) unit per wave ==================
+        {
+            const int mt = w & 1, nt = w >> 1;
+            const int m = 32 * nt + j;
+            const bool pv = m < 49;
+            const int mm = pv ? m : 0;
+            const int oy = mm / 7, ox = mm - oy * 7;
+            f32x16 acc[1][1];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+            tap_loop_kc<1, 1, 4>(acc, 9, W3, sm4 + EN_C2 / 4, h, [&](int t, int (&bs)[1], int (&sw)[1], int& wt) {
+                const int kh = t / 3, kw = t - kh * 3;
+                wt = t;
+                const int sp = (2 * oy + kh) * 15 + 2 * ox + kw;
+                bs[0] = sp * 8; sw[0] = sp & 7;
+            }, PackedWIdx{2, 4, mt});
+            if (pv) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c4 = mt * 8 + 2 * g4 + h;
+                    const float4 bb = reinterpret_cast<const float4*>(a.b3)[c4];
+                    float4 v;
+                    v.x = fmaxf(acc[0][0][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[0][0][4 * g4 + 1] + bb.y, 0.f);
+                    v.z = fmaxf(acc[0][0][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[0][0][4 * g4 + 3] + bb.w, 0.f);
+                    sm4[EN_C3 / 4 + m * 16 + (c4 ^ (m & 15))] = v;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ================= conv4: 9 pixels x 64 channels, K = 9 taps x 64 split over two waves per channel tile ==================
+        {
+            const int mt = w & 1, kh2 = w >> 1;                 // kh2 = 0: taps 0..4, kh2 = 1: taps 5..8
+            const bool pv = j < 9;
+            const int mm = pv ? j : 0;
+            const int oy = mm / 3, ox = mm - oy * 3;
+            const int t0 = kh2 ? 5 : 0, nt_ = kh2 ? 4 : 5;
+            f32x16 acc[1][1];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
+            tap_loop_kc<1, 1, 8>(acc, nt_, W4, sm4 + EN_C3 / 4, h, [&](int tt, int (&bs)[1], int (&sw)[1], int& wt) {
+                const int t = t0 + tt;
+                const int kh = t / 3, kw = t - kh * 3;
+                wt = t;
+                const int sp = (2 * oy + kh) * 7 + 2 * ox + kw;
+                bs[0] = sp * 16; sw[0] = sp & 15;
+            }, PackedWIdx{2, 8, mt});
+            float* red = smf + EN_RED + (size_t)mt * 16 * 64;   // [mt][e 0..15][lane]
+            if (kh2 == 1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[e * 64 + lane] = acc[0][0][e];
+            }
+            __syncthreads();
+            if (kh2 == 0 && pv) {
+                float* op = a.out + (size_t)img * 576 + j * 64;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c4 = mt * 8 + 2 * g4 + h;
+                    const float4 bb = reinterpret_cast<const float4*>(a.b4)[c4];
+                    float4 v;
+                    v.x = fmaxf(acc[0][0][4 * g4 + 0] + red[(4 * g4 + 0) * 64 + lane] + bb.x, 0.f);
+                    v.y = fmaxf(acc[0][0][4 * g4 + 1] + red[(4 * g4 + 1) * 64 + lane] + bb.y, 0.f);
+                    v.z = fmaxf(acc[0][0][4 * g4 + 2] + red[(4 * g4 + 2) * 64 + lane] + bb.z, 0.f);
+                    v.w = fmaxf(acc[0][0][4 * g4 + 3] + red[(4 * g4 + 3) * 64 + lane] + bb.w, 0.f);
+                    reinterpret_cast<float4*>(op)[c4] = v;
+                }
+            }
+        }
+        __syncthreads();        // the input image buffer (aliased by the partials) is free for the next image
+    }
+}
+
+void launch_enc_trunk(const EncArgs& a, hipStream_t st) {
+    const int grid = a.rows < 512 ? a.rows : 512;
+    hipLaunchKernelGGL(k_enc_trunk, dim3(grid), dim3(256), EN_END * sizeof(float), st, a);
+}
+
+}  // namespace efe

@@ -234,22 +234,20 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
 // ModelDown.qs_net over N rows; o is [N][4096]; out enc [N][32] (mean 0..9, logvar 10..19).
 int run_encoder(efe_ctx* ctx, const float* o, int N, const NoiseCfg& nc, float* enc, hipStream_t st) {
     const int C = (int)std::min<int64_t>(ctx->enc_chunk, N);
-    float* c1 = ctx->allocT<float>((size_t)C * 961 * 32);
-    float* c2 = ctx->allocT<float>((size_t)C * 225 * 32);
-    float* c3 = ctx->allocT<float>((size_t)C * 49 * 64);
     float* c4 = ctx->allocT<float>((size_t)C * 9 * 64);
     float* hA = ctx->allocT<float>((size_t)C * 256);
     float* hB = ctx->allocT<float>((size_t)C * 256);
-    if (!c1 || !c2 || !c3 || !c4 || !hA || !hB) return 1;
+    if (!c4 || !hA || !hB) return 1;
     for (int m0 = 0; m0 < N; m0 += C) {
         const int c = std::min(C, N - m0);
         ctx->cls = PROF_ENC;
+        EncArgs ea{};
+        ea.o = o + (size_t)m0 * 4096; ea.out = c4; ea.w1 = ctx->enc_w1; ea.b1 = ctx->enc_b1;
+        ea.w2 = ctx->enc_conv[0].Wp; ea.b2 = ctx->enc_conv[0].bias; ea.w3 = ctx->enc_conv[1].Wp; ea.b3 = ctx->enc_conv[1].bias;
+        ea.w4 = ctx->enc_conv[2].Wp; ea.b4 = ctx->enc_conv[2].bias; ea.rows = c;
         hipEvent_t e0 = ctx->prof_begin(st);
-        launch_enc_conv1(o + (size_t)m0 * 4096, ctx->enc_w1, ctx->enc_b1, c1, c, st);
+        launch_enc_trunk(ea, st);
         ctx->prof_end(e0, st);
-        conv(ctx, MODE_CONV_S2, 1, 2, ctx->enc_conv[0], c1, c2, c * 225, 31, 15, st);
-        conv(ctx, MODE_CONV_S2, 2, 2, ctx->enc_conv[1], c2, c3, c * 49, 15, 7, st);
-        conv(ctx, MODE_CONV_S2, 2, 2, ctx->enc_conv[2], c3, c4, c * 9, 7, 3, st);
         fc(ctx, ctx->enc_fc[0], c4, 576, 0, hA, 256, c, true, true, TAG_ENC + 0, nc, m0, st);
         fc(ctx, ctx->enc_fc[1], hA, 256, 0, hB, 256, c, true, true, TAG_ENC + 1, nc, m0, st);
         fc(ctx, ctx->enc_fc[2], hB, 256, 0, hA, 256, c, true, true, TAG_ENC + 2, nc, m0, st);

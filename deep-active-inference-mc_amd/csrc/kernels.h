@@ -92,6 +92,16 @@ struct DecBArgs {
     float* po;            // [slots][rows_per_group][4096] stored images
     int dbg;              // timing experiments only: 1 = skip tap-plane MFMAs, 2 = skip gather/epilogue math
 };
+// fused encoder trunk: o [rows][64][64] -> conv1..conv4 (+ReLU) -> out [rows][576] in NHWC (p*64 + c) order
+struct EncArgs {
+    const float* o; float* out;
+    const float* w1; const float* b1;   // conv1 [9 taps][32], [32]
+    const float* w2; const float* b2;   // packed [9][1][4][64][4]
+    const float* w3; const float* b3;   // packed [9][2][4][64][4]
+    const float* w4; const float* b4;   // packed [9][2][8][64][4]
+    int rows;
+};
+void launch_enc_trunk(const EncArgs& a, hipStream_t st);
 void launch_fc4(const GemmArgs& a, hipStream_t st);      // Linear(256,16384)+ReLU+Dropout with the batch tile staged in LDS
 void launch_dec_a(const DecAArgs& a, hipStream_t st);
 void launch_dec_b(const DecBArgs& a, hipStream_t st);

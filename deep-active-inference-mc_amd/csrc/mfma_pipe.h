@@ -1,0 +1,128 @@
+// Shared MFMA pipeline pieces of the LDS-staged kernels (decoder.hip, encoder.hip): fp32 32x32x2 MFMA macros, the
+// XOR-swizzled LDS image addressing, and the software-pipelined tap contraction (TapPipe).
+#pragma once
+#include "kernels.h"
+
+namespace efe {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: plain loads/stores, no struct memcpy
+
+#define MFMA4(ACC, AV, BV)                                                      \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, (BV).x, ACC, 0, 0, 0);   \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, (BV).y, ACC, 0, 0, 0);   \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, (BV).z, ACC, 0, 0, 0);   \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, (BV).w, ACC, 0, 0, 0);
+
+__device__ __forceinline__ int swz(int pix, int c4) { return pix * 16 + (c4 ^ (pix & 15)); }   // float4 index
+
+// Software-pipelined contraction over `ntaps` taps x 64 input channels (8 chunks of 8): the A fragments (weights,
+// L2) and B fragments (activations, LDS) of chunk i+1 are requested before the MFMAs of chunk i issue, so neither
+// latency is exposed (hipcc otherwise waits for each chunk's loads right before its first MFMA).
+// addr(t, base[NT], sw[NT], wtap): LDS float4 base + swizzle key of every pixel tile and the packed-weight tap index.
+struct ConvWIdx {          // packed conv weights [tap][MT tiles][8 chunks][64 lanes]
+    template <int MT> __device__ __forceinline__ static size_t at(int wt, int mt, int kc) { return (size_t)((wt * MT + mt) * 8 + kc) * 64; }
+};
+struct DenseWIdx {         // packed dense weights [feature tile][32 chunks][64 lanes]; "tap" t = 64-channel slice of K = 256
+    int mt0;
+    template <int MT> __device__ __forceinline__ size_t at(int wt, int mt, int kc) const { return (size_t)((mt0 + mt) * 32 + wt * 8 + kc) * 64; }
+};
+
+// tap -> LDS source of the stride-2 transposed convs (oh = 2*ih - 1 + kh: even output rows use kh=1 (ih=a); odd rows use
+// kh=0 (ih=a+1) and kh=2 (ih=a)); `rows`/`cols` bound the staged image, `zero` is the zero-pixel slot.
+template <int NT>
+struct ConvT2Addr {
+    int ph, pw, row0, row_step, col, rows, cols, zero;
+    __device__ __forceinline__ void operator()(int t, int (&bs)[NT], int (&sw)[NT], int& wt) const {
+        const int th = t / (1 + pw), tw = t - th * (1 + pw);
+        const int kh = ph ? (th ? 2 : 0) : 1, da = (ph && th == 0) ? 1 : 0;
+        const int kw = pw ? (tw ? 2 : 0) : 1, db = (pw && tw == 0) ? 1 : 0;
+        wt = kh * 3 + kw;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int sy = row0 + row_step * nt + da, sx = col + db;
+            const int sp = (sy < rows && sx < cols) ? sy * cols + sx : zero;
+            bs[nt] = sp * 16; sw[nt] = sp & 15;
+        }
+    }
+};
+
+template <int MT, int NT, int KC = 8>
+struct TapPipe {
+    float4 av[MT], bv[NT];       // fragments of the NEXT chunk to be multiplied (already requested)
+    int bs[NT], sw[NT], wt;
+
+    // request the first chunk of a contraction; call it as early as the operands are valid (e.g. before the epilogue
+    // of the previous tile) so that its L2 / LDS latency is covered by that epilogue
+    template <class AddrFn, class WIdx>
+    __device__ __forceinline__ void begin(const float4* __restrict__ Wl, const float4* sm, const int h, AddrFn addr, WIdx widx) {
+        addr(0, bs, sw, wt);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = Wl[widx.template at<MT>(wt, mt, 0)];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = sm[bs[nt] + (h ^ sw[nt])];
+    }
+
+    template <class AddrFn, class WIdx>
+    __device__ __forceinline__ void run(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
+                                        const float4* sm, const int h, AddrFn addr, WIdx widx) {
+        for (int t = 0; t < ntaps; ++t) {
+            int nbs[NT], nsw[NT], nwt;
+            addr((t + 1 < ntaps) ? t + 1 : t, nbs, nsw, nwt);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                float4 an[MT], bn[NT];
+                if (kc < KC - 1) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) an[mt] = Wl[widx.template at<MT>(wt, mt, kc + 1)];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[bs[nt] + ((2 * (kc + 1) + h) ^ sw[nt])];
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) an[mt] = Wl[widx.template at<MT>(nwt, mt, 0)];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[nbs[nt] + (h ^ nsw[nt])];
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch loads AHEAD of this chunk's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { MFMA4(acc[mt][nt], av[mt], bv[nt]) }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = an[mt];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bs[nt] = nbs[nt]; sw[nt] = nsw[nt]; }
+            wt = nwt;
+        }
+    }
+};
+
+template <int MT, int NT, class AddrFn, class WIdx>
+__device__ __forceinline__ void tap_loop(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
+                                         const float4* sm, const int h, AddrFn addr, WIdx widx) {
+    TapPipe<MT, NT> p;
+    p.begin(Wl, sm, h, addr, widx);
+    p.run(acc, ntaps, Wl, sm, h, addr, widx);
+}
+
+
+template <int MT, int NT, int KC, class AddrFn, class WIdx>
+__device__ __forceinline__ void tap_loop_kc(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
+                                            const float4* sm, const int h, AddrFn addr, WIdx widx) {
+    TapPipe<MT, NT, KC> p;
+    p.begin(Wl, sm, h, addr, widx);
+    p.run(acc, ntaps, Wl, sm, h, addr, widx);
+}
+
+// packed weights [tap][mtiles][kcn chunks][64 lanes] with a tile offset
+struct PackedWIdx {
+    int mtiles, kcn, mt0;
+    template <int MT> __device__ __forceinline__ size_t at(int wt, int mt, int kc) const {
+        return (size_t)((wt * mtiles + mt0 + mt) * kcn + kc) * 64;
+    }
+};
+
+}  // namespace efe
