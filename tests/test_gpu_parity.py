@@ -383,3 +383,16 @@ def test_api_errors_are_loud(models):
     import daimc_amd
     p = daimc_amd.MCTS_Params()
     assert daimc_amd.active_inference_mcts(m, [], p) == ([0], 0, 0, [], [])
+
+
+def test_plan_actions_batch_vs_golden(golden, models):
+    """model side of make_batch_dsprites_active_inference (util.py:55-70): posterior of the summed EFE vs the reference's"""
+    import daimc_amd
+    g = golden('rollout_m8d2s2')
+    m = _model(g, models)
+    frames = g['o'][::4]                                  # the golden rows are (frame i, action a) at 4i + a
+    eps = eps_rollout(int(g['nseed']), 8, 2, 2, int(g['stage']))
+    pi0, logP, P, sumG = daimc_amd.plan_actions_batch(m, frames, deepness=2, samples=2, stage=int(g['stage']), eps=eps)
+    np.testing.assert_allclose(c(sumG).reshape(-1), g['sum_G'], atol=2 * gtol(np.array([2800.0])))
+    np.testing.assert_allclose(c(P), g['Ppi'], atol=5e-3)
+    assert pi0.shape == (2, 4) and torch.all(pi0.sum(1) == 1)
