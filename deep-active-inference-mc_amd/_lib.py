@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libefe_mi355x.so')
+LIB_PATH = os.environ.get('EFE_LIB_PATH') or os.path.join(HERE, 'libefe_mi355x.so')    # override: A/B of kernel builds
 
 EXPORTS = ['efe_create', 'efe_destroy', 'efe_last_error', 'efe_abi_version', 'efe_set_weight', 'efe_commit_weights',
            'efe_set_option', 'efe_transition', 'efe_decoder', 'efe_encoder', 'efe_habit', 'efe_calculate_g',

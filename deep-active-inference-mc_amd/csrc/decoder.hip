@@ -19,7 +19,14 @@ namespace efe {
 // ---------------------------------------------------------------------------------------------------------
 // k_dec_a: ConvTranspose2d(64,64,3,s1,p1)+ReLU then ConvTranspose2d(64,64,3,s2,p1,op1)+ReLU, one image per WG.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int DA_BIAS = 257 * 16;          // float4 index of the two bias vectors behind the image + zero pixel
+#ifdef EFE_TIMELINE
+#define TL(i) do { if (a.tl && tid == 0 && blockIdx.x == 0 && tlk < 60) a.tl[tlk++] = clock64(); } while (0)
+#else
+#define TL(i) do {} while (0)
+#endif
 __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
+    int tlk = 0; (void)tlk;
     extern __shared__ __attribute__((aligned(16))) float4 sm[];        // [257 pixels][16 quads]; pixel 256 = zeros
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -41,8 +48,13 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
         for (int it = 0; it < 8; ++it) { pfa[it] = X[it * 256 + tid]; pfb[it] = X[(it + 8) * 256 + tid]; }
     }
     if (tid < 16) sm[256 * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // biases live in LDS: a global bias load inside an epilogue forces s_waitcnt vmcnt(0), i.e. waits for every store
+    // issued before it (vmcnt retires in order) and serialises the whole store stream
+    if (tid < 16) sm[DA_BIAS + tid] = reinterpret_cast<const float4*>(a.b1)[tid];
+    else if (tid < 32) sm[DA_BIAS + tid] = reinterpret_cast<const float4*>(a.b2)[tid - 16];
 
     for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
+        TL(0);
         // stage the 16x16x64 input image (64 KiB) into the swizzled LDS layout
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -51,6 +63,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
             smv[swz(idx2 >> 4, idx2 & 15)] = pfb[it];
         }
         __syncthreads();
+        TL(1);
         const int nimg = img + gridDim.x;
         const bool more = nimg < a.rows;
         {   // request the next image now (clamped on the last pass: unconditional loads keep pf[] in registers)
@@ -78,7 +91,9 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
                 bs[nt] = sp * 16; sw[nt] = sp & 15;
             }
         }, ConvWIdx{});
+        TL(2);
         __syncthreads();            // every wave is done reading the input image
+        TL(3);
         // bias + ReLU, written back IN PLACE as the input image of layer 2 (same swizzled layout)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -88,7 +103,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int c4 = mt * 8 + 2 * g4 + h;
-                    const float4 bb = reinterpret_cast<const float4*>(a.b1)[c4];
+                    const float4 bb = sm[DA_BIAS + c4];
                     float4 v;
                     v.x = fmaxf(acc[mt][nt][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[mt][nt][4 * g4 + 1] + bb.y, 0.f);
                     v.z = fmaxf(acc[mt][nt][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[mt][nt][4 * g4 + 3] + bb.w, 0.f);
@@ -96,6 +111,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
                 }
         }
         __syncthreads();
+        TL(4);
 
         // ---------------- layer 2 (stride 2): 4 output parities, oh = 2*ih - 1 + kh ----------------------------
         float* Y = a.y2 + (size_t)img * (32 * 32 * 64);
@@ -109,6 +125,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
             tap_loop<2, 2>(acc, (1 + ph) * (1 + pw), W2, sm, h, ConvT2Addr<2>{ph, pw, prow0, 2, pcol, 16, 16, 256}, ConvWIdx{});
+            TL(5);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 float* yp = Y + ((size_t)(2 * (prow0 + 2 * nt) + ph) * 32 + (2 * pcol + pw)) * 64;
@@ -117,23 +134,24 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int c4 = mt * 8 + 2 * g4 + h;
-                        const float4 bb = reinterpret_cast<const float4*>(a.b2)[c4];
+                        const float4 bb = sm[DA_BIAS + 16 + c4];
                         float4 v;
                         v.x = fmaxf(acc[mt][nt][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[mt][nt][4 * g4 + 1] + bb.y, 0.f);
                         v.z = fmaxf(acc[mt][nt][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[mt][nt][4 * g4 + 3] + bb.w, 0.f);
-                        if (!(a.dbg & 1) || v.x == 12345.678f) reinterpret_cast<float4*>(yp)[c4] = v;
+                        reinterpret_cast<float4*>(yp)[c4] = v;
                     }
             }
         }
+        TL(9);
         __syncthreads();            // every wave is done reading layer-1's image before the next one overwrites it
     }
 }
 
 void launch_dec_a(const DecAArgs& a, hipStream_t st) {
     static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)k_dec_a, hipFuncAttributeMaxDynamicSharedMemorySize, 257 * 16 * sizeof(float4)); once = true; }
+    if (!once) { (void)hipFuncSetAttribute((const void*)k_dec_a, hipFuncAttributeMaxDynamicSharedMemorySize, (257 * 16 + 32) * sizeof(float4)); once = true; }
     const int grid = a.rows < 512 ? a.rows : 512;         // persistent: 2 workgroups per CU, images strided by the grid
-    hipLaunchKernelGGL(k_dec_a, dim3(grid), dim3(256), 257 * 16 * sizeof(float4), st, a);
+    hipLaunchKernelGGL(k_dec_a, dim3(grid), dim3(256), (257 * 16 + 32) * sizeof(float4), st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -355,6 +373,13 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+        // the step's bias quads are requested BEFORE the contraction: a load placed between the stores would need
+        // s_waitcnt vmcnt(0) and wait for every store ahead of it
+        float4 bq[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) bq[mt][g4] = *reinterpret_cast<const float4*>(a.bias + (mt0 + mt) * 32 + 8 * g4 + 4 * h);
         tap_loop<2, 2>(acc, 4, Wl, sm, h, xaddr, DenseWIdx{mt0});
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -366,7 +391,7 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int co = (mt0 + mt) * 32 + 8 * g4 + 4 * h;
-                    const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
+                    const float4 bb = bq[mt][g4];
                     const uint32_t word = ((co >> 5) & 3) == 0 ? rnd.x : ((co >> 5) & 3) == 1 ? rnd.y : ((co >> 5) & 3) == 2 ? rnd.z : rnd.w;
                     float v[4] = {acc[mt][nt][4 * g4 + 0] + bb.x, acc[mt][nt][4 * g4 + 1] + bb.y,
                                   acc[mt][nt][4 * g4 + 2] + bb.z, acc[mt][nt][4 * g4 + 3] + bb.w};

@@ -53,6 +53,7 @@ struct efe_ctx {
     std::vector<void*> owned;
     Arena arena;
     int64_t dec_chunk = 8192, enc_chunk = 8192, fc4_mt = 2, dbg_a = 0, dbg_b = 0;
+    void* tl_buf = nullptr;   // EFE_TIMELINE experiments: device buffer of 64 int64 stamps (option "tl_buf" = device pointer)
     int64_t last_macs = 0;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
     unsigned prof = 0;        // bitmask of ProfClass values to time
@@ -213,7 +214,7 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         ctx->cls = PROF_CT2;
         DecAArgs da{};
         da.x4 = x4; da.y2 = y2; da.w1 = ctx->dec_ct[0].Wp; da.b1 = ctx->dec_ct[0].bias; da.w2 = ctx->dec_ct[1].Wp;
-        da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.dbg = (int)ctx->dbg_a;
+        da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.dbg = (int)ctx->dbg_a; da.tl = (long long*)ctx->tl_buf;
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_dec_a(da, st);
         ctx->prof_end(e0, st);
@@ -405,6 +406,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return 1;
     if (!strcmp(name, "dec_chunk")) { if (value < 1) return ctx->fail("dec_chunk < 1"); ctx->dec_chunk = value; return 0; }
     if (!strcmp(name, "fc4_mt")) { if (value != 2 && value != 4) return ctx->fail("fc4_mt must be 2 or 4"); ctx->fc4_mt = value; return 0; }
+    if (!strcmp(name, "tl_buf")) { ctx->tl_buf = (void*)(intptr_t)value; return 0; }
     if (!strcmp(name, "dbg_a")) { ctx->dbg_a = value; return 0; }
     if (!strcmp(name, "dbg_b")) { ctx->dbg_b = value; return 0; }
     if (!strcmp(name, "enc_chunk")) { if (value < 1) return ctx->fail("enc_chunk < 1"); ctx->enc_chunk = value; return 0; }

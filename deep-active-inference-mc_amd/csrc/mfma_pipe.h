@@ -3,6 +3,13 @@
 #pragma once
 #include "kernels.h"
 
+#ifndef EFE_PD_WIDE
+#define EFE_PD_WIDE 1      // 2x2 tiles: 16 MFMAs = 1024 cycles per chunk
+#endif
+#ifndef EFE_PD_NARROW
+#define EFE_PD_NARROW 2    // 1x2 / 1x1 tiles: 8 / 4 MFMAs per chunk
+#endif
+
 namespace efe {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -47,18 +54,23 @@ struct ConvT2Addr {
     }
 };
 
-template <int MT, int NT, int KC = 8>
+// PD = prefetch distance of the weight (A) fragments in chunks: they come from L2 (~500-900 cycles under load), and a
+// chunk of MT*NT*4 MFMAs only covers MT*NT*256 cycles, so narrow tiles need PD >= 2.  B fragments (LDS) stay 1 ahead.
+template <int MT, int NT, int KC = 8, int PD = 1>
 struct TapPipe {
-    float4 av[MT], bv[NT];       // fragments of the NEXT chunk to be multiplied (already requested)
+    static_assert(KC % PD == 0, "the A-fragment ring must wrap consistently across taps");
+    float4 aq[PD][MT];           // A fragments of the next PD chunks (already requested)
+    float4 bv[NT];               // B fragments of the next chunk
     int bs[NT], sw[NT], wt;
 
-    // request the first chunk of a contraction; call it as early as the operands are valid (e.g. before the epilogue
-    // of the previous tile) so that its L2 / LDS latency is covered by that epilogue
+    // request the first chunks of a contraction; call it as early as the operands are valid
     template <class AddrFn, class WIdx>
     __device__ __forceinline__ void begin(const float4* __restrict__ Wl, const float4* sm, const int h, AddrFn addr, WIdx widx) {
         addr(0, bs, sw, wt);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt] = Wl[widx.template at<MT>(wt, mt, 0)];
+        for (int p = 0; p < PD; ++p)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) aq[p][mt] = Wl[widx.template at<MT>(wt, mt, p)];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bv[nt] = sm[bs[nt] + (h ^ sw[nt])];
     }
@@ -71,25 +83,33 @@ struct TapPipe {
             addr((t + 1 < ntaps) ? t + 1 : t, nbs, nsw, nwt);
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
-                float4 an[MT], bn[NT];
-                if (kc < KC - 1) {
+                float4 av[MT], bn[NT];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) an[mt] = Wl[widx.template at<MT>(wt, mt, kc + 1)];
+                for (int mt = 0; mt < MT; ++mt) av[mt] = aq[kc % PD][mt];
+                // chunk kc + PD of this tap, or chunk kc + PD - KC of the next one, replaces the slot just consumed
+#ifndef EFE_DBG_NO_A          // timing experiment: skip the weight-fragment loads (wrong results)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    aq[kc % PD][mt] = (kc + PD < KC) ? Wl[widx.template at<MT>(wt, mt, kc + PD)]
+                                                     : Wl[widx.template at<MT>(nwt, mt, kc + PD - KC)];
+#endif
+#ifdef EFE_DBG_NO_B           // timing experiment: skip the LDS activation-fragment reads (wrong results)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bn[nt] = bv[nt];
+#else
+                if (kc < KC - 1) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[bs[nt] + ((2 * (kc + 1) + h) ^ sw[nt])];
                 } else {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) an[mt] = Wl[widx.template at<MT>(nwt, mt, 0)];
-#pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[nbs[nt] + (h ^ nsw[nt])];
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch loads AHEAD of this chunk's MFMAs (hipcc sinks them otherwise)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) { MFMA4(acc[mt][nt], av[mt], bv[nt]) }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt] = an[mt];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
             }
@@ -103,7 +123,7 @@ struct TapPipe {
 template <int MT, int NT, class AddrFn, class WIdx>
 __device__ __forceinline__ void tap_loop(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
                                          const float4* sm, const int h, AddrFn addr, WIdx widx) {
-    TapPipe<MT, NT> p;
+    TapPipe<MT, NT, 8, (MT * NT >= 4 ? EFE_PD_WIDE : EFE_PD_NARROW)> p;
     p.begin(Wl, sm, h, addr, widx);
     p.run(acc, ntaps, Wl, sm, h, addr, widx);
 }
@@ -112,7 +132,7 @@ __device__ __forceinline__ void tap_loop(f32x16 (&acc)[MT][NT], const int ntaps,
 template <int MT, int NT, int KC, class AddrFn, class WIdx>
 __device__ __forceinline__ void tap_loop_kc(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
                                             const float4* sm, const int h, AddrFn addr, WIdx widx) {
-    TapPipe<MT, NT, KC> p;
+    TapPipe<MT, NT, KC, EFE_PD_NARROW> p;
     p.begin(Wl, sm, h, addr, widx);
     p.run(acc, ntaps, Wl, sm, h, addr, widx);
 }
