@@ -143,6 +143,7 @@ def main():
     ap.add_argument('--workload', default='rollout', choices=['rollout', 'mcts'],
                     help="'mcts' = BASELINE configs[2]: full lock-step MCTS (50 expansions, 10 samples, sim depth 5) over 64 episodes/GPU (secondary metric)")
     ap.add_argument('--episodes', type=int, default=64)
+    ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path on a 1-GPU box')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-prof', action='store_true')
     a = ap.parse_args()
@@ -151,8 +152,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
@@ -177,7 +181,7 @@ def main():
     def step(k):
         G, _, _ = model.calculate_G_repeated(o, pi, steps=D, samples=S, stage=k * D)
         P, _ = model.action_posterior(G)
-        if world > 1:
+        if use_dist:
             daimc_amd.gather_action_posteriors(P, world * (R // 4))      # the only RCCL traffic: [R/4, 4] floats per rank
         return G
 
@@ -185,7 +189,7 @@ def main():
     for k in range(a.warmup):
         step(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     DOM = 'dec_b_convT3_final_reduce'
     if not a.no_prof:
@@ -195,7 +199,7 @@ def main():
     for k in range(a.steps):
         G = step(a.warmup + k)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     print(f'[bench] rank {rank}: timed region {dt:.3f}s', file=sys.stderr, flush=True)
@@ -207,7 +211,7 @@ def main():
         step(a.warmup + a.steps)
         breakdown = model.prof_read()
     model.prof_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -257,7 +261,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(D, S)
             out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

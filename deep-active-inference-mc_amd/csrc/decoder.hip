@@ -155,6 +155,13 @@ void launch_dec_a(const DecAArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+#ifdef EFE_FAST_MATH_EPILOGUE
+#define EFE_EXP __expf
+#define EFE_LOG __logf
+#else
+#define EFE_EXP expf
+#define EFE_LOG logf
+#endif
 // k_dec_b: ConvTranspose2d(64,32,3,s2,p1,op1)+ReLU, ConvTranspose2d(32,1,3,s1,p1)+Sigmoid and the per-image
 // reduction, one image per WG, 8 strips of 4 input rows (8 output rows).
 //
@@ -293,9 +300,9 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
                     if (tc >= 0 && tc < 64) v += trow[kw * 64 + tc];
                 }
             }
-            const float pr = 1.0f / (1.0f + expf(-v));
+            const float pr = 1.0f / (1.0f + EFE_EXP(-v));
             if (po) po[oh * 64 + ow] = pr;
-            if (mode == 0) part += -(1.0f - pr) * logf(D1 - pr) - pr * logf(D0 + pr);
+            if (mode == 0) part += -(1.0f - pr) * EFE_LOG(D1 - pr) - pr * EFE_LOG(D0 + pr);
             else           // target = 1 for image rows h < 32, 0 below (NCHW broadcast of the port)
                 part += (oh < 32) ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f) : pr * logf(D0) + (1.0f - pr) * logf(D1);
         }
