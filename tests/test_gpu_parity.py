@@ -396,3 +396,56 @@ def test_plan_actions_batch_vs_golden(golden, models):
     np.testing.assert_allclose(c(sumG).reshape(-1), g['sum_G'], atol=2 * gtol(np.array([2800.0])))
     np.testing.assert_allclose(c(P), g['Ppi'], atol=5e-3)
     assert pi0.shape == (2, 4) and torch.all(pi0.sum(1) == 1)
+
+
+def test_full_depth_rollout_vs_oracle(models, weights_cache):
+    """BASELINE cfg-2 depth and sample count (D=5, S=10) on 4 rows against the CPU oracle"""
+    seed, st, M, D, S = 61, 7, 4, 5, 10
+    w = weights_cache(1234, 1.15)
+    m = models(1234, 1.15, seed)
+    orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
+    o = np.repeat(synth.make_frames(71, 1), 4, axis=0)
+    pi = np.eye(4, dtype=np.float32)
+    with torch.no_grad():
+        oG, oT, opo1 = orc.calculate_G_repeated(torch.from_numpy(o), torch.from_numpy(pi), D, False, S, st)
+    G, T, po1 = m.calculate_G_repeated(o, pi, steps=D, samples=S, stage=st, eps=eps_rollout(seed, M, D, S, st))
+    np.testing.assert_allclose(c(T[0]), oT[0].numpy(), atol=5e-3)
+    np.testing.assert_allclose(c(T[1]), oT[1].numpy(), atol=5e-3)
+    np.testing.assert_allclose(c(G), oG.numpy(), atol=D * gtol(np.array([2800.0])))
+    np.testing.assert_allclose(c(po1), opo1.numpy(), rtol=1e-5, atol=5e-5)
+
+
+def test_simulate_batch_vs_oracle_per_episode(models, weights_cache):
+    """E lock-step episodes == E independent reference-style simulations (global episode keys)"""
+    seed, st, E, T = 71, 12, 3, 4
+    w = weights_cache(1234, 1.15)
+    m = models(1234, 1.15, seed)
+    starts = PX.uniform_fill(8, (E, 10), 910, -1, 1)
+    G, pi0, q0 = m.simulate_batch(starts, T, use_means=False, stage=st, row_offset=5)
+    orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
+    for e in range(E):
+        with torch.no_grad():
+            oG, opi0, oq = orc.mcts_step_simulate(torch.from_numpy(starts[e]), T, False, st, episode=5 + e)
+        assert np.array_equal(c(pi0[e]), opi0.numpy())
+        np.testing.assert_allclose(c(q0[e]), oq.numpy(), rtol=1e-5, atol=1e-6)
+        assert abs(float(G[e]) - oG) < 0.05
+
+
+def test_mcts_habit_shortcut_and_prior_exploration(models):
+    import daimc_amd
+    m = models(1234, 1.15, 81)
+    frame = torch.from_numpy(synth.make_frames(91, 1)[0])
+    p = daimc_amd.MCTS_Params()
+    p.repeats, p.simulation_depth, p.threshold = 4, 2, 0.9
+    p.use_habit = True
+    p.threshold = -1.0                     # habit posterior always "confident": decision in phase A (mcts.py:166-170)
+    m._stage = 0
+    path, reps, explored, ap, ag = daimc_amd.active_inference_mcts(m, frame, p, o_shape=(1, 64, 64))
+    assert len(path) == 1 and 0 <= path[0] < 4 and reps == 0 and explored == 0
+    p.use_habit, p.threshold, p.using_prior_for_exploration = False, 0.9, True
+    m._stage = 0
+    path, reps, explored, ap, ag = daimc_amd.active_inference_mcts(m, frame, p, o_shape=(1, 64, 64))
+    assert reps == 4 and explored == 8 and len(ap) == 4 and all(np.isfinite(ag))
+    m._stage = 0
+    out, dist = daimc_amd.active_inference_mcts_batch(m, frame[None], p, o_shape=(1, 64, 64))
+    assert out[0][0] == path and out[0][3] == [[int(a) for a in q] for q in ap]
