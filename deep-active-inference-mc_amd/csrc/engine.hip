@@ -52,7 +52,7 @@ struct efe_ctx {
     float* zeros = nullptr;
     std::vector<void*> owned;
     Arena arena;
-    int64_t dec_chunk = 8192, enc_chunk = 8192, fc4_mt = 2, dbg_a = 0, dbg_b = 0;
+    int64_t dec_chunk = 32768, enc_chunk = 32768, fc4_mt = 2, dbg_a = 0, dbg_b = 0;
     void* tl_buf = nullptr;   // EFE_TIMELINE experiments: device buffer of 64 int64 stamps (option "tl_buf" = device pointer)
     int64_t last_macs = 0;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)

@@ -213,7 +213,7 @@ def test_chunking_invariance(models):
     G1, _, po1 = m.calculate_G_repeated(o, pi, steps=2, samples=3, stage=3)
     m.set_option('dec_chunk', 7); m.set_option('enc_chunk', 5)
     G2, _, po2 = m.calculate_G_repeated(o, pi, steps=2, samples=3, stage=3)
-    m.set_option('dec_chunk', 8192); m.set_option('enc_chunk', 8192)
+    m.set_option('dec_chunk', 32768); m.set_option('enc_chunk', 32768)
     assert torch.equal(G1, G2) and torch.equal(po1, po2)
 
 
