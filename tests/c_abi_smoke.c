@@ -1,0 +1,103 @@
+/* Plain-C consumer of include/efe_engine.h: no Python, no torch -- the drop-in boundary is a C ABI.
+ * Build:  gcc tests/c_abi_smoke.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -L<pkg> -lefe_mi355x -L/opt/rocm/lib -lamdhip64 -lm
+ * Loads random weights of the reference architecture (state_dict key names of SURVEY 8b), runs ModelDown.decoder,
+ * calculate_G and the action posterior on device buffers, checks ranges / determinism. */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "efe_engine.h"
+
+#define CHECK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "FAIL %s -> %d (%s)\n", #x, rc_, efe_last_error(ctx)); return 1; } } while (0)
+#define HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP FAIL %s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+static unsigned long long s_ = 88172645463325252ULL;
+static float urand(void) { s_ ^= s_ << 13; s_ ^= s_ >> 7; s_ ^= s_ << 17; return (float)((s_ >> 40) / 16777216.0) * 2.f - 1.f; }
+
+static int set_w(efe_ctx* ctx, const char* key, int64_t d0, int64_t d1, int64_t d2, int64_t d3, float bound) {
+    int64_t shape[4] = {d0, d1, d2, d3};
+    int nd = d3 ? 4 : d2 ? 3 : d1 ? 2 : 1;
+    size_t n = 1;
+    for (int i = 0; i < nd; ++i) n *= (size_t)shape[i];
+    float* h = (float*)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; ++i) h[i] = urand() * bound;
+    int rc = efe_set_weight(ctx, key, h, shape, nd);
+    free(h);
+    return rc;
+}
+
+static int lin(efe_ctx* ctx, const char* name, int out, int in) {
+    char k[96];
+    snprintf(k, sizeof k, "%s.weight", name);
+    if (set_w(ctx, k, out, in, 0, 0, sqrtf(3.f / in))) return 1;
+    snprintf(k, sizeof k, "%s.bias", name);
+    return set_w(ctx, k, out, 0, 0, 0, 0.1f);
+}
+
+static int conv(efe_ctx* ctx, const char* name, int d0, int d1, int nbias, float fan) {
+    char k[96];
+    snprintf(k, sizeof k, "%s.weight", name);
+    if (set_w(ctx, k, d0, d1, 3, 3, sqrtf(3.f / fan))) return 1;
+    snprintf(k, sizeof k, "%s.bias", name);
+    return set_w(ctx, k, nbias, 0, 0, 0, 0.1f);
+}
+
+int main(void) {
+    efe_ctx* ctx = NULL;
+    if (efe_abi_version() != 1) { fprintf(stderr, "abi version\n"); return 1; }
+    if (efe_create(&ctx, 0)) { fprintf(stderr, "efe_create failed (no HIP device?)\n"); return 2; }
+    CHECK(lin(ctx, "top.qpi_net.0", 128, 10)); CHECK(lin(ctx, "top.qpi_net.2", 128, 128)); CHECK(lin(ctx, "top.qpi_net.4", 4, 128));
+    CHECK(lin(ctx, "mid.ps_net.0", 512, 14)); CHECK(lin(ctx, "mid.ps_net.3", 512, 512)); CHECK(lin(ctx, "mid.ps_net.6", 512, 512));
+    CHECK(lin(ctx, "mid.ps_net.9", 20, 512));
+    CHECK(conv(ctx, "down.qs_net.0", 32, 1, 32, 9)); CHECK(conv(ctx, "down.qs_net.2", 32, 32, 32, 288));
+    CHECK(conv(ctx, "down.qs_net.4", 64, 32, 64, 288)); CHECK(conv(ctx, "down.qs_net.6", 64, 64, 64, 576));
+    CHECK(lin(ctx, "down.qs_net.9", 256, 576)); CHECK(lin(ctx, "down.qs_net.12", 256, 256)); CHECK(lin(ctx, "down.qs_net.15", 256, 256));
+    CHECK(lin(ctx, "down.qs_net.18", 20, 256));
+    CHECK(lin(ctx, "down.po_net.0", 256, 10)); CHECK(lin(ctx, "down.po_net.3", 256, 256)); CHECK(lin(ctx, "down.po_net.6", 256, 256));
+    CHECK(lin(ctx, "down.po_net.9", 16384, 256));
+    CHECK(conv(ctx, "down.po_net.13", 64, 64, 64, 576)); CHECK(conv(ctx, "down.po_net.15", 64, 64, 64, 144));
+    CHECK(conv(ctx, "down.po_net.17", 64, 32, 32, 144)); CHECK(conv(ctx, "down.po_net.19", 32, 1, 1, 288));
+    CHECK(efe_commit_weights(ctx));
+
+    enum { M = 8, S = 3 };
+    float hs[M * 10], hpi[M * 4];
+    for (int i = 0; i < M * 10; ++i) hs[i] = urand();
+    memset(hpi, 0, sizeof hpi);
+    for (int i = 0; i < M; ++i) hpi[i * 4 + (i & 3)] = 1.f;
+    float *ds, *dpi, *dpo, *dG, *dT, *dps1, *dmean, *dpo1, *dP, *dlogP;
+    HIP(hipMalloc((void**)&ds, sizeof hs)); HIP(hipMalloc((void**)&dpi, sizeof hpi));
+    HIP(hipMalloc((void**)&dpo, M * 4096 * 4)); HIP(hipMalloc((void**)&dG, M * 4)); HIP(hipMalloc((void**)&dT, 3 * M * 4));
+    HIP(hipMalloc((void**)&dps1, M * 40)); HIP(hipMalloc((void**)&dmean, M * 40)); HIP(hipMalloc((void**)&dpo1, M * 4096 * 4));
+    HIP(hipMalloc((void**)&dP, M * 4)); HIP(hipMalloc((void**)&dlogP, M * 4));
+    HIP(hipMemcpy(ds, hs, sizeof hs, hipMemcpyHostToDevice)); HIP(hipMemcpy(dpi, hpi, sizeof hpi, hipMemcpyHostToDevice));
+
+    efe_noise nz = {1234u, 0u, 1u, 0u, 0u};
+    CHECK(efe_decoder(ctx, ds, M, &nz, dpo, NULL));
+    float* hpo = (float*)malloc(M * 4096 * 4);
+    HIP(hipMemcpy(hpo, dpo, M * 4096 * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < M * 4096; ++i) if (!(hpo[i] >= 0.f && hpo[i] <= 1.f)) { fprintf(stderr, "decoder output out of [0,1]\n"); return 1; }
+
+    float hG[2][M];
+    for (int rep = 0; rep < 2; ++rep) {          /* same keys -> bit-identical results */
+        CHECK(efe_calculate_g(ctx, ds, dpi, M, S, 0, &nz, NULL, dG, dT, dps1, dmean, dpo1, NULL, NULL));
+        HIP(hipMemcpy(hG[rep], dG, M * 4, hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < M; ++i) {
+        if (!isfinite(hG[0][i]) || hG[0][i] != hG[1][i]) { fprintf(stderr, "calculate_G not finite/deterministic\n"); return 1; }
+    }
+    CHECK(efe_action_posterior(ctx, dG, M / 4, 4, 10.0f, dP, dlogP, NULL));
+    float hP[M];
+    HIP(hipMemcpy(hP, dP, M * 4, hipMemcpyDeviceToHost));
+    for (int g = 0; g < M / 4; ++g) {
+        float t = hP[4 * g] + hP[4 * g + 1] + hP[4 * g + 2] + hP[4 * g + 3];
+        if (fabsf(t - 1.f) > 1e-5f) { fprintf(stderr, "posterior does not sum to 1\n"); return 1; }
+    }
+    /* error path: bad argument -> non-zero + message, context still usable */
+    if (efe_decoder(ctx, ds, 0, &nz, dpo, NULL) == 0) { fprintf(stderr, "M = 0 accepted\n"); return 1; }
+    if (strlen(efe_last_error(ctx)) == 0) { fprintf(stderr, "no error message\n"); return 1; }
+    CHECK(efe_decoder(ctx, ds, M, &nz, dpo, NULL));
+    printf("c_abi_smoke OK  G[0]=%g  macs(last call)=%lld\n", hG[0][0], (long long)efe_last_call_macs(ctx));
+    efe_destroy(ctx);
+    return 0;
+}

@@ -449,3 +449,19 @@ def test_mcts_habit_shortcut_and_prior_exploration(models):
     m._stage = 0
     out, dist = daimc_amd.active_inference_mcts_batch(m, frame[None], p, o_shape=(1, 64, 64))
     assert out[0][0] == path and out[0][3] == [[int(a) for a in q] for q in ap]
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """compile and run tests/c_abi_smoke.c: the boundary is usable from C with nothing but the header and the .so"""
+    import subprocess
+    from conftest import ROOT
+    import os
+    pkg = os.path.join(ROOT, 'deep-active-inference-mc_amd')
+    exe = str(tmp_path / 'c_abi_smoke')
+    cmd = ['gcc', os.path.join(ROOT, 'tests', 'c_abi_smoke.c'), '-I' + os.path.join(ROOT, 'include'), '-I/opt/rocm/include',
+           '-D__HIP_PLATFORM_AMD__', '-L' + pkg, '-lefe_mi355x', '-L/opt/rocm/lib', '-lamdhip64', '-lm',
+           '-Wl,-rpath,' + pkg, '-Wl,-rpath,/opt/rocm/lib', '-o', exe]
+    subprocess.run(cmd, check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'c_abi_smoke OK' in r.stdout
