@@ -163,7 +163,7 @@ void launch_dec_a(const DecAArgs& a, hipStream_t st) {
 #define EFE_LOG logf
 #endif
 // k_dec_b: ConvTranspose2d(64,32,3,s2,p1,op1)+ReLU, ConvTranspose2d(32,1,3,s1,p1)+Sigmoid and the per-image
-// reduction, one image per WG, 8 strips of 4 input rows (8 output rows).
+// reduction, one image per WG, strips of SR input rows (2*SR output rows).
 //
 // The 32->1 conv is applied to the layer-3 accumulators while they are still in registers: for each finished
 // 32(co) x 32(pixel) tile, 16 extra MFMAs contract the channel axis against the 9 taps,
@@ -173,14 +173,20 @@ void launch_dec_a(const DecAArgs& a, hipStream_t st) {
 // and the 3x3 "gather"  out[oh,ow] = b4 + sum_{kh,kw} T[kh*3+kw][oh+1-kh][ow+1-kw]  is done once the rows
 // above and below exist.  y3 (512 KiB per image) never exists in memory.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int DB_ZERO = 160;                 // zero pixel slot of the 5-row input strip
-constexpr int DB_IN_F4 = (160 + 1) * 16;     // float4s
-constexpr int DB_YROWS = 10;
-
-__global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
+// SR = input rows per strip = waves per workgroup.  SR = 4: 256 threads, 8 strips, 64 KiB LDS, 2 workgroups per CU.
+// SR = 2: 128 threads, 16 strips, 38 KiB LDS, 4 workgroups per CU -- the same 8 waves per CU, but four independent
+// phase streams instead of two, and barriers that only join two waves.
+template <int SR>
+__global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
+    constexpr int NTHR = 64 * SR;
+    constexpr int DB_ZERO = (SR + 1) * 32;            // zero pixel slot behind the (SR+1)-row input strip
+    constexpr int DB_IN_F4 = (DB_ZERO + 1) * 16;      // float4s
+    constexpr int DB_YROWS = 2 * SR + 2;              // tap-plane ring: the strip's 2*SR rows + 2 kept from the previous one
+    constexpr int NPF = (SR + 1) * 512 / NTHR;        // float4s of the input strip per thread
+    constexpr int NS = 32 / SR;                       // strips per image
     extern __shared__ __attribute__((aligned(16))) float4 sm[];        // input strip, then T ring
-    float* sT = reinterpret_cast<float*>(sm + DB_IN_F4);               // [10 rows][9 taps][64 cols]
-    __shared__ float sred[4];
+    float* sT = reinterpret_cast<float*>(sm + DB_IN_F4);               // [ring rows][9 taps][64 cols]
+    __shared__ float sred[SR];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,27 +217,27 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
     const float4* W3 = reinterpret_cast<const float4*>(a.w3) + lane;
     const float D1 = 1.00001f, D0 = 0.00001f;      // fp32 constants of log_bernoulli / entropy_bernoulli
     float part = 0.f;
-    f32x4 pf[10];                                                      // input strip in flight
+    f32x4 pf[NPF];                                                     // input strip in flight
     f32x4* smv = reinterpret_cast<f32x4*>(sm);
     const f32x4* Xv = reinterpret_cast<const f32x4*>(X);
 #pragma unroll
-    for (int it = 0; it < 10; ++it) pf[it] = Xv[it * 256 + tid];       // strip 0 = rows 0..4 (contiguous)
+    for (int it = 0; it < NPF; ++it) pf[it] = Xv[it * NTHR + tid];     // strip 0 = rows 0..SR (contiguous)
 
-    for (int s = 0; s < 8; ++s) {
-        // ---- stage input rows 4s .. 4s+4 (row 32 does not exist: zeros); the data was requested one strip earlier
+    for (int s = 0; s < NS; ++s) {
+        // ---- stage input rows SR*s .. SR*s+SR (row 32 does not exist: zeros); the data was requested one strip earlier
 #pragma unroll
-        for (int it = 0; it < 10; ++it) {
-            const int idx = it * 256 + tid;                            // 0..2559 = 5 rows x 32 px x 16 quads
+        for (int it = 0; it < NPF; ++it) {
+            const int idx = it * NTHR + tid;                           // (SR+1) rows x 32 px x 16 quads
             const int rl = idx >> 9, rem = idx & 511;
-            smv[swz(rl * 32 + (rem >> 4), rem & 15)] = (4 * s + rl < 32) ? pf[it] : (f32x4)(0.f);
+            smv[swz(rl * 32 + (rem >> 4), rem & 15)] = (SR * s + rl < 32) ? pf[it] : (f32x4)(0.f);
         }
         __syncthreads();
         {   // request strip s+1 now (it lands during the MFMA phase); rows >= 32 are clamped here and zeroed when staged
-            const int sn = (s < 7) ? s + 1 : 7;
+            const int sn = (s < NS - 1) ? s + 1 : NS - 1;
 #pragma unroll
-            for (int it = 0; it < 10; ++it) {
-                const int idx = it * 256 + tid;
-                const int grow = min(4 * sn + (idx >> 9), 31);
+            for (int it = 0; it < NPF; ++it) {
+                const int idx = it * NTHR + tid;
+                const int grow = min(SR * sn + (idx >> 9), 31);
                 pf[it] = Xv[(size_t)grow * 512 + (idx & 511)];
             }
         }
@@ -265,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
                 // D layout: T[4b + r] = D_b[row = 4*(lane>>4) + r][col = lane&15]; pixel p = 16*(b&1) + col, and the two
                 // channel halves (b, b+2) of the same pixel sit in the same lane: add them.
                 const int tq = lane >> 4, c = lane & 15;               // this lane holds taps 4*tq + r
-                const int orow = 2 * (4 * s + 2 * rp + nt) + ph;
+                const int orow = 2 * (SR * s + 2 * rp + nt) + ph;
                 float* tp = sT + ((orow % DB_YROWS) * 9 + 4 * tq) * 64 + pw;
                 if (tq < 2) {
 #pragma unroll
@@ -281,12 +287,12 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
         }
         __syncthreads();
 
-        // ---- gather: output rows 8s-1 .. 8s+6 are complete now (row 63 after the last strip)
-        const int nq = (a.dbg & 2) ? 0 : (s == 7) ? 3 : 2;
+        // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete now (row 63 after the last strip)
+        const int nq = (a.dbg & 2) ? 0 : (s == NS - 1) ? 3 : 2;
         for (int q = 0; q < nq; ++q) {
-            const int p = q * 256 + tid;
+            const int p = q * NTHR + tid;
             if (q == 2 && tid >= 64) break;
-            const int oh = 8 * s - 1 + (p >> 6), ow = p & 63;
+            const int oh = 2 * SR * s - 1 + (p >> 6), ow = p & 63;
             if (oh < 0) continue;
             float v = a.b4;
 #pragma unroll
@@ -313,12 +319,21 @@ __global__ void __launch_bounds__(256, 2) k_dec_b(const DecBArgs a) {
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
     if (lane == 0) sred[w] = part;
     __syncthreads();
-    if (tid == 0) a.val[mg] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    if (tid == 0) {
+        float tot = sred[0] + sred[1];
+        if (SR == 4) tot += sred[2] + sred[3];      // (s0 + s1) + (s2 + s3): fixed order
+        a.val[mg] = tot;
+    }
 }
 
 void launch_dec_b(const DecBArgs& a, hipStream_t st) {
-    const size_t lds = DB_IN_F4 * sizeof(float4) + DB_YROWS * 9 * 64 * sizeof(float);
-    hipLaunchKernelGGL(k_dec_b, dim3(a.rows), dim3(256), lds, st, a);
+    if (!(a.dbg & 8)) {       // default: 4-wave workgroups, 4-row strips (2-wave / 2-row variant measured 5 % slower; kept for A/B)
+        const size_t lds = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 64 * sizeof(float);
+        hipLaunchKernelGGL(k_dec_b<4>, dim3(a.rows), dim3(256), lds, st, a);
+    } else {
+        const size_t lds = ((3 * 32 + 1) * 16) * sizeof(float4) + 6 * 9 * 64 * sizeof(float);
+        hipLaunchKernelGGL(k_dec_b<2>, dim3(a.rows), dim3(128), lds, st, a);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
