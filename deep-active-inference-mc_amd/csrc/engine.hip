@@ -52,7 +52,7 @@ struct efe_ctx {
     float* zeros = nullptr;
     std::vector<void*> owned;
     Arena arena;
-    int64_t dec_chunk = 32768, enc_chunk = 32768, fc4_mt = 2, dbg_a = 0, dbg_b = 0;
+    int64_t dec_chunk = 32768, enc_chunk = 32768, dbg_a = 0, dbg_b = 0;
     void* tl_buf = nullptr;   // EFE_TIMELINE experiments: device buffer of 64 int64 stamps (option "tl_buf" = device pointer)
     int64_t last_macs = 0;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
@@ -154,26 +154,17 @@ void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float*
     a.n_pix = M; a.cin = L.cin; a.cout = L.cout; a.mtiles = L.mtiles; a.ldx = ldx; a.ldy = ldy; a.x_mod = x_mod;
     a.relu = relu; a.dropout = drop; a.tag = tag; a.k0 = nc.k0; a.k1 = nc.k1; a.gm = nc.gm;
     a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = m0;
-    // tile shape by problem size: small launches (transition / habit / encoder head) use 32x32 wave tiles so that the
-    // grid still covers the 256 CUs; the big 256->16384 layer takes the largest feature tile (fewest activation re-reads)
-    int MT = L.mtiles == 1 ? 1 : 2, NT = 2;
-    if (L.mtiles >= 64) MT = (int)ctx->fc4_mt;
-    else {
+    hipEvent_t e0 = ctx->prof_begin(st);
+    if (L.mtiles == 512 && L.cin == 256 && ldx == 256 && x_mod == 0 && relu && drop) {
+        launch_fc4(a, st);          // Linear(256,16384): batch tile staged in LDS
+    } else {
+        // tile shape by problem size: small launches (transition / habit / heads) use 32x32 wave tiles so that the
+        // grid still covers the 256 CUs
+        int MT = L.mtiles == 1 ? 1 : 2, NT = 2;
         const long tiles22 = (long)((L.mtiles + MT - 1) / MT) * ((M + 63) / 64);
         if (tiles22 < 2048) { NT = 1; if (tiles22 * 2 < 2048) MT = 1; }
+        launch_dense(MT, NT, a, st);
     }
-    hipEvent_t e0 = ctx->prof_begin(st);
-    if (L.mtiles == 512 && L.cin == 256 && ldx == 256 && x_mod == 0 && relu && drop && ctx->fc4_mt == 2) { a.x_mod = (int)(ctx->dbg_a & 4); launch_fc4(a, st); }
-    else launch_tapgemm(MODE_FC, MT, NT, a, st);
-    ctx->prof_end(e0, st);
-}
-
-void conv(efe_ctx* ctx, int mode, int MT, int NT, const Layer& L, const float* X, float* Y, int n_pix, int geo_n, int geo_o, hipStream_t st) {
-    GemmArgs a{};
-    a.Wp = L.Wp; a.bias = L.bias; a.X = X; a.Y = Y; a.zeros = ctx->zeros;
-    a.n_pix = n_pix; a.cin = L.cin; a.cout = L.cout; a.mtiles = L.mtiles; a.geo_n = geo_n; a.geo_o = geo_o; a.relu = 1;
-    hipEvent_t e0 = ctx->prof_begin(st);
-    launch_tapgemm(mode, MT, NT, a, st);
     ctx->prof_end(e0, st);
 }
 
@@ -405,7 +396,6 @@ int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const 
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return 1;
     if (!strcmp(name, "dec_chunk")) { if (value < 1) return ctx->fail("dec_chunk < 1"); ctx->dec_chunk = value; return 0; }
-    if (!strcmp(name, "fc4_mt")) { if (value != 2 && value != 4) return ctx->fail("fc4_mt must be 2 or 4"); ctx->fc4_mt = value; return 0; }
     if (!strcmp(name, "tl_buf")) { ctx->tl_buf = (void*)(intptr_t)value; return 0; }
     if (!strcmp(name, "dbg_a")) { ctx->dbg_a = value; return 0; }
     if (!strcmp(name, "dbg_b")) { ctx->dbg_b = value; return 0; }

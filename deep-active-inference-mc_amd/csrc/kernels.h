@@ -1,28 +1,24 @@
-// Device kernels of the EFE rollout engine (gfx950 / CDNA4 only).
+// Device kernels of the EFE rollout engine (gfx950 / CDNA4 only): shared argument structs and launchers.
 //
-// One MFMA "tap-GEMM" template covers every dense contraction on the hot path
-// (reference layers: /root/reference/src/torchmodel.py:41-52 ps_net, :84-104 qs_net, :106-128 po_net,
-//  :19-25 qpi_net):
+// Every dense contraction on the hot path (reference layers: /root/reference/src/torchmodel.py:41-52 ps_net,
+// :84-104 qs_net, :106-128 po_net, :19-25 qpi_net) has the same MFMA mapping:
 //
-//      Y^T[co, m] = act( bias[co] + sum_{tap} sum_{ci} Wtap[co, ci] * X[src(m, tap), ci] )
+//   * MFMA rows  = output features (A operand = weights, pre-packed fragment-major so every wave-level load is one
+//                  fully coalesced 1 KiB global_load_dwordx4),
+//   * MFMA cols  = batch rows / output pixels (B operand = NHWC activations, 16 B per lane, from LDS in the fused
+//                  kernels or straight from L2 in k_dense),
+//   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD,
+//   * a lane owns ONE batch row / pixel and 16 features per 32x32 tile, so the MC-dropout mask of a row is one Philox
+//     call per 128 features, generated in the epilogue; no mask is ever stored.
 //
-//   * MFMA rows  = output features (A operand = weights, pre-packed fragment-major so every
-//                  wave-level load is one fully coalesced 1 KiB global_load_dwordx4),
-//   * MFMA cols  = batch rows / output pixels (B operand = NHWC activations, 16 B per lane),
-//   * v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD.
-//   * a lane owns ONE batch row / pixel and 16 features per 32x32 tile, so the MC-dropout mask of a
-//     row is one Philox call per 128 features, generated in the epilogue; no mask is ever stored.
-//
-// Small VALU kernels handle the Cin=1 / Cout=1 convolutions, reparameterisation and the EFE term
-// reductions (wavefront shuffles).
+// kernels.hip: k_dense + the small VALU kernels (reparameterisation, term combine, softmax, sampling);
+// decoder.hip: k_fc4, k_dec_a, k_dec_b;  encoder.hip: k_enc_trunk;  mfma_pipe.h: the shared software pipeline.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "philox.h"
 
 namespace efe {
-
-enum GemmMode { MODE_FC = 0, MODE_CONVT_S1 = 1, MODE_CONVT_S2 = 2, MODE_CONV_S2 = 3 };
 
 // The batch of one launch is [group][row]: a group is one network evaluation ("pass") over the same
 // rows_per_group logical rows.  Group g of a multi-stage batch decomposes as t = g / per_stage (stage),
@@ -51,16 +47,14 @@ struct GemmArgs {
     const float* X;       // input activations
     float* Y;             // output activations
     const float* zeros;   // >= 4 KiB of zeros (source for padded taps / out-of-range rows)
-    int n_pix;            // GEMM columns in this launch (batch rows, or pixels of the m-grid)
+    int n_pix;            // GEMM columns in this launch (batch rows)
     int cin;              // K per tap (multiple of 8)
     int cout;             // real output features (multiple of 4)
     int mtiles;           // 32-feature tiles in the packed weights
-    int ldx, ldy;         // FC: row strides in floats
-    int x_mod;            // FC: if > 0 the input row is (m % x_mod)  (same input for every MC pass)
-    int geo_n;            // conv: input grid edge (ConvT s1: H; ConvT s2: n; Conv s2: Hin)
-    int geo_o;            // Conv s2: output grid edge
+    int ldx, ldy;         // row strides in floats
+    int x_mod;            // if > 0 the input row is (m % x_mod)  (same input for every MC pass)
     int relu;
-    // MC-dropout (FC only): keep-mask * 2.0 from Philox, keyed by (tag, global row, group key)
+    // MC-dropout: keep-mask * 2.0 from Philox, keyed by (tag, global row, group key)
     int dropout;
     uint32_t tag, k0, k1;
     GroupMap gm;          // group index -> (stream id, stage)
@@ -107,8 +101,7 @@ void launch_fc4(const GemmArgs& a, hipStream_t st);      // Linear(256,16384)+Re
 void launch_dec_a(const DecAArgs& a, hipStream_t st);
 void launch_dec_b(const DecBArgs& a, hipStream_t st);
 
-void launch_tapgemm(int mode, int MT, int NT, const GemmArgs& a, hipStream_t st);
-void launch_enc_conv1(const float* o, const float* w1, const float* b1, float* y, int rows, hipStream_t st);
+void launch_dense(int MT, int NT, const GemmArgs& a, hipStream_t st);
 
 struct TransPostArgs {
     const float* tr;       // [2S][R][32] (mean 0..9, logvar 10..19); group order T1_0..T1_{S-1}, T2_0..T2_{S-1}

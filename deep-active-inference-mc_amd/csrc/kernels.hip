@@ -6,208 +6,119 @@ namespace efe {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------
-// tap-GEMM:  Y^T[co, m] = act(bias[co] + sum_tap sum_ci Wtap[co,ci] * X[src(m,tap), ci])
+// Dense layer:  Y^T[co, m] = act(bias[co] + sum_ci W[co,ci] * X[m, ci])  (+ MC-dropout)
 //
-// One wave owns MT x NT tiles of 32x32 (features x pixels); a workgroup is 4 independent waves
-// laid out along the pixel axis (they share the weight fragments through L1).  Operands go
-// straight from L1/L2 to VGPRs: weights are pre-packed so that lane l of (tile, k-chunk) finds
-// its 4 k-values W[co = l&31][ci = 8*kc + 4*(l>>5) + s] in one 16-byte word; activations are NHWC
-// so the same 4 ci of a pixel are 16 contiguous bytes.  MFMA step s of a chunk contracts the
-// ci pair {8*kc + s, 8*kc + 4 + s}: lanes 0-31 carry the first, lanes 32-63 the second
-// (v_mfma_f32_32x32x2_f32: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]).
+// One wave owns MT x NT tiles of 32x32 (features x batch rows); a workgroup is 4 independent waves
+// laid out along the row axis (they share the weight fragments through L1).  Operands go straight
+// from L1/L2 to VGPRs: weights are pre-packed so that lane l of (tile, k-chunk) finds its 4 k-values
+// W[co = l&31][ci = 8*kc + 4*(l>>5) + s] in one 16-byte word; an activation row's same 4 ci are 16
+// contiguous bytes.  MFMA step s of a chunk contracts the ci pair {8*kc + s, 8*kc + 4 + s}: lanes 0-31
+// carry the first, lanes 32-63 the second (v_mfma_f32_32x32x2_f32: A[i = l&31][k = l>>5],
+// B[k = l>>5][j = l&31]).  Used for the small layers (transition / habit / decoder head / encoder head);
+// the 256 -> 16384 layer has its own LDS-staged kernel (decoder.hip: k_fc4).
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int MT, int NT>
-__global__ void __launch_bounds__(256) k_tapgemm(const GemmArgs a) {
+template <int MT, int NT>
+__global__ void __launch_bounds__(256) k_dense(const GemmArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
     const int KC = a.cin >> 3;
     const int mt0 = blockIdx.y * MT;
-    const int pix0 = (blockIdx.x * 4 + wave) * (NT * 32);
-    if (pix0 >= a.n_pix) return;                      // wave-uniform
+    const int row0 = (blockIdx.x * 4 + wave) * (NT * 32);
+    if (row0 >= a.n_pix) return;                      // wave-uniform
 
-    int img[NT], py[NT], px[NT];
     bool pv[NT];
-    const int grid = (MODE == MODE_CONV_S2) ? a.geo_o : a.geo_n;
+    const float* xp[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int m = pix0 + nt * 32 + j;
+        const int m = row0 + nt * 32 + j;
         pv[nt] = m < a.n_pix;
-        const int mm = pv[nt] ? m : 0;
-        if (MODE == MODE_FC) {
-            img[nt] = mm; py[nt] = 0; px[nt] = 0;
-        } else {
-            const int P = grid * grid;
-            img[nt] = mm / P;
-            const int rem = mm - img[nt] * P;
-            py[nt] = rem / grid;
-            px[nt] = rem - py[nt] * grid;
-        }
+        const int r = (a.x_mod > 0) ? (m % a.x_mod) : m;
+        xp[nt] = (pv[nt] ? a.X + (size_t)r * a.ldx : a.zeros) + 4 * h;
     }
 
-    constexpr int NPAR = (MODE == MODE_CONVT_S2) ? 4 : 1;
-    for (int par = 0; par < NPAR; ++par) {
-        const int ph = par >> 1, pw = par & 1;
-        const int ntaps = (MODE == MODE_FC) ? 1 : (MODE == MODE_CONVT_S2) ? (1 + ph) * (1 + pw) : 9;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.0f;
 
-        f32x16 acc[MT][NT];
+    const float4* wp = reinterpret_cast<const float4*>(a.Wp) + ((size_t)mt0 * KC) * 64 + lane;
+#pragma unroll 2
+    for (int kc = 0; kc < KC; ++kc) {
+        float4 av[MT], bv[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = wp[(size_t)(mt * KC + kc) * 64];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(xp[nt] + kc * 8);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.0f;
-
-        for (int t = 0; t < ntaps; ++t) {
-            int wtap = 0, kh = 0, kw = 0, da = 0, db = 0;
-            if (MODE == MODE_CONVT_S1 || MODE == MODE_CONV_S2) {
-                kh = t / 3; kw = t - kh * 3; wtap = t;
-            } else if (MODE == MODE_CONVT_S2) {
-                // oh = 2*ih - 1 + kh: even rows take kh=1 (ih=a); odd rows take kh=0 (ih=a+1) and kh=2 (ih=a)
-                const int th = t / (1 + pw), tw = t - th * (1 + pw);
-                kh = ph ? (th ? 2 : 0) : 1; da = (ph && th == 0) ? 1 : 0;
-                kw = pw ? (tw ? 2 : 0) : 1; db = (pw && tw == 0) ? 1 : 0;
-                wtap = kh * 3 + kw;
-            }
-            const float* xp[NT];
-#pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                bool ok = pv[nt];
-                size_t off;
-                if (MODE == MODE_FC) {
-                    const int r = (a.x_mod > 0) ? (img[nt] % a.x_mod) : img[nt];
-                    off = (size_t)r * a.ldx;
-                } else {
-                    int sy, sx;
-                    if (MODE == MODE_CONVT_S1) { sy = py[nt] + 1 - kh; sx = px[nt] + 1 - kw; }      // ih = oh + 1 - kh
-                    else if (MODE == MODE_CONVT_S2) { sy = py[nt] + da; sx = px[nt] + db; }
-                    else { sy = 2 * py[nt] + kh; sx = 2 * px[nt] + kw; }                         // valid conv, stride 2
-                    ok = ok && sy >= 0 && sy < a.geo_n && sx >= 0 && sx < a.geo_n;
-                    off = (((size_t)img[nt] * a.geo_n + sy) * a.geo_n + sx) * a.cin;
-                }
-                xp[nt] = (ok ? a.X + off : a.zeros) + 4 * h;
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
             }
-            const float4* wp = reinterpret_cast<const float4*>(a.Wp) + ((size_t)(wtap * a.mtiles + mt0) * KC) * 64 + lane;
+    }
 
-#pragma unroll 2
-            for (int kc = 0; kc < KC; ++kc) {
-                float4 av[MT], bv[NT];
+    // ---- epilogue: C/D layout col = lane&31 (batch row), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (feature)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt] = wp[(size_t)(mt * KC + kc) * 64];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(xp[nt] + kc * 8);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
-                    }
-            }
+    for (int nt = 0; nt < NT; ++nt) {
+        if (!pv[nt]) continue;
+        const int m = row0 + nt * 32 + j;
+        const size_t yoff = (size_t)m * a.ldy;
+        uint4 rnd = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (a.dropout) {
+            const int mg = a.m0 + m;
+            const int g = mg / a.rows_per_group;
+            const uint32_t r = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
+            const uint2 key = group_key(a.gm, g);
+            rnd = noise_words(a.k0, a.k1, a.tag, (uint32_t)((mt0 * 32) >> 7), r, key.x, key.y);
         }
-
-        // ---- epilogue: C/D layout col = lane&31 (pixel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (feature)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (!pv[nt]) continue;
-            const int m = pix0 + nt * 32 + j;
-            size_t yoff;
-            if (MODE == MODE_FC) yoff = (size_t)m * a.ldy;
-            else if (MODE == MODE_CONVT_S2)
-                yoff = (((size_t)img[nt] * (2 * a.geo_n) + 2 * py[nt] + ph) * (2 * a.geo_n) + 2 * px[nt] + pw) * a.cout;
-            else yoff = (size_t)m * a.cout;
-
-            uint4 rnd = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            if (MODE == MODE_FC && a.dropout) {
-                const int mg = a.m0 + m;
-                const int g = mg / a.rows_per_group;
-                const uint32_t r = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
-                const uint2 key = group_key(a.gm, g);
-                rnd = noise_words(a.k0, a.k1, a.tag, (uint32_t)((mt0 * 32) >> 7), r, key.x, key.y);
-            }
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int co = (mt0 + mt) * 32 + 8 * g4 + 4 * h;
+                if (co < a.cout) {
+                    const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
+                    float v[4] = {acc[mt][nt][4 * g4 + 0] + bb.x, acc[mt][nt][4 * g4 + 1] + bb.y,
+                                  acc[mt][nt][4 * g4 + 2] + bb.z, acc[mt][nt][4 * g4 + 3] + bb.w};
+                    if (a.relu) {
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int co = (mt0 + mt) * 32 + 8 * g4 + 4 * h;
-                    if (co < a.cout) {
-                        const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
-                        float v[4] = {acc[mt][nt][4 * g4 + 0] + bb.x, acc[mt][nt][4 * g4 + 1] + bb.y,
-                                      acc[mt][nt][4 * g4 + 2] + bb.z, acc[mt][nt][4 * g4 + 3] + bb.w};
-                        if (a.relu) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-                        }
-                        if (MODE == MODE_FC && a.dropout) {
-                            const uint32_t word = ((co >> 5) & 3) == 0 ? rnd.x : ((co >> 5) & 3) == 1 ? rnd.y
-                                                : ((co >> 5) & 3) == 2 ? rnd.z : rnd.w;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = ((word >> ((co + e) & 31)) & 1u) ? v[e] * 2.0f : 0.0f;
-                        }
-                        *reinterpret_cast<float4*>(a.Y + yoff + co) = make_float4(v[0], v[1], v[2], v[3]);
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
                     }
+                    if (a.dropout) {
+                        const uint32_t word = ((co >> 5) & 3) == 0 ? rnd.x : ((co >> 5) & 3) == 1 ? rnd.y
+                                            : ((co >> 5) & 3) == 2 ? rnd.z : rnd.w;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ((word >> ((co + e) & 31)) & 1u) ? v[e] * 2.0f : 0.0f;
+                    }
+                    *reinterpret_cast<float4*>(a.Y + yoff + co) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
     }
 }
 
-template <int MODE, int MT, int NT>
-static void launch_tg(const GemmArgs& a, hipStream_t st) {
-    const int pix_per_wg = 4 * NT * 32;
-    dim3 grid((a.n_pix + pix_per_wg - 1) / pix_per_wg, (a.mtiles + MT - 1) / MT);
-    hipLaunchKernelGGL((k_tapgemm<MODE, MT, NT>), grid, dim3(256), 0, st, a);
+template <int MT, int NT>
+static void launch_dn(const GemmArgs& a, hipStream_t st) {
+    const int rows_per_wg = 4 * NT * 32;
+    dim3 grid((a.n_pix + rows_per_wg - 1) / rows_per_wg, (a.mtiles + MT - 1) / MT);
+    hipLaunchKernelGGL((k_dense<MT, NT>), grid, dim3(256), 0, st, a);
 }
 
-void launch_tapgemm(int mode, int MT, int NT, const GemmArgs& a, hipStream_t st) {
-#define EFE_CASE(MD, M_, N_) if (mode == MD && MT == M_ && NT == N_) { launch_tg<MD, M_, N_>(a, st); return; }
-    EFE_CASE(MODE_FC, 1, 1)
-    EFE_CASE(MODE_FC, 2, 1)
-    EFE_CASE(MODE_FC, 1, 2)
-    EFE_CASE(MODE_FC, 2, 2)
-    EFE_CASE(MODE_FC, 4, 2)
-    EFE_CASE(MODE_CONV_S2, 1, 2)
-    EFE_CASE(MODE_CONV_S2, 2, 2)
+void launch_dense(int MT, int NT, const GemmArgs& a, hipStream_t st) {
+#define EFE_CASE(M_, N_) if (MT == M_ && NT == N_) { launch_dn<M_, N_>(a, st); return; }
+    EFE_CASE(1, 1)
+    EFE_CASE(2, 1)
+    EFE_CASE(1, 2)
+    EFE_CASE(2, 2)
 #undef EFE_CASE
     abort();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Encoder conv1: Conv2d(1,32,3,stride 2) + ReLU (torchmodel.py:85-86); Cin = 1 -> VALU.
-// o [rows][64][64] -> y [rows][31][31][32] (NHWC).  8 lanes per output pixel, 4 channels each.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_enc_conv1(const float* __restrict__ o, const float* __restrict__ w1,
-                                                   const float* __restrict__ b1, float* __restrict__ y, int rows) {
-    __shared__ float sw[9 * 32 + 32];
-    for (int i = threadIdx.x; i < 9 * 32 + 32; i += 256) sw[i] = (i < 288) ? w1[i] : b1[i - 288];
-    __syncthreads();
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long pix = gid >> 3;
-    const int cg = (int)(gid & 7);
-    if (pix >= (long)rows * 961) return;
-    const int img = (int)(pix / 961);
-    const int rem = (int)(pix - (long)img * 961);
-    const int oh = rem / 31, ow = rem - oh * 31;
-    const float* src = o + (size_t)img * 4096 + (2 * oh) * 64 + 2 * ow;
-    float acc[4] = {sw[288 + cg * 4], sw[288 + cg * 4 + 1], sw[288 + cg * 4 + 2], sw[288 + cg * 4 + 3]};
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const float x = src[kh * 64 + kw];
-            const float* w = sw + (kh * 3 + kw) * 32 + cg * 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(x, w[e], acc[e]);
-        }
-    *reinterpret_cast<float4*>(y + pix * 32 + cg * 4) =
-        make_float4(fmaxf(acc[0], 0.f), fmaxf(acc[1], 0.f), fmaxf(acc[2], 0.f), fmaxf(acc[3], 0.f));
-}
-
-void launch_enc_conv1(const float* o, const float* w1, const float* b1, float* y, int rows, hipStream_t st) {
-    const long threads = (long)rows * 961 * 8;
-    hipLaunchKernelGGL(k_enc_conv1, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, o, w1, b1, y, rows);
 }
 
 // ---------------------------------------------------------------------------------------------
