@@ -479,6 +479,33 @@ int efe_commit_weights(efe_ctx* ctx) {
     return 0;
 }
 
+int efe_env_reset(efe_ctx* ctx, float* state, float* last_r, int E, const efe_noise* nz, void* stream) {
+    if (!ctx) return 1;
+    if (!state || !last_r || !nz || E < 1) return ctx->fail("efe_env_reset: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_env_reset(state, last_r, E, (uint32_t)nz->seed, (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, (hipStream_t)stream);
+    return finish(ctx);
+}
+
+int efe_env_step(efe_ctx* ctx, float* state, float* last_r, const int32_t* actions, int E, int repeats, const efe_noise* nz,
+                 int32_t* round_changed, void* stream) {
+    if (!ctx) return 1;
+    if (!state || !last_r || !actions || !nz || E < 1 || repeats < 1) return ctx->fail("efe_env_step: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_env_step(state, last_r, actions, round_changed, E, repeats, (uint32_t)nz->seed, (uint32_t)(nz->seed >> 32), nz->stage,
+                    nz->row_offset, (hipStream_t)stream);
+    return finish(ctx);
+}
+
+int efe_env_render(efe_ctx* ctx, const float* state, const float* last_r, const uint8_t* imgs, int64_t n_imgs, float* frames,
+                   int32_t* err, int E, void* stream) {
+    if (!ctx) return 1;
+    if (!state || !last_r || !imgs || !frames || n_imgs < 1 || E < 1) return ctx->fail("efe_env_render: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_env_render(state, last_r, imgs, (long)n_imgs, frames, err, E, (hipStream_t)stream);
+    return finish(ctx);
+}
+
 int64_t efe_last_call_macs(efe_ctx* ctx) { return ctx ? ctx->last_macs : 0; }
 
 int efe_prof_enable(efe_ctx* ctx, int on) {

@@ -144,4 +144,10 @@ void launch_mean_rows(const float* G, float* out, int E, int T, hipStream_t st);
 void launch_fill_tr(const float* mean, const float* logvar, float* tr, int R, hipStream_t st);
 void launch_posterior(const float* sumG, float* P, float* logP, int n_groups, int n, float temperature, hipStream_t st);
 
+void launch_env_step(float* state, float* last_r, const int* actions, int* round_changed, int E, int repeats,
+                     uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset, hipStream_t st);
+void launch_env_reset(float* state, float* last_r, int E, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset, hipStream_t st);
+void launch_env_render(const float* state, const float* last_r, const unsigned char* imgs, long n_imgs, float* frames, int* err,
+                       int E, hipStream_t st);
+
 }  // namespace efe

@@ -389,4 +389,101 @@ void launch_posterior(const float* sumG, float* P, float* logP, int n_groups, in
     hipLaunchKernelGGL(k_posterior, dim3((n_groups + 127) / 128), dim3(128), 0, st, sumG, P, logP, n_groups, n, temperature);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dynamic-dSprites environment, batched over games: one thread = one game.
+// Restates /root/reference/src/game_environment.py: tick (:113-117), up/down/left/right (:119-152),
+// pi_to_action (:154-169), new_image (:84-87) with the latent resampling drawn from Philox, and
+// randomize_environment_all (:72-75).  State s[7] = (colour, shape, scale, orientation, x, y, reward).
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t { TAG_ENV = 0x60, PASS_ENV = 9 };
+__device__ __forceinline__ int env_randint(uint32_t k0, uint32_t k1, uint32_t game, uint32_t stage, int latent, int size) {
+    const float u = u01(noise_words(k0, k1, TAG_ENV, (uint32_t)latent, game, stream_id(PASS_ENV, 0), stage).x);
+    const int v = (int)(u * (float)size);
+    return v < size ? v : size - 1;
+}
+
+__global__ void k_env_step(float* state, float* last_r, const int* actions, int* round_changed, int E, int repeats,
+                           uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    float* s = state + (size_t)e * 7;
+    float r = last_r[e];
+    const int pi = actions[e];
+    bool changed = false;
+    for (int i = 0; i < repeats && !changed; ++i) {
+        r *= 0.95f;                                                   // tick
+        if (pi == 0) {                                                // up
+            s[5] += 1.0f;
+            if (s[5] >= 32.0f) {
+                const float x = s[4];
+                if (s[1] < 0.5f) r = (x > 15.0f) ? (15.0f - x) / 16.0f : (16.0f - x) / 16.0f;      // square
+                else             r = (x > 15.0f) ? (x - 15.0f) / 16.0f : (x - 16.0f) / 16.0f;      // ellipse / heart
+                const int sizes[6] = {1, 3, 6, 40, 32, 32};
+                for (int k = 0; k < 6; ++k) s[k] = (float)env_randint(k0, k1, game_offset + e, stage, k, sizes[k]);
+                // port quirk, replicated because the oracle pins it: new_image() holds the accumulated reward as a tensor VIEW,
+                // overwrites the row with a fresh sample (slot 6 = 0) and writes the view back -> the reward restarts at 0
+                s[6] = 0.0f;
+                changed = true;
+            }
+        } else if (pi == 1) { if (s[5] > 0.0f) s[5] -= 1.0f; }       // down
+        else if (pi == 2) { if (s[4] < 31.0f) s[4] += 1.0f; }         // left
+        else if (pi == 3) { if (s[4] > 0.0f) s[4] -= 1.0f; }          // right
+    }
+    last_r[e] = r;
+    if (round_changed) round_changed[e] = changed ? 1 : 0;
+}
+void launch_env_step(float* state, float* last_r, const int* actions, int* round_changed, int E, int repeats,
+                     uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset, hipStream_t st) {
+    hipLaunchKernelGGL(k_env_step, dim3((E + 127) / 128), dim3(128), 0, st, state, last_r, actions, round_changed, E, repeats,
+                       k0, k1, stage, game_offset);
+}
+
+__global__ void k_env_reset(float* state, float* last_r, int E, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int sizes[6] = {1, 3, 6, 40, 32, 32};
+    float* s = state + (size_t)e * 7;
+    for (int k = 0; k < 6; ++k) s[k] = (float)env_randint(k0, k1, game_offset + e, stage, k, sizes[k]);
+    const float u6 = u01(noise_words(k0, k1, TAG_ENV, 6u, game_offset + e, stream_id(PASS_ENV, 0), stage).x);
+    const float u7 = u01(noise_words(k0, k1, TAG_ENV, 7u, game_offset + e, stream_id(PASS_ENV, 0), stage).x);
+    // separate multiply and add: the reference rounds `rand * 20` before adding -10 (hipcc would contract to an FMA, and
+    // HIP's __fmul_rn/__fadd_rn are plain operators, so the product is laundered through an empty asm)
+    float t6 = u6 * 20.0f, t7 = u7 * 2.0f;
+    asm volatile("" : "+v"(t6), "+v"(t7));
+    s[6] = -10.0f + t6;                                               // game_environment.py:74
+    last_r[e] = -1.0f + t7;                                           // :75
+}
+void launch_env_reset(float* state, float* last_r, int E, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset, hipStream_t st) {
+    hipLaunchKernelGGL(k_env_reset, dim3((E + 127) / 128), dim3(128), 0, st, state, last_r, E, k0, k1, stage, game_offset);
+}
+
+// s_to_o (game_environment.py:44-54): image lookup by the port's index rule dot(s[0:6], [1,3,6,40,32,32]) plus the
+// reward bar in rows 0..2 (left half = +r, right half = -r).  One workgroup = one game; err[e] = 1 if |r| > 1.
+__global__ void __launch_bounds__(256) k_env_render(const float* state, const float* last_r, const unsigned char* imgs, long n_imgs,
+                                                   float* frames, int* err) {
+    const int e = blockIdx.x;
+    const float* s = state + (size_t)e * 7;
+    const float r = last_r[e];
+    long idx = (long)(s[0] * 1.0f + s[1] * 3.0f + s[2] * 6.0f + s[3] * 40.0f + s[4] * 32.0f + s[5] * 32.0f);
+    if (idx < 0) idx = 0;
+    if (idx >= n_imgs) idx = n_imgs - 1;
+    const unsigned char* src = imgs + idx * 4096;
+    float* dst = frames + (size_t)e * 4096;
+    const bool pos = (r >= 0.0f && r <= 1.0f), neg = (r >= -1.0f && r < 0.0f);
+    for (int p = threadIdx.x; p < 4096; p += 256) {
+        float v = (float)src[p];
+        const int y = p >> 6, x = p & 63;
+        if (y < 3) {
+            if (pos && x < 32) v = r;
+            else if (neg && x >= 32) v = -r;
+        }
+        dst[p] = v;
+    }
+    if (threadIdx.x == 0 && err) err[e] = (pos || neg) ? 0 : 1;
+}
+void launch_env_render(const float* state, const float* last_r, const unsigned char* imgs, long n_imgs, float* frames, int* err,
+                       int E, hipStream_t st) {
+    hipLaunchKernelGGL(k_env_render, dim3(E), dim3(256), 0, st, state, last_r, imgs, n_imgs, frames, err);
+}
+
 }  // namespace efe

@@ -32,3 +32,14 @@ def plan_actions_batch(model, frames, deepness=10, samples=5, calc_mean=False, t
     pi0 = torch.zeros(n, 4, device=Ppi.device)
     pi0[torch.arange(n, device=Ppi.device), choices] = 1.0            # util.py:73-74
     return pi0, log_Ppi, Ppi, sum_G.reshape(n, 4)
+
+
+def make_batch_dsprites_active_inference(games, model, deepness=10, samples=5, calc_mean=False, repeats=1, generator=None):
+    """/root/reference/src/util.py:55-80 with the batched device environment (env.Game): observe all games, plan every game's
+    action by EFE rollouts in one engine call, act, observe again.  -> (o0, o1, pi0, log_Ppi) as device tensors
+    (o0/o1 in the reference's [games,64,64,1] layout)."""
+    o0 = games.current_frame_all()
+    pi0, log_Ppi, Ppi, _ = plan_actions_batch(model, o0, deepness=deepness, samples=samples, calc_mean=calc_mean, generator=generator)
+    games.pi_to_action_all(pi0.argmax(dim=1), repeats=repeats)
+    o1 = games.current_frame_all()
+    return o0, o1, pi0, log_Ppi

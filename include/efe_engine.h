@@ -101,6 +101,20 @@ int efe_simulate(efe_ctx*, const float* starting_s, int E, int depth, int use_me
 int efe_action_posterior(efe_ctx*, const float* sum_G /*[n_groups*n]*/, int n_groups, int n, float temperature,
                          float* P, float* logP, void* stream);
 
+/* Dynamic-dSprites environment, batched over E games (/root/reference/src/game_environment.py).
+ * state [E,7] = (colour, shape, scale, orientation, x, y, accumulated reward), last_r [E]; all device pointers.
+ * No engine weights are involved: these calls work on any context.
+ *   efe_env_reset : randomize_environment_all (:72-75), latents / reward / last_r drawn from Philox(seed, stage).
+ *   efe_env_step  : pi_to_action(actions[e], e, repeats) for every game (:113-169); a finished round resamples the
+ *                   latents (new_image, :84-87) from Philox(seed, stage); round_changed [E] may be NULL.
+ *   efe_env_render: s_to_o (:44-54): frames[e] = imgs[index(state[e])] (uint8 -> float, imgs is [n_imgs,64,64] uint8)
+ *                   with the reward bar; err[e] = 1 where |last_r| > 1 (the reference raises ValueError), may be NULL. */
+int efe_env_reset(efe_ctx*, float* state, float* last_r, int E, const efe_noise* nz, void* stream);
+int efe_env_step(efe_ctx*, float* state, float* last_r, const int32_t* actions, int E, int repeats, const efe_noise* nz,
+                 int32_t* round_changed, void* stream);
+int efe_env_render(efe_ctx*, const float* state, const float* last_r, const uint8_t* imgs, int64_t n_imgs, float* frames,
+                   int32_t* err, int E, void* stream);
+
 /* introspection for benches: algorithmic MACs of the last EFE-level call. */
 int64_t efe_last_call_macs(efe_ctx*);
 
