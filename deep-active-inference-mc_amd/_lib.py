@@ -9,7 +9,8 @@ LIB_PATH = os.environ.get('EFE_LIB_PATH') or os.path.join(HERE, 'libefe_mi355x.s
 EXPORTS = ['efe_create', 'efe_destroy', 'efe_last_error', 'efe_abi_version', 'efe_set_weight', 'efe_commit_weights',
            'efe_set_option', 'efe_transition', 'efe_decoder', 'efe_encoder', 'efe_habit', 'efe_calculate_g',
            'efe_rollout', 'efe_trajectory', 'efe_simulate', 'efe_action_posterior', 'efe_last_call_macs',
-           'efe_prof_enable', 'efe_prof_classes', 'efe_prof_read', 'efe_env_reset', 'efe_env_step', 'efe_env_render']
+           'efe_prof_enable', 'efe_prof_classes', 'efe_prof_read', 'efe_env_reset', 'efe_env_step', 'efe_env_render',
+           'efe_check_reward', 'efe_reparameterize']
 
 
 class EfeNoise(C.Structure):
@@ -54,5 +55,7 @@ def load():
     lib.efe_env_reset.argtypes = [p, f32p, f32p, i, nzp, p]; lib.efe_env_reset.restype = i
     lib.efe_env_step.argtypes = [p, f32p, f32p, C.c_void_p, i, i, nzp, C.c_void_p, p]; lib.efe_env_step.restype = i
     lib.efe_env_render.argtypes = [p, f32p, f32p, C.c_void_p, C.c_int64, f32p, C.c_void_p, i, p]; lib.efe_env_render.restype = i
+    lib.efe_check_reward.argtypes = [p, f32p, i, f32p, p]; lib.efe_check_reward.restype = i
+    lib.efe_reparameterize.argtypes = [p, f32p, f32p, i, i, nzp, f32p, f32p, p]; lib.efe_reparameterize.restype = i
     _lib = lib
     return lib

@@ -592,6 +592,24 @@ int efe_habit(efe_ctx* ctx, const float* s, int M, float* logits, float* q, floa
     return finish(ctx);
 }
 
+int efe_check_reward(efe_ctx* ctx, const float* o, int M, float* out, void* stream) {
+    if (!ctx) return 1;
+    if (!o || !out || M < 1) return ctx->fail("efe_check_reward: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_check_reward(o, out, M, (hipStream_t)stream);
+    return finish(ctx);
+}
+
+int efe_reparameterize(efe_ctx* ctx, const float* mean, const float* logvar, int M, int n, const efe_noise* nz, const float* eps,
+                       float* out, void* stream) {
+    if (!ctx) return 1;
+    if (!mean || !logvar || !nz || !out || M < 1 || n < 1) return ctx->fail("efe_reparameterize: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_reparam(mean, logvar, eps, out, M, n, (uint32_t)nz->seed, (uint32_t)(nz->seed >> 32), nz->pass, nz->sample, nz->stage,
+                   nz->row_offset, (hipStream_t)stream);
+    return finish(ctx);
+}
+
 // ---- EFE level -----------------------------------------------------------------------------------------
 int efe_calculate_g(efe_ctx* ctx, const float* s0, const float* pi0, int M, int samples, int mean_mode, const efe_noise* nz,
                     const float* eps, float* G, float* terms, float* ps1, float* ps1_mean, float* po1, float* t2parts, void* stream) {

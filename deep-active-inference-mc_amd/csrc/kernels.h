@@ -144,6 +144,9 @@ void launch_mean_rows(const float* G, float* out, int E, int T, hipStream_t st);
 void launch_fill_tr(const float* mean, const float* logvar, float* tr, int R, hipStream_t st);
 void launch_posterior(const float* sumG, float* P, float* logP, int n_groups, int n, float temperature, hipStream_t st);
 
+void launch_check_reward(const float* o, float* out, int M, hipStream_t st);
+void launch_reparam(const float* mean, const float* logvar, const float* eps_inj, float* out, int M, int n, uint32_t k0, uint32_t k1,
+                    uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, hipStream_t st);
 void launch_env_step(float* state, float* last_r, const int* actions, int* round_changed, int E, int repeats,
                      uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset, hipStream_t st);
 void launch_env_reset(float* state, float* last_r, int E, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset, hipStream_t st);

@@ -389,6 +389,42 @@ void launch_posterior(const float* sumG, float* P, float* logP, int n_groups, in
     hipLaunchKernelGGL(k_posterior, dim3((n_groups + 127) / 128), dim3(128), 0, st, sumG, P, logP, n_groups, n, temperature);
 }
 
+// check_reward (torchmodel.py:210-212, torchutils.py:30-37) on an arbitrary image batch: one workgroup per image.
+// Same per-pixel expression as the fused decoder epilogue (target 1 for rows h < 32, 0 below; mean over pixels * 10).
+__global__ void __launch_bounds__(256) k_check_reward(const float* o, float* out) {
+    __shared__ float sred[4];
+    const float* img = o + (size_t)blockIdx.x * 4096;
+    const float D1 = 1.00001f, D0 = 0.00001f;
+    float part = 0.f;
+    for (int p = threadIdx.x; p < 4096; p += 256) {
+        const float pr = img[p];
+        part += ((p >> 6) < 32) ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f) : pr * logf(D0) + (1.0f - pr) * logf(D1);
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) part += __shfl_xor(part, k);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = ((sred[0] + sred[1]) + (sred[2] + sred[3])) * (1.0f / 4096.0f) * 10.0f;
+}
+void launch_check_reward(const float* o, float* out, int M, hipStream_t st) {
+    hipLaunchKernelGGL(k_check_reward, dim3(M), dim3(256), 0, st, o, out);
+}
+
+// reparameterize (torchmodel.py:54-56 / 130-132): out = eps * exp(logvar / 2) + mean, eps from Philox or injected
+__global__ void k_reparam(const float* mean, const float* logvar, const float* eps_inj, float* out, int M, int n,
+                          uint32_t k0, uint32_t k1, uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= M * n) return;
+    const int r = gid / n, k = gid - r * n;
+    const float eps = eps_inj ? eps_inj[gid] : normal_elem(k0, k1, row_offset + r, stream_id(pass, sample), stage, k);
+    out[gid] = eps * expf(logvar[gid] * 0.5f) + mean[gid];
+}
+void launch_reparam(const float* mean, const float* logvar, const float* eps_inj, float* out, int M, int n, uint32_t k0, uint32_t k1,
+                    uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, hipStream_t st) {
+    hipLaunchKernelGGL(k_reparam, dim3((M * n + 255) / 256), dim3(256), 0, st, mean, logvar, eps_inj, out, M, n, k0, k1, pass, sample,
+                       stage, row_offset);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Dynamic-dSprites environment, batched over games: one thread = one game.
 // Restates /root/reference/src/game_environment.py: tick (:113-117), up/down/left/right (:119-152),

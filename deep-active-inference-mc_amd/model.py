@@ -141,9 +141,9 @@ class ModelMid(_Module):
         super().__init__(owner, 'mid')
         self.s_dim, self.pi_dim = owner.s_dim, owner.pi_dim
 
-    def reparameterize(self, mean, logvar):
-        eps = torch.randn_like(mean)
-        return eps * torch.exp(logvar * 0.5) + mean
+    def reparameterize(self, mean, logvar, **kw):
+        """torchmodel.py:54-56; the normals come from the model's Philox stream (one stage per call)"""
+        return self._owner._reparameterize(mean, logvar, **kw)
 
     def transition_with_sample(self, pi, s0, stage=None, pass_=PASS_T1, sample=0, eps=None, row_offset=None):
         m = self._owner
@@ -170,9 +170,9 @@ class ModelDown(_Module):
         self.s_dim, self.pi_dim = owner.s_dim, owner.pi_dim
         self.colour_channels, self.resolution = 1, 64
 
-    def reparameterize(self, mean, logvar):
-        eps = torch.randn_like(mean)
-        return eps * torch.exp(logvar * 0.5) + mean
+    def reparameterize(self, mean, logvar, **kw):
+        """torchmodel.py:130-132; the normals come from the model's Philox stream (one stage per call)"""
+        return self._owner._reparameterize(mean, logvar, **kw)
 
     def encoder_with_sample(self, o, stage=None, pass_=PASS_E1, sample=0, eps=None, row_offset=None, _want_s=True):
         m = self._owner
@@ -339,14 +339,23 @@ class ActiveInferenceModel:
 
     # ---- hot path -----------------------------------------------------------------------------------
     def check_reward(self, o):
-        """torchmodel.py:210-212 via the oracle-pinned constants: a host-side convenience for callers that
-        hold an image; the rollout path computes this inside the fused decoder epilogue."""
-        o = self._engine.tensor(o, (-1, 1, 64, 64))
-        d1, d0 = np.float32(1.00001), np.float32(0.00001)
-        l_top = o * float(np.log(d1)) + (1 - o) * float(np.log(np.float32(d1 - np.float32(1.0))))
-        l_bot = o * float(np.log(d0)) + (1 - o) * float(np.log(d1))
-        h = torch.arange(64, device=o.device).reshape(1, 1, 64, 1)
-        return torch.where(h < 32, l_top, l_bot).mean(dim=[1, 2, 3]) * 10.0
+        """torchmodel.py:210-212 on an arbitrary image batch [M,1,64,64] -> [M] (the rollout path computes the same
+        expression inside the fused decoder epilogue)"""
+        e = self._ready()
+        o = e.tensor(o, (-1, 1, 64, 64))
+        out = e.empty(o.shape[0])
+        e.check(e.lib.efe_check_reward(e.ctx, _ptr(o), o.shape[0], _ptr(out), e.stream()))
+        return out
+
+    def _reparameterize(self, mean, logvar, stage=None, pass_=PASS_ROOT, sample=0, eps=None, row_offset=None):
+        e = self._ready()
+        mean = e.tensor(mean); logvar = e.tensor(logvar)
+        M, n = mean.shape[0], mean.shape[1]
+        nz = self._noise(stage, pass_, sample, row_offset)
+        out = e.empty(M, n)
+        eps_t = e.tensor(eps, (M, n)) if eps is not None else None
+        e.check(e.lib.efe_reparameterize(e.ctx, _ptr(mean), _ptr(logvar), M, n, C.byref(nz), _ptr(eps_t), _ptr(out), e.stream()))
+        return out
 
     def imagine_future_from_o(self, o0, pi):
         """torchmodel.py:216-220"""

@@ -65,6 +65,13 @@ int efe_encoder(efe_ctx*, const float* o /*[M,1,64,64]*/, int M, const efe_noise
 /* ModelTop.encode_s, torchmodel.py:27-31 (no dropout). */
 int efe_habit(efe_ctx*, const float* s /*[M,10]*/, int M, float* logits, float* q, float* logq, void* stream);
 
+/* ActiveInferenceModel.check_reward, torchmodel.py:210-212 (resolution-64 branch). o: [M,1,64,64] -> out [M]. */
+int efe_check_reward(efe_ctx*, const float* o, int M, float* out, void* stream);
+/* Model{Mid,Down}.reparameterize, torchmodel.py:54-56 / 130-132: out = eps * exp(logvar/2) + mean, [M,n];
+ * eps optional (NULL = Philox normals keyed by nz->pass / sample / stage / row_offset). */
+int efe_reparameterize(efe_ctx*, const float* mean, const float* logvar, int M, int n, const efe_noise* nz, const float* eps,
+                       float* out, void* stream);
+
 /* EFE level -------------------------------------------------------------------------------------- */
 /* calculate_G (torchmodel.py:270-300) when mean_mode == 0; calculate_G_mean (torchmodel.py:302-327)
  * when mean_mode == 1 (samples forced to 1).

@@ -465,3 +465,12 @@ def test_c_abi_from_plain_c(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert 'c_abi_smoke OK' in r.stdout
+
+
+def test_reparameterize_through_engine(models):
+    m = models(1234, 1.15, 17)
+    mean = PX.uniform_fill(8, (6, 10), 920, -1, 1); lv = PX.uniform_fill(8, (6, 10), 921, -2, 0)
+    eps = PX.normals(17, 6, 10, PX.PASS_ROOT, 0, 3)
+    ref = eps * np.exp(lv * np.float32(0.5)) + mean
+    np.testing.assert_allclose(c(m.model_down.reparameterize(mean, lv, stage=3, eps=eps)), ref, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(c(m.model_mid.reparameterize(mean, lv, stage=3)), ref, rtol=1e-4, atol=1e-5)   # device Box-Muller
