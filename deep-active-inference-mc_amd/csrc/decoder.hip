@@ -21,12 +21,29 @@ namespace efe {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int DA_BIAS = 257 * 16;          // float4 index of the two bias vectors behind the image + zero pixel
 #ifdef EFE_TIMELINE
-#define TL(i) do { if (a.tl && tid == 0 && blockIdx.x == 0 && tlk < 60) a.tl[tlk++] = clock64(); } while (0)
+#ifndef EFE_TL_SKIP
+#define EFE_TL_SKIP 0
+#endif
+#ifndef EFE_TL_BLOCK
+#define EFE_TL_BLOCK 0
+#endif
+#define TL(i) do { if (a.tl && tid == 0 && blockIdx.x == EFE_TL_BLOCK) { if (tlk >= EFE_TL_SKIP && tlk < EFE_TL_SKIP + 60) a.tl[tlk - EFE_TL_SKIP] = clock64(); ++tlk; } } while (0)
+#elif defined(EFE_PHASE_CLK)
+// per-phase cycle sums of wave 0 of every workgroup, written once at kernel end: a.tl[block * 16 + phase]
+#define TL(i) do { const long long t_ = clock64(); phs[i] += t_ - tprev; tprev = t_; } while (0)
 #else
 #define TL(i) do {} while (0)
 #endif
+#ifdef EFE_X_NOBAR            // timing experiment (wrong results): no workgroup barriers in the image loop
+#define EFE_X_BAR() do {} while (0)
+#else
+#define EFE_X_BAR() __syncthreads()
+#endif
 __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
     int tlk = 0; (void)tlk;
+#ifdef EFE_PHASE_CLK
+    long long phs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) float4 sm[];        // [257 pixels][16 quads]; pixel 256 = zeros
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -36,8 +53,8 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
     // this wave's 64 pixels / input positions: image rows 4w .. 4w+3, two 32-pixel tiles of two rows each
     const int pcol = j & 15;
     const int prow0 = 4 * w + (j >> 4);                                // tile nt covers rows prow0 + 2*nt
-    const float4* W1 = reinterpret_cast<const float4*>(a.w1) + lane;
-    const float4* W2 = reinterpret_cast<const float4*>(a.w2) + lane;
+    const float4* W1 = reinterpret_cast<const float4*>(a.w1);
+    const float4* W2 = reinterpret_cast<const float4*>(a.w2);
 
     if ((int)blockIdx.x >= a.rows) return;
     f32x4 pfa[8], pfb[8];                                              // next image, in flight during compute
@@ -56,21 +73,28 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
     for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
         TL(0);
         // stage the 16x16x64 input image (64 KiB) into the swizzled LDS layout
+#ifndef EFE_X_NOSTAGE         // timing experiment (wrong results): no staging of the input image
+        // per-image laundering of the thread index: stops hipcc hoisting ~40 loop-invariant staging / prefetch addresses out of
+        // the image loop, which pushed the kernel over 256 VGPRs (spill reloads carry s_waitcnt vmcnt(0): they serialised
+        // the prefetch loads and waited for every outstanding y2 store)
+        int tl_ = tid; asm volatile("" : "+v"(tl_));
+        {   // swz(it*16 + (tid>>4), tid&15) = it*256 + sbase: one address register, immediate offsets
+            const int sbase = (tl_ >> 4) * 16 + ((tl_ & 15) ^ ((tl_ >> 4) & 15));
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int idx = it * 256 + tid, idx2 = idx + 2048;
-            smv[swz(idx >> 4, idx & 15)] = pfa[it];
-            smv[swz(idx2 >> 4, idx2 & 15)] = pfb[it];
+            for (int it = 0; it < 8; ++it) { smv[sbase + it * 256] = pfa[it]; smv[sbase + (it + 8) * 256] = pfb[it]; }
         }
-        __syncthreads();
+#endif
+        EFE_X_BAR();
         TL(1);
         const int nimg = img + gridDim.x;
         const bool more = nimg < a.rows;
+#ifndef EFE_X_NOSTAGE
         {   // request the next image now (clamped on the last pass: unconditional loads keep pf[] in registers)
             const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)((more && !(a.dbg & 2)) ? nimg : img) * 4096;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) { pfa[it] = X[it * 256 + tid]; pfb[it] = X[(it + 8) * 256 + tid]; }
+            for (int it = 0; it < 8; ++it) { pfa[it] = (X + it * 256)[tl_]; pfb[it] = (X + (it + 8) * 256)[tl_]; }
         }
+#endif
 
         f32x16 acc[2][2];
         // ---------------- layer 1: out[oh,ow] = sum_{kh,kw} in[oh+1-kh, ow+1-kw] . W[:, :, kh, kw] --------------
@@ -92,8 +116,9 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
             }
         }, ConvWIdx{});
         TL(2);
-        __syncthreads();            // every wave is done reading the input image
+        EFE_X_BAR();                // every wave is done reading the input image
         TL(3);
+#ifndef EFE_X_NOEPI1          // timing experiment (wrong results): no layer-1 epilogue
         // bias + ReLU, written back IN PLACE as the input image of layer 2 (same swizzled layout)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -110,11 +135,15 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
                     sm[swz(pix, c4)] = v;
                 }
         }
-        __syncthreads();
+#endif
+        EFE_X_BAR();
         TL(4);
 
         // ---------------- layer 2 (stride 2): 4 output parities, oh = 2*ih - 1 + kh ----------------------------
         float* Y = a.y2 + (size_t)img * (32 * 32 * 64);
+#ifdef EFE_X_NOSTORE
+        float keep = 0.f;
+#endif
 #pragma unroll 1
         for (int par = 0; par < 4; ++par) {
             const int ph = par >> 1, pw = par & 1;
@@ -128,7 +157,10 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
             TL(5);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                float* yp = Y + ((size_t)(2 * (prow0 + 2 * nt) + ph) * 32 + (2 * pcol + pw)) * 64;
+                // y2 layout (float4 units): [parity][8 channel groups][256 input positions][2 quads] -- for one (mt, g4) the 64
+                // lanes (position j of this wave's tile, quad h) write 1 KiB contiguous; the NHWC order would split every
+                // store into 32 scattered 32-byte pieces
+                float4* yp = reinterpret_cast<float4*>(Y) + (size_t)par * 4096 + ((4 * w + 2 * nt) * 16 + j) * 2 + h;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -138,13 +170,27 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
                         float4 v;
                         v.x = fmaxf(acc[mt][nt][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[mt][nt][4 * g4 + 1] + bb.y, 0.f);
                         v.z = fmaxf(acc[mt][nt][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[mt][nt][4 * g4 + 3] + bb.w, 0.f);
-                        reinterpret_cast<float4*>(yp)[c4] = v;
+#ifdef EFE_X_NOSTORE          // timing experiment (wrong results): no y2 stores
+                        keep += v.x + v.y + v.z + v.w;
+#else
+                        yp[(mt * 4 + g4) * 512] = v;
+#endif
                     }
             }
+#ifdef EFE_PHASE_CLK
+            TL(6);
+#endif
         }
+#ifdef EFE_X_NOSTORE
+        Y[tid] = keep;
+#endif
         TL(9);
-        __syncthreads();            // every wave is done reading layer-1's image before the next one overwrites it
+        EFE_X_BAR();                // every wave is done reading layer-1's image before the next one overwrites it
     }
+#ifdef EFE_PHASE_CLK
+    if (a.tl && tid == 0)
+        for (int i = 0; i < 10; ++i) a.tl[blockIdx.x * 16 + i] = phs[i];
+#endif
 }
 
 void launch_dec_a(const DecAArgs& a, hipStream_t st) {
@@ -214,22 +260,26 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
     if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const float4* X = reinterpret_cast<const float4*>(a.y2) + (size_t)img * (32 * 32 * 16);
-    const float4* W3 = reinterpret_cast<const float4*>(a.w3) + lane;
+    const float4* W3 = reinterpret_cast<const float4*>(a.w3);
     const float D1 = 1.00001f, D0 = 0.00001f;      // fp32 constants of log_bernoulli / entropy_bernoulli
     float part = 0.f;
     f32x4 pf[NPF];                                                     // input strip in flight
     f32x4* smv = reinterpret_cast<f32x4*>(sm);
     const f32x4* Xv = reinterpret_cast<const f32x4*>(X);
+    // y2 image layout (written by k_dec_a): [parity (iy&1, ix&1)][8 channel groups][16 x 16 positions (iy>>1, ix>>1)][2 quads];
+    // element idx of a staged row = (segment = pw*8 + cg, b = ix>>1, quad half): 512-byte contiguous pieces
+    auto y2_at = [&](int iy, int idx) -> size_t { return (size_t)(((iy & 1) * 16 + ((idx & 511) >> 5)) * 512 + (iy >> 1) * 32 + (idx & 31)); };
 #pragma unroll
-    for (int it = 0; it < NPF; ++it) pf[it] = Xv[it * NTHR + tid];     // strip 0 = rows 0..SR (contiguous)
+    for (int it = 0; it < NPF; ++it) { const int idx = it * NTHR + tid; pf[it] = Xv[y2_at(idx >> 9, idx)]; }   // strip 0 = rows 0..SR
 
     for (int s = 0; s < NS; ++s) {
         // ---- stage input rows SR*s .. SR*s+SR (row 32 does not exist: zeros); the data was requested one strip earlier
 #pragma unroll
         for (int it = 0; it < NPF; ++it) {
             const int idx = it * NTHR + tid;                           // (SR+1) rows x 32 px x 16 quads
-            const int rl = idx >> 9, rem = idx & 511;
-            smv[swz(rl * 32 + (rem >> 4), rem & 15)] = (SR * s + rl < 32) ? pf[it] : (f32x4)(0.f);
+            const int rl = idx >> 9, seg = (idx & 511) >> 5, wi = idx & 31;
+            const int ix = 2 * (wi >> 1) + (seg >> 3), c4 = 2 * (seg & 7) + (wi & 1);
+            smv[swz(rl * 32 + ix, c4)] = (SR * s + rl < 32) ? pf[it] : (f32x4)(0.f);
         }
         __syncthreads();
         {   // request strip s+1 now (it lands during the MFMA phase); rows >= 32 are clamped here and zeroed when staged
@@ -238,7 +288,7 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
             for (int it = 0; it < NPF; ++it) {
                 const int idx = it * NTHR + tid;
                 const int grow = min(SR * sn + (idx >> 9), 31);
-                pf[it] = Xv[(size_t)grow * 512 + (idx & 511)];
+                pf[it] = Xv[y2_at(grow, idx)];
             }
         }
 
@@ -364,7 +414,7 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
         }
     }
     __syncthreads();
-    const float4* Wl = reinterpret_cast<const float4*>(a.Wp) + lane;
+    const float4* Wl = reinterpret_cast<const float4*>(a.Wp);
 
     // dropout keys of this lane's two rows
     uint32_t krow[2], kstream[2], kstage[2];

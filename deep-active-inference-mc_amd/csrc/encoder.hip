@@ -29,8 +29,8 @@ __global__ void __launch_bounds__(256, 2) k_enc_trunk(const EncArgs a) {
     for (int i = tid; i < 320; i += 256) smf[EN_W1 + i] = (i < 288) ? a.w1[i] : a.b1[i - 288];
     const float4* w1s = reinterpret_cast<const float4*>(smf + EN_W1);
     const float4* W2 = reinterpret_cast<const float4*>(a.w2) + lane;      // [9][1][4][64]
-    const float4* W3 = reinterpret_cast<const float4*>(a.w3) + lane;      // [9][2][4][64]
-    const float4* W4 = reinterpret_cast<const float4*>(a.w4) + lane;      // [9][2][8][64]
+    const float4* W3 = reinterpret_cast<const float4*>(a.w3);             // [9][2][4][64] (uniform base, see TapPipe)
+    const float4* W4 = reinterpret_cast<const float4*>(a.w4);             // [9][2][8][64]
 
     for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
         {   // stage the image (16 KiB)

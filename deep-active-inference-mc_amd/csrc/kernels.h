@@ -63,7 +63,7 @@ struct GemmArgs {
     int m0;               // index of column 0 of this launch inside the [group][row] batch
 };
 
-// fused decoder, stage A: x4 [rows][16][16][64] -> ConvT(64,64,s1)+ReLU -> ConvT(64,64,s2)+ReLU -> y2 [rows][32][32][64]
+// fused decoder, stage A: x4 [rows][16][16][64] -> ConvT(64,64,s1)+ReLU -> ConvT(64,64,s2)+ReLU -> y2 [rows][4 parities][8 channel groups][16x16 positions][8] (see k_dec_a)
 struct DecAArgs {
     const float* x4; float* y2;
     const float* w1; const float* b1;   // packed [9][2][8][64][4], bias [64]

@@ -21,12 +21,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: p
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, (BV).z, ACC, 0, 0, 0);   \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, (BV).w, ACC, 0, 0, 0);
 
+// Weight (A) fragments are fetched with buffer loads: SGPR resource (base) + SGPR byte offset (tap / tile / chunk, all
+// uniform) + ONE per-lane VGPR offset (lane * 16).  With flat global loads hipcc folds the lane into a 64-bit per-lane
+// pointer and materialises a VGPR pair per distinct offset -- dozens of pairs, hoisted out of the loops and spilled.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);   // raw buffer, 2 GiB window
+}
+__device__ __forceinline__ float4 wfrag(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, size_t f4_index) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, (unsigned)f4_index * 16u, 0);
+    return __builtin_bit_cast(float4, v);
+}
+
 __device__ __forceinline__ int swz(int pix, int c4) { return pix * 16 + (c4 ^ (pix & 15)); }   // float4 index
 
 // Software-pipelined contraction over `ntaps` taps x 64 input channels (8 chunks of 8): the A fragments (weights,
 // L2) and B fragments (activations, LDS) of chunk i+1 are requested before the MFMAs of chunk i issue, so neither
 // latency is exposed (hipcc otherwise waits for each chunk's loads right before its first MFMA).
 // addr(t, base[NT], sw[NT], wtap): LDS float4 base + swizzle key of every pixel tile and the packed-weight tap index.
+// Wl is the UNIFORM base of the packed weights: the fragment address is (scalar base + scalar tap/chunk offset) + lane, i.e.
+// global_load with an SGPR base and one 32-bit lane offset.  A per-lane 64-bit pointer instead makes hipcc materialise a
+// VGPR pair per distinct offset (dozens, hoisted out of the loops and spilled).
 struct ConvWIdx {          // packed conv weights [tap][MT tiles][8 chunks][64 lanes]
     template <int MT> __device__ __forceinline__ static size_t at(int wt, int mt, int kc) { return (size_t)((wt * MT + mt) * 8 + kc) * 64; }
 };
@@ -66,11 +81,13 @@ struct TapPipe {
     // request the first chunks of a contraction; call it as early as the operands are valid
     template <class AddrFn, class WIdx>
     __device__ __forceinline__ void begin(const float4* __restrict__ Wl, const float4* sm, const int h, AddrFn addr, WIdx widx) {
+        const unsigned ln = (threadIdx.x & 63u) * 16u;
+        const __amdgpu_buffer_rsrc_t wr = wrsrc(Wl);
         addr(0, bs, sw, wt);
 #pragma unroll
         for (int p = 0; p < PD; ++p)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) aq[p][mt] = Wl[widx.template at<MT>(wt, mt, p)];
+            for (int mt = 0; mt < MT; ++mt) aq[p][mt] = wfrag(wr, ln, widx.template at<MT>(wt, mt, p));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bv[nt] = sm[bs[nt] + (h ^ sw[nt])];
     }
@@ -78,6 +95,8 @@ struct TapPipe {
     template <class AddrFn, class WIdx>
     __device__ __forceinline__ void run(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
                                         const float4* sm, const int h, AddrFn addr, WIdx widx) {
+        const unsigned ln = (threadIdx.x & 63u) * 16u;
+        const __amdgpu_buffer_rsrc_t wr = wrsrc(Wl);
         for (int t = 0; t < ntaps; ++t) {
             int nbs[NT], nsw[NT], nwt;
             addr((t + 1 < ntaps) ? t + 1 : t, nbs, nsw, nwt);
@@ -90,8 +109,8 @@ struct TapPipe {
 #ifndef EFE_DBG_NO_A          // timing experiment: skip the weight-fragment loads (wrong results)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    aq[kc % PD][mt] = (kc + PD < KC) ? Wl[widx.template at<MT>(wt, mt, kc + PD)]
-                                                     : Wl[widx.template at<MT>(nwt, mt, kc + PD - KC)];
+                    aq[kc % PD][mt] = (kc + PD < KC) ? wfrag(wr, ln, widx.template at<MT>(wt, mt, kc + PD))
+                                                     : wfrag(wr, ln, widx.template at<MT>(nwt, mt, kc + PD - KC));
 #endif
 #ifdef EFE_DBG_NO_B           // timing experiment: skip the LDS activation-fragment reads (wrong results)
 #pragma unroll
@@ -105,11 +124,30 @@ struct TapPipe {
                     for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[nbs[nt] + (h ^ nsw[nt])];
                 }
 #endif
+#ifndef EFE_SCHED_SPREAD
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch loads AHEAD of this chunk's MFMAs (hipcc sinks them otherwise)
+#endif
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) { MFMA4(acc[mt][nt], av[mt], bv[nt]) }
+#ifdef EFE_SCHED_SPREAD
+                // one prefetch instruction behind each of the first MFMAs instead of a cluster in front of them
+#pragma unroll
+                for (int q = 0; q < MT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, EFE_SCHED_SPREAD, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, EFE_SCHED_SPREAD, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT * 4 - MT - NT, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
             }

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, daimc_amd
 m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=1)
 tl = torch.zeros(64, dtype=torch.int64, device='cuda')
-s = torch.randn(4096, 10, device='cuda') * 0.3
+s = torch.randn(19200, 10, device='cuda') * 0.3
 m.model_down.decoder(s); torch.cuda.synchronize()
 m.set_option('tl_buf', tl.data_ptr())
 m.model_down.decoder(s); torch.cuda.synchronize()

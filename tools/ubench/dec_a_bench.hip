@@ -1,0 +1,57 @@
+// micro-benchmark: k_dec_a (ConvT1 + ConvT2 of the decoder) alone on synthetic data, MFMA efficiency vs the 157.3 TF
+// fp32 peak.  dev tool, not part of the product.   usage: dec_a_bench [rows] [dbg]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deep-active-inference-mc_amd/csrc tools/ubench/dec_a_bench.hip -o tools/ubench/dec_a_bench
+#include "decoder.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace efe;
+
+__global__ void k_fill(float* p, size_t n, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = scale * (float)((i * 2654435761u) >> 20 & 1023) * (1.f / 1024.f);
+}
+
+int main(int argc, char** argv) {
+    const int rows = argc > 1 ? atoi(argv[1]) : 16384;
+    const int dbg = argc > 2 ? atoi(argv[2]) : 0;
+    float *x, *y, *w1, *w2, *b;
+    const size_t wn = 9 * 2 * 8 * 64 * 4;
+    hipMalloc(&x, (size_t)rows * 16384 * 4); hipMalloc(&y, (size_t)rows * 65536 * 4);
+    hipMalloc(&w1, wn * 4); hipMalloc(&w2, wn * 4); hipMalloc(&b, 128 * 4);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, x, (size_t)rows * 16384, 1.f);
+    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, w1, wn, 0.05f);
+    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, w2, wn, 0.05f);
+    hipLaunchKernelGGL(k_fill, dim3(1), dim3(128), 0, 0, b, (size_t)128, 0.01f);
+    DecAArgs a{};
+    a.x4 = x; a.y2 = y; a.w1 = w1; a.b1 = b; a.w2 = w2; a.b2 = b + 64; a.rows = rows; a.dbg = dbg; a.tl = nullptr;
+    launch_dec_a(a, 0); hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 12; ++rep) {
+        hipEventRecord(e0); launch_dec_a(a, 0); hipEventRecord(e1); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+#ifdef EFE_PHASE_CLK
+    {
+        long long* tl; hipMalloc(&tl, 512 * 16 * 8); hipMemset(tl, 0, 512 * 16 * 8);
+        a.tl = tl; launch_dec_a(a, 0); hipDeviceSynchronize();
+        std::vector<long long> h(512 * 16); hipMemcpy(h.data(), tl, 512 * 16 * 8, hipMemcpyDeviceToHost);
+        const char* nm[10] = {"end barrier", "stage+barrier", "prefetch+CT1 loop", "CT1 barrier", "CT1 epilogue+barrier", "CT2 loops", "CT2 epilogues", "-", "-", "tail"};
+        const int grid = rows < 512 ? rows : 512; const double imgs = (double)rows / grid;
+        for (int half = 0; half < 2; ++half) {
+            double tot = 0; printf("WGs %d..%d, cycles per image (wave 0):", half * 256, half * 256 + 255);
+            for (int i = 0; i < 10; ++i) {
+                double sacc = 0; for (int b = half * 256; b < half * 256 + 256 && b < grid; ++b) sacc += (double)h[b * 16 + i];
+                sacc /= 256.0 * imgs; tot += sacc;
+                if (nm[i][0] != '-') printf("  %s %.0f", nm[i], sacc);
+            }
+            printf("  | total %.0f (MFMA demand of the pair 294912)\n", tot);
+        }
+    }
+#endif
+    const double flops = (double)rows * 2.0 * 2.0 * 9.0 * 64 * 64 * 256;
+    printf("k_dec_a rows %d dbg %d: best of 12 %.3f ms  %.1f TFLOP/s  frac %.3f\n", rows, dbg, best, flops / best / 1e9, flops / best / 1e9 / 157.3);
+    return 0;
+}
