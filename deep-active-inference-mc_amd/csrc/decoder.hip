@@ -48,15 +48,18 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
 
-    // this wave's 64 pixels / input positions: image rows 4w .. 4w+3, two 32-pixel tiles of two rows each
-    const int pcol = j & 15;
-    const int prow0 = 4 * w + (j >> 4);                                // tile nt covers rows prow0 + 2*nt
     const float4* W1 = reinterpret_cast<const float4*>(a.w1);
     const float4* W2 = reinterpret_cast<const float4*>(a.w2);
 
     if ((int)blockIdx.x >= a.rows) return;
+    // Image schedule: the first two images of a workgroup are static (blockIdx, blockIdx + grid), the rest are claimed from a
+    // ticket counter.  The two workgroups of a CU do not run at the same speed (the older one wins the MFMA arbitration,
+    // ~300k vs ~365k cycles per image), so a static stride leaves the younger one alone -- at half the CU's throughput -- for
+    // the last ~18 % of the kernel.  Tickets are fetched two images ahead by thread 0 and handed over through LDS.
+    int* const slot = reinterpret_cast<int*>(sm + DA_BIAS + 32);
+    if (tid == 0) slot[0] = 2 * (int)gridDim.x + atomicAdd(a.queue, 1);
+    int nimg = (int)blockIdx.x + (int)gridDim.x;
     f32x4 pfa[8], pfb[8];                                              // next image, in flight during compute
     f32x4* smv = reinterpret_cast<f32x4*>(sm);
     {
@@ -70,7 +73,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
     if (tid < 16) sm[DA_BIAS + tid] = reinterpret_cast<const float4*>(a.b1)[tid];
     else if (tid < 32) sm[DA_BIAS + tid] = reinterpret_cast<const float4*>(a.b2)[tid - 16];
 
-    for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
+    for (int img = blockIdx.x; img < a.rows;) {
         TL(0);
         // stage the 16x16x64 input image (64 KiB) into the swizzled LDS layout
 #ifndef EFE_X_NOSTAGE         // timing experiment (wrong results): no staging of the input image
@@ -78,6 +81,10 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
         // the image loop, which pushed the kernel over 256 VGPRs (spill reloads carry s_waitcnt vmcnt(0): they serialised
         // the prefetch loads and waited for every outstanding y2 store)
         int tl_ = tid; asm volatile("" : "+v"(tl_));
+        // this wave's 64 pixels / input positions: image rows 4w .. 4w+3, two 32-pixel tiles of two rows each
+        const int j = tl_ & 31, h = (tl_ >> 5) & 1;
+        const int pcol = j & 15;
+        const int prow0 = 4 * w + (j >> 4);                            // tile nt covers rows prow0 + 2*nt
         {   // swz(it*16 + (tid>>4), tid&15) = it*256 + sbase: one address register, immediate offsets
             const int sbase = (tl_ >> 4) * 16 + ((tl_ & 15) ^ ((tl_ >> 4) & 15));
 #pragma unroll
@@ -86,7 +93,9 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
 #endif
         EFE_X_BAR();
         TL(1);
-        const int nimg = img + gridDim.x;
+        const int nnimg = slot[0];                     // the image after nimg (written one iteration ago)
+        int ticket = 0;
+        if (tid == 0) ticket = 2 * (int)gridDim.x + atomicAdd(a.queue, 1);     // lands during the layer-1 contraction
         const bool more = nimg < a.rows;
 #ifndef EFE_X_NOSTAGE
         {   // request the next image now (clamped on the last pass: unconditional loads keep pf[] in registers)
@@ -116,7 +125,8 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
             }
         }, ConvWIdx{});
         TL(2);
-        EFE_X_BAR();                // every wave is done reading the input image
+        EFE_X_BAR();                // every wave is done reading the input image (and slot[0])
+        if (tid == 0) slot[0] = ticket;
         TL(3);
 #ifndef EFE_X_NOEPI1          // timing experiment (wrong results): no layer-1 epilogue
         // bias + ReLU, written back IN PLACE as the input image of layer 2 (same swizzled layout)
@@ -186,6 +196,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
 #endif
         TL(9);
         EFE_X_BAR();                // every wave is done reading layer-1's image before the next one overwrites it
+        img = nimg; nimg = nnimg;
     }
 #ifdef EFE_PHASE_CLK
     if (a.tl && tid == 0)
@@ -195,9 +206,9 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
 
 void launch_dec_a(const DecAArgs& a, hipStream_t st) {
     static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)k_dec_a, hipFuncAttributeMaxDynamicSharedMemorySize, (257 * 16 + 32) * sizeof(float4)); once = true; }
+    if (!once) { (void)hipFuncSetAttribute((const void*)k_dec_a, hipFuncAttributeMaxDynamicSharedMemorySize, (257 * 16 + 33) * sizeof(float4)); once = true; }
     const int grid = a.rows < 512 ? a.rows : 512;         // persistent: 2 workgroups per CU, images strided by the grid
-    hipLaunchKernelGGL(k_dec_a, dim3(grid), dim3(256), (257 * 16 + 32) * sizeof(float4), st, a);
+    hipLaunchKernelGGL(k_dec_a, dim3(grid), dim3(256), (257 * 16 + 33) * sizeof(float4), st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -222,8 +233,16 @@ void launch_dec_a(const DecAArgs& a, hipStream_t st) {
 // SR = input rows per strip = waves per workgroup.  SR = 4: 256 threads, 8 strips, 64 KiB LDS, 2 workgroups per CU.
 // SR = 2: 128 threads, 16 strips, 38 KiB LDS, 4 workgroups per CU -- the same 8 waves per CU, but four independent
 // phase streams instead of two, and barriers that only join two waves.
+#ifdef EFE_PHASE_CLK
+#define TLB(i) do { const long long t_ = clock64(); phs[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define TLB(i) do {} while (0)
+#endif
 template <int SR>
 __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
+#ifdef EFE_PHASE_CLK
+    long long phs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
     constexpr int NTHR = 64 * SR;
     constexpr int DB_ZERO = (SR + 1) * 32;            // zero pixel slot behind the (SR+1)-row input strip
     constexpr int DB_IN_F4 = (DB_ZERO + 1) * 16;      // float4s
@@ -231,7 +250,8 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
     constexpr int NPF = (SR + 1) * 512 / NTHR;        // float4s of the input strip per thread
     constexpr int NS = 32 / SR;                       // strips per image
     extern __shared__ __attribute__((aligned(16))) float4 sm[];        // input strip, then T ring
-    float* sT = reinterpret_cast<float*>(sm + DB_IN_F4);               // [ring rows][9 taps][64 cols]
+    constexpr int TS = 66;                            // tap-plane row: zero column, 64 columns, zero column
+    float* sT = reinterpret_cast<float*>(sm + DB_IN_F4);               // [ring rows][9 taps][TS]
     __shared__ float sred[SR];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -258,6 +278,7 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
         w4f[e] = ((lane & 15) < 9) ? a.w4[(lane & 15) * 32 + co] : 0.f;   // A_b[i = tap = lane&15], b>>1 = h
     }
     if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < DB_YROWS * 9 * 2; i += NTHR) sT[(i >> 1) * TS + (i & 1) * (TS - 1)] = 0.f;   // the pad columns (never rewritten)
 
     const float4* X = reinterpret_cast<const float4*>(a.y2) + (size_t)img * (32 * 32 * 16);
     const float4* W3 = reinterpret_cast<const float4*>(a.w3);
@@ -272,6 +293,7 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
 #pragma unroll
     for (int it = 0; it < NPF; ++it) { const int idx = it * NTHR + tid; pf[it] = Xv[y2_at(idx >> 9, idx)]; }   // strip 0 = rows 0..SR
 
+    TLB(0);
     for (int s = 0; s < NS; ++s) {
         // ---- stage input rows SR*s .. SR*s+SR (row 32 does not exist: zeros); the data was requested one strip earlier
 #pragma unroll
@@ -282,6 +304,7 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
             smv[swz(rl * 32 + ix, c4)] = (SR * s + rl < 32) ? pf[it] : (f32x4)(0.f);
         }
         __syncthreads();
+        TLB(1);
         {   // request strip s+1 now (it lands during the MFMA phase); rows >= 32 are clamped here and zeroed when staged
             const int sn = (s < NS - 1) ? s + 1 : NS - 1;
 #pragma unroll
@@ -301,61 +324,74 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[nt][e] = b3[e];        // the accumulators start at the layer-3 bias
             f32x16 (&acc1)[1][2] = reinterpret_cast<f32x16 (&)[1][2]>(acc);
             tap_loop<1, 2>(acc1, (1 + ph) * (1 + pw), W3, sm, h, ConvT2Addr<2>{ph, pw, 2 * rp, 1, j, 8, 32, DB_ZERO}, ConvWIdx{});
-            // ---- bias + ReLU in registers, then contract channels against the 9 taps of the final conv with the
-            // 4-block form v_mfma_f32_16x16x1_4b_f32: block = lane>>4 = (channel half h)*2 + (pixel half), so the
-            // accumulator register e is again the B operand as it stands; A[i = lane&15] = W4[tap i][co(e, h)].
-            // 16 instructions x 32 cycles (half the cost of the 32x32x2 form, whose 32 tap rows would be 72 % padding).
+            TLB(2);
+            // ---- ReLU in registers (a plain VALU instruction costs ~19 cycles of wave time while the co-resident wave streams
+            // MFMAs: the bias add is folded into the accumulator init), then contract channels against the 9 taps of the final conv with the 4-block form
+            // v_mfma_f32_16x16x1_4b_f32: block = lane>>4 = (channel half h)*2 + (pixel half), so the accumulator register e
+            // is again the B operand as it stands; A[i = lane&15] = W4[tap i][co(e, h)].  16 instructions x 32 cycles per
+            // tile (half the cost of the 32x32x2 form, whose 32 tap rows would be 72 % padding); the two tiles' dependent
+            // chains are interleaved.
+            f32x16 T2[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                f32x16 T;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) T[e] = 0.f;
-                if (!(a.dbg & 1)) {
+                for (int e = 0; e < 16; ++e)            // ReLU as ONE integer max on the bit pattern (fmaxf on a raw MFMA result
+                    acc[nt][e] = relu_bits(acc[nt][e]);  // costs a second, canonicalising v_max_f32)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        T = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], fmaxf(acc[nt][e] + b3[e], 0.f), T, 0, 0, 0);
-                }
+                for (int e = 0; e < 16; ++e) T2[nt][e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                T2[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[0][e], T2[0], 0, 0, 0);
+                T2[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[1][e], T2[1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x16 T = T2[nt];
                 // D layout: T[4b + r] = D_b[row = 4*(lane>>4) + r][col = lane&15]; pixel p = 16*(b&1) + col, and the two
                 // channel halves (b, b+2) of the same pixel sit in the same lane: add them.
                 const int tq = lane >> 4, c = lane & 15;               // this lane holds taps 4*tq + r
                 const int orow = 2 * (SR * s + 2 * rp + nt) + ph;
-                float* tp = sT + ((orow % DB_YROWS) * 9 + 4 * tq) * 64 + pw;
+                float* tp = sT + ((orow % DB_YROWS) * 9 + 4 * tq) * TS + 1 + pw;
                 if (tq < 2) {
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
-                        tp[r4 * 64 + 2 * c] = T[r4] + T[8 + r4];
-                        tp[r4 * 64 + 2 * (16 + c)] = T[4 + r4] + T[12 + r4];
+                        tp[r4 * TS + 2 * c] = T[r4] + T[8 + r4];
+                        tp[r4 * TS + 2 * (16 + c)] = T[4 + r4] + T[12 + r4];
                     }
                 } else if (tq == 2) {
                     tp[2 * c] = T[0] + T[8];
                     tp[2 * (16 + c)] = T[4] + T[12];
                 }
             }
+            TLB(3);
         }
         __syncthreads();
+        TLB(4);
 
-        // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete now (row 63 after the last strip)
+        // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete now (row 63 after the last strip).  One output row
+        // per wave and pass (row index wave-uniform: scalar branches only), 9 unconditional LDS reads per pixel -- the zero
+        // pad columns stand in for the out-of-image taps, adding 0.f leaves the fp32 sum unchanged.
         const int nq = (a.dbg & 2) ? 0 : (s == NS - 1) ? 3 : 2;
         for (int q = 0; q < nq; ++q) {
-            const int p = q * NTHR + tid;
-            if (q == 2 && tid >= 64) break;
-            const int oh = 2 * SR * s - 1 + (p >> 6), ow = p & 63;
+            if (q == 2 && w != 0) break;
+            const int oh = 2 * SR * s - 1 + q * SR + w, ow = lane;
             if (oh < 0) continue;
-            float v = a.b4;
+            float tv[9];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const int tr = oh + 1 - kh;
-                if (tr < 0 || tr > 63) continue;
-                const float* trow = sT + ((tr % DB_YROWS) * 9 + kh * 3) * 64;
+                const bool rv = tr >= 0 && tr <= 63;
+                const float* trow = sT + (((rv ? tr : 0) % DB_YROWS) * 9 + kh * 3) * TS + ow + 2;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int tc = ow + 1 - kw;
-                    if (tc >= 0 && tc < 64) v += trow[kw * 64 + tc];
-                }
+                for (int kw = 0; kw < 3; ++kw) tv[kh * 3 + kw] = rv ? trow[kw * TS - kw] : 0.f;
             }
+            float v = a.b4;
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) v += tv[t9];
             const float pr = 1.0f / (1.0f + EFE_EXP(-v));
             if (po) po[oh * 64 + ow] = pr;
             if (mode == 0) part += -(1.0f - pr) * EFE_LOG(D1 - pr) - pr * EFE_LOG(D0 + pr);
@@ -364,6 +400,7 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
         }
         // no barrier here: the next strip's staging only touches the input buffer (all waves are past the MFMA
         // phase), and its T writes come after the next barrier, i.e. after every thread finished this gather.
+        TLB(5);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
@@ -374,14 +411,19 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
         if (SR == 4) tot += sred[2] + sred[3];      // (s0 + s1) + (s2 + s3): fixed order
         a.val[mg] = tot;
     }
+#ifdef EFE_PHASE_CLK
+    TLB(6);
+    if (a.tl && tid == 0)
+        for (int i = 0; i < 8; ++i) a.tl[(size_t)blockIdx.x * 8 + i] = phs[i];
+#endif
 }
 
 void launch_dec_b(const DecBArgs& a, hipStream_t st) {
     if (!(a.dbg & 8)) {       // default: 4-wave workgroups, 4-row strips (2-wave / 2-row variant measured 5 % slower; kept for A/B)
-        const size_t lds = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 64 * sizeof(float);
+        const size_t lds = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 66 * sizeof(float);
         hipLaunchKernelGGL(k_dec_b<4>, dim3(a.rows), dim3(256), lds, st, a);
     } else {
-        const size_t lds = ((3 * 32 + 1) * 16) * sizeof(float4) + 6 * 9 * 64 * sizeof(float);
+        const size_t lds = ((3 * 32 + 1) * 16) * sizeof(float4) + 6 * 9 * 66 * sizeof(float);
         hipLaunchKernelGGL(k_dec_b<2>, dim3(a.rows), dim3(128), lds, st, a);
     }
 }

@@ -53,6 +53,7 @@ struct efe_ctx {
     std::vector<void*> owned;
     Arena arena;
     int64_t dec_chunk = 32768, enc_chunk = 32768, dbg_a = 0, dbg_b = 0;
+    int64_t arena_align = 256;
     void* tl_buf = nullptr;   // EFE_TIMELINE experiments: device buffer of 64 int64 stamps (option "tl_buf" = device pointer)
     int64_t last_macs = 0;
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
@@ -79,7 +80,7 @@ struct efe_ctx {
 
     // bump allocator over a list of device blocks; grows (synchronously) on first use at a new size
     void* alloc(size_t bytes) {
-        bytes = (bytes + 255) & ~(size_t)255;
+        bytes = (bytes + (size_t)arena_align - 1) / (size_t)arena_align * (size_t)arena_align;
         while (true) {
             if (arena.cur < arena.blocks.size()) {
                 auto& b = arena.blocks[arena.cur];
@@ -198,6 +199,10 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
     fc(ctx, ctx->dec_fc[0], dec_in, 16, 0, hA, 256, N, true, true, TAG_DEC + 0, nc, 0, st);
     fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, N, true, true, TAG_DEC + 1, nc, 0, st);
     fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, N, true, true, TAG_DEC + 2, nc, 0, st);
+    const int nchunks = (N + C - 1) / C;
+    int* queues = ctx->allocT<int>((size_t)nchunks);        // one image-ticket counter per k_dec_a launch
+    if (!queues) return 1;
+    if (hipMemsetAsync(queues, 0, (size_t)nchunks * sizeof(int), st) != hipSuccess) return ctx->fail("hipMemsetAsync failed");
     for (int m0 = 0; m0 < N; m0 += C) {
         const int c = std::min(C, N - m0);
         ctx->cls = PROF_DEC_FC4;
@@ -205,7 +210,7 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         ctx->cls = PROF_CT2;
         DecAArgs da{};
         da.x4 = x4; da.y2 = y2; da.w1 = ctx->dec_ct[0].Wp; da.b1 = ctx->dec_ct[0].bias; da.w2 = ctx->dec_ct[1].Wp;
-        da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.dbg = (int)ctx->dbg_a; da.tl = (long long*)ctx->tl_buf;
+        da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.queue = queues + m0 / C; da.dbg = (int)ctx->dbg_a; da.tl = (long long*)ctx->tl_buf;
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_dec_a(da, st);
         ctx->prof_end(e0, st);
@@ -399,6 +404,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "tl_buf")) { ctx->tl_buf = (void*)(intptr_t)value; return 0; }
     if (!strcmp(name, "dbg_a")) { ctx->dbg_a = value; return 0; }
     if (!strcmp(name, "dbg_b")) { ctx->dbg_b = value; return 0; }
+    if (!strcmp(name, "arena_align")) { if (value < 256 || (value & (value - 1))) return ctx->fail("arena_align must be a power of two >= 256"); ctx->arena_align = value; return 0; }
     if (!strcmp(name, "enc_chunk")) { if (value < 1) return ctx->fail("enc_chunk < 1"); ctx->enc_chunk = value; return 0; }
     return ctx->fail(std::string("unknown option ") + name);
 }

@@ -69,7 +69,8 @@ struct DecAArgs {
     const float* w1; const float* b1;   // packed [9][2][8][64][4], bias [64]
     const float* w2; const float* b2;
     int rows;
-    int dbg;              // timing experiments only (0 in production): 1 = skip y2 stores, 2 = skip next-image prefetch
+    int* queue;           // zero-initialised ticket counter of this launch: images beyond the first two per workgroup are claimed dynamically
+    int dbg;              // timing experiments only (0 in production): 2 = skip next-image prefetch
     long long* tl;        // timeline experiments only (EFE_TIMELINE builds): s_memtime stamps of workgroup 0 / wave 0
 };
 // fused decoder, stage B: y2 -> ConvT(64,32,s2)+ReLU -> ConvT(32,1,s1)+Sigmoid -> per-image reduction (+ image store)
@@ -86,6 +87,7 @@ struct DecBArgs {
     float* val;           // [batch] per-image pixel sum (entropy sum, or log-likelihood sum)
     float* po;            // [slots][rows_per_group][4096] stored images
     int dbg;              // timing experiments only: 1 = skip tap-plane MFMAs, 2 = skip gather/epilogue math
+    long long* tl;        // EFE_PHASE_CLK builds only: per-workgroup phase cycle sums [rows][8]
 };
 // fused encoder trunk: o [rows][64][64] -> conv1..conv4 (+ReLU) -> out [rows][576] in NHWC (p*64 + c) order
 struct EncArgs {

@@ -13,6 +13,7 @@
 namespace efe {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: plain loads/stores, no struct memcpy
 
 #define MFMA4(ACC, AV, BV)                                                      \
@@ -31,6 +32,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wrsrc(const void* base) {
 __device__ __forceinline__ float4 wfrag(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, size_t f4_index) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, (unsigned)f4_index * 16u, 0);
     return __builtin_bit_cast(float4, v);
+}
+
+// max(x, 0) for fp32 as a signed-integer max of the bit pattern: negative floats (and -0, -NaN) are negative integers.
+__device__ __forceinline__ float relu_bits(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
 __device__ __forceinline__ int swz(int pix, int c4) { return pix * 16 + (c4 ^ (pix & 15)); }   // float4 index

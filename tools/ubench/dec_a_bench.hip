@@ -7,36 +7,46 @@
 #include <vector>
 using namespace efe;
 
-__global__ void k_fill(float* p, size_t n, float scale) {
+__global__ void k_fill(float* p, size_t n, float scale, int lowent, unsigned zero256) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        p[i] = scale * (float)((i * 2654435761u) >> 20 & 1023) * (1.f / 1024.f);
+    {
+        // full-entropy mantissas (data-dependent power decides the sustained clock); `zero_frac` of the values are exact zeros
+        unsigned x = (unsigned)i * 2654435761u + 12345u; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        const float v = __uint_as_float(0x3f800000u | (x & 0x7fffffu)) - 1.0f;
+        p[i] = (lowent ? (float)(x >> 22) * (1.f / 1024.f) : v) * scale * (((x >> 23) & 255u) < zero256 ? 0.f : 1.f);
+    }
 }
 
 int main(int argc, char** argv) {
     const int rows = argc > 1 ? atoi(argv[1]) : 16384;
     const int dbg = argc > 2 ? atoi(argv[2]) : 0;
+    const int lowent = argc > 3 ? atoi(argv[3]) : 0;           // 1 = 10-bit mantissas (low switching power)
+    const unsigned zero256 = argc > 4 ? atoi(argv[4]) : 0;     // zeros per 256 input activations
     float *x, *y, *w1, *w2, *b;
     const size_t wn = 9 * 2 * 8 * 64 * 4;
     hipMalloc(&x, (size_t)rows * 16384 * 4); hipMalloc(&y, (size_t)rows * 65536 * 4);
     hipMalloc(&w1, wn * 4); hipMalloc(&w2, wn * 4); hipMalloc(&b, 128 * 4);
-    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, x, (size_t)rows * 16384, 1.f);
-    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, w1, wn, 0.05f);
-    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, w2, wn, 0.05f);
-    hipLaunchKernelGGL(k_fill, dim3(1), dim3(128), 0, 0, b, (size_t)128, 0.01f);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, x, (size_t)rows * 16384, 1.f, lowent, zero256);
+    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, w1, wn, 0.05f, lowent, 0u);
+    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, w2, wn, 0.05f, lowent, 0u);
+    hipLaunchKernelGGL(k_fill, dim3(1), dim3(128), 0, 0, b, (size_t)128, 0.01f, lowent, 0u);
+    int* queue; hipMalloc(&queue, 4);
     DecAArgs a{};
+    a.queue = queue;
     a.x4 = x; a.y2 = y; a.w1 = w1; a.b1 = b; a.w2 = w2; a.b2 = b + 64; a.rows = rows; a.dbg = dbg; a.tl = nullptr;
-    launch_dec_a(a, 0); hipDeviceSynchronize();
+    hipMemset(queue, 0, 4); launch_dec_a(a, 0); hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    float best = 1e9f;
+    float best = 1e9f, sum = 0.f;
     for (int rep = 0; rep < 12; ++rep) {
-        hipEventRecord(e0); launch_dec_a(a, 0); hipEventRecord(e1); hipDeviceSynchronize();
+        hipMemsetAsync(queue, 0, 4, 0); hipEventRecord(e0); launch_dec_a(a, 0); hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
+        sum += ms;
     }
 #ifdef EFE_PHASE_CLK
     {
         long long* tl; hipMalloc(&tl, 512 * 16 * 8); hipMemset(tl, 0, 512 * 16 * 8);
-        a.tl = tl; launch_dec_a(a, 0); hipDeviceSynchronize();
+        a.tl = tl; hipMemset(queue, 0, 4); launch_dec_a(a, 0); hipDeviceSynchronize();
         std::vector<long long> h(512 * 16); hipMemcpy(h.data(), tl, 512 * 16 * 8, hipMemcpyDeviceToHost);
         const char* nm[10] = {"end barrier", "stage+barrier", "prefetch+CT1 loop", "CT1 barrier", "CT1 epilogue+barrier", "CT2 loops", "CT2 epilogues", "-", "-", "tail"};
         const int grid = rows < 512 ? rows : 512; const double imgs = (double)rows / grid;
@@ -52,6 +62,6 @@ int main(int argc, char** argv) {
     }
 #endif
     const double flops = (double)rows * 2.0 * 2.0 * 9.0 * 64 * 64 * 256;
-    printf("k_dec_a rows %d dbg %d: best of 12 %.3f ms  %.1f TFLOP/s  frac %.3f\n", rows, dbg, best, flops / best / 1e9, flops / best / 1e9 / 157.3);
+    printf("k_dec_a rows %d dbg %d: best of 12 %.3f ms (mean %.3f)  %.1f TFLOP/s  frac %.3f\n", rows, dbg, best, sum / 12, flops / best / 1e9, flops / best / 1e9 / 157.3);
     return 0;
 }
