@@ -206,10 +206,12 @@ def main():
     assert torch.isfinite(G).all()
     prof = model.prof_read() if not a.no_prof else {}
     breakdown = {}
-    if not a.no_prof:                                   # per-class breakdown from ONE extra, un-timed step
+    NB = 3
+    if not a.no_prof:                                   # per-class breakdown: mean of NB extra, un-timed steps
         model.prof_enable(True)
-        step(a.warmup + a.steps)
-        breakdown = model.prof_read()
+        for k in range(NB):
+            step(a.warmup + a.steps + k)
+        breakdown = {k_: (ms / NB, n // NB) for k_, (ms, n) in model.prof_read().items()}
     model.prof_enable(False)
     if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)

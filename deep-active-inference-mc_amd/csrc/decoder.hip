@@ -230,20 +230,22 @@ void launch_dec_a(const DecAArgs& a, hipStream_t st) {
 // and the 3x3 "gather"  out[oh,ow] = b4 + sum_{kh,kw} T[kh*3+kw][oh+1-kh][ow+1-kw]  is done once the rows
 // above and below exist.  y3 (512 KiB per image) never exists in memory.
 // ---------------------------------------------------------------------------------------------------------
-// SR = input rows per strip = waves per workgroup.  SR = 4: 256 threads, 8 strips, 64 KiB LDS, 2 workgroups per CU.
-// SR = 2: 128 threads, 16 strips, 38 KiB LDS, 4 workgroups per CU -- the same 8 waves per CU, but four independent
-// phase streams instead of two, and barriers that only join two waves.
+// SR = input rows per strip.  SR = 4: 8 strips, 64 KiB LDS, 2 workgroups per CU.  SR = 2: 16 strips, 38 KiB LDS, 4 per CU.
 #ifdef EFE_PHASE_CLK
 #define TLB(i) do { const long long t_ = clock64(); phs[i] += t_ - tprev; tprev = t_; } while (0)
 #else
 #define TLB(i) do {} while (0)
 #endif
-template <int SR>
-__global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
+// RW = strip rows (32-pixel tiles) per wave.  RW = 2: SR waves (the original form).  RW = 1: 2*SR waves of <= 128 VGPRs, i.e. four
+// waves per SIMD with two workgroups per CU: a wave in a VALU phase (staging, ReLU, tap-plane writes, gather) issues one
+// instruction per ~19 cycles beside an MFMA stream, and with only two waves per SIMD both were out of MFMA work ~20 % of the time.
+template <int SR, int RW>
+__global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs a) {
 #ifdef EFE_PHASE_CLK
     long long phs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
 #endif
-    constexpr int NTHR = 64 * SR;
+    constexpr int NW = 2 * SR / RW;                   // waves per workgroup
+    constexpr int NTHR = 64 * NW;
     constexpr int DB_ZERO = (SR + 1) * 32;            // zero pixel slot behind the (SR+1)-row input strip
     constexpr int DB_IN_F4 = (DB_ZERO + 1) * 16;      // float4s
     constexpr int DB_YROWS = 2 * SR + 2;              // tap-plane ring: the strip's 2*SR rows + 2 kept from the previous one
@@ -252,12 +254,15 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 sm[];        // input strip, then T ring
     constexpr int TS = 66;                            // tap-plane row: zero column, 64 columns, zero column
     float* sT = reinterpret_cast<float*>(sm + DB_IN_F4);               // [ring rows][9 taps][TS]
-    __shared__ float sred[SR];
+    __shared__ float sred[NW];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int rp = w >> 1, pg = w & 1;
+    // wave -> (row group rp, parity group pg).  pg 0 contracts 5 tap-tiles per row, pg 1 only 4, and waves w and w+4 share a
+    // SIMD: flip pg for the upper four waves so every SIMD gets one heavy and one light wave (otherwise two SIMDs of the CU
+    // carry 25 % more MFMA work than the other two and everyone waits for them at the strip barrier).
+    const int rp = w >> 1, pg = (w ^ (w >> 2)) & 1;
     const int img = blockIdx.x;
 
     const int mg = a.m0 + img;
@@ -269,12 +274,13 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
     const int slot = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
     float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + r) * 4096 : nullptr;
 
-    // per-lane constants: layer-3 bias of the 16 channels this lane holds, and the A fragments of the 32->1 conv
-    float b3[16], w4f[16];
+    // per-lane constants: the A fragments of the 32->1 conv; the layer-3 bias (accumulator init) is read from LDS per tile
+    __shared__ float4 sb3[8];
+    if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];
+    float w4f[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int co = (e & 3) + 8 * (e >> 2) + 4 * h;
-        b3[e] = a.b3[co];
         w4f[e] = ((lane & 15) < 9) ? a.w4[(lane & 15) * 32 + co] : 0.f;   // A_b[i = tap = lane&15], b>>1 = h
     }
     if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -320,13 +326,15 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
         for (int pi = 0; pi < 2; ++pi) {
             const int par = pg ? (pi ? 2 : 1) : (pi ? 0 : 3);          // pg0: (1,1),(0,0)   pg1: (0,1),(1,0)
             const int ph = par >> 1, pw = par & 1;
-            f32x16 acc[2];
+            f32x16 acc[RW];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int g4 = 0; g4 < 4; ++g4) {                            // the accumulators start at the layer-3 bias:
+                const float4 bb = sb3[2 * g4 + h];                      // register e holds channel (e&3) + 8*(e>>2) + 4h
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[nt][e] = b3[e];        // the accumulators start at the layer-3 bias
-            f32x16 (&acc1)[1][2] = reinterpret_cast<f32x16 (&)[1][2]>(acc);
-            tap_loop<1, 2>(acc1, (1 + ph) * (1 + pw), W3, sm, h, ConvT2Addr<2>{ph, pw, 2 * rp, 1, j, 8, 32, DB_ZERO}, ConvWIdx{});
+                for (int nt = 0; nt < RW; ++nt) { acc[nt][4 * g4] = bb.x; acc[nt][4 * g4 + 1] = bb.y; acc[nt][4 * g4 + 2] = bb.z; acc[nt][4 * g4 + 3] = bb.w; }
+            }
+            f32x16 (&acc1)[1][RW] = reinterpret_cast<f32x16 (&)[1][RW]>(acc);
+            tap_loop<1, RW>(acc1, (1 + ph) * (1 + pw), W3, sm, h, ConvT2Addr<RW>{ph, pw, RW * rp, 1, j, 8, 32, DB_ZERO}, ConvWIdx{});
             TLB(2);
             // ---- ReLU in registers (a plain VALU instruction costs ~19 cycles of wave time while the co-resident wave streams
             // MFMAs: the bias add is folded into the accumulator init), then contract channels against the 9 taps of the final conv with the 4-block form
@@ -334,9 +342,9 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
             // is again the B operand as it stands; A[i = lane&15] = W4[tap i][co(e, h)].  16 instructions x 32 cycles per
             // tile (half the cost of the 32x32x2 form, whose 32 tap rows would be 72 % padding); the two tiles' dependent
             // chains are interleaved.
-            f32x16 T2[2];
+            f32x16 T2[RW];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < RW; ++nt) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)            // ReLU as ONE integer max on the bit pattern (fmaxf on a raw MFMA result
                     acc[nt][e] = relu_bits(acc[nt][e]);  // costs a second, canonicalising v_max_f32)
@@ -345,16 +353,16 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                T2[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[0][e], T2[0], 0, 0, 0);
-                T2[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[1][e], T2[1], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < RW; ++nt) T2[nt] = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[nt][e], T2[nt], 0, 0, 0);
             }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < RW; ++nt) {
                 const f32x16 T = T2[nt];
                 // D layout: T[4b + r] = D_b[row = 4*(lane>>4) + r][col = lane&15]; pixel p = 16*(b&1) + col, and the two
                 // channel halves (b, b+2) of the same pixel sit in the same lane: add them.
                 const int tq = lane >> 4, c = lane & 15;               // this lane holds taps 4*tq + r
-                const int orow = 2 * (SR * s + 2 * rp + nt) + ph;
+                const int orow = 2 * (SR * s + RW * rp + nt) + ph;
                 float* tp = sT + ((orow % DB_YROWS) * 9 + 4 * tq) * TS + 1 + pw;
                 if (tq < 2) {
 #pragma unroll
@@ -375,10 +383,10 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
         // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete now (row 63 after the last strip).  One output row
         // per wave and pass (row index wave-uniform: scalar branches only), 9 unconditional LDS reads per pixel -- the zero
         // pad columns stand in for the out-of-image taps, adding 0.f leaves the fp32 sum unchanged.
-        const int nq = (a.dbg & 2) ? 0 : (s == NS - 1) ? 3 : 2;
+        const int nq = (a.dbg & 2) ? 0 : (s == NS - 1) ? RW + 1 : RW;
         for (int q = 0; q < nq; ++q) {
-            if (q == 2 && w != 0) break;
-            const int oh = 2 * SR * s - 1 + q * SR + w, ow = lane;
+            if (q == RW && w != 0) break;
+            const int oh = 2 * SR * s - 1 + q * NW + w, ow = lane;
             if (oh < 0) continue;
             float tv[9];
 #pragma unroll
@@ -407,8 +415,9 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
     if (lane == 0) sred[w] = part;
     __syncthreads();
     if (tid == 0) {
-        float tot = sred[0] + sred[1];
-        if (SR == 4) tot += sred[2] + sred[3];      // (s0 + s1) + (s2 + s3): fixed order
+        float tot = sred[0] + sred[1];              // fixed order: (s0 + s1) + (s2 + s3) + ...
+#pragma unroll
+        for (int i = 2; i < NW; i += 2) tot += sred[i] + sred[i + 1];
         a.val[mg] = tot;
     }
 #ifdef EFE_PHASE_CLK
@@ -419,12 +428,14 @@ __global__ void __launch_bounds__(64 * SR, 2) k_dec_b(const DecBArgs a) {
 }
 
 void launch_dec_b(const DecBArgs& a, hipStream_t st) {
-    if (!(a.dbg & 8)) {       // default: 4-wave workgroups, 4-row strips (2-wave / 2-row variant measured 5 % slower; kept for A/B)
-        const size_t lds = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 66 * sizeof(float);
-        hipLaunchKernelGGL(k_dec_b<4>, dim3(a.rows), dim3(256), lds, st, a);
-    } else {
+    const size_t lds4 = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 66 * sizeof(float);
+    if (!(a.dbg & 24)) {        // default: 8 waves per workgroup, one strip row each, 4 waves per SIMD
+        hipLaunchKernelGGL((k_dec_b<4, 1>), dim3(a.rows), dim3(512), lds4, st, a);
+    } else if (a.dbg & 16) {    // 4-wave workgroups, 4-row strips, two rows per wave (measured 4 % slower; kept for A/B)
+        hipLaunchKernelGGL((k_dec_b<4, 2>), dim3(a.rows), dim3(256), lds4, st, a);
+    } else {                    // 2-wave workgroups, 2-row strips (measured 9 % slower; kept for A/B)
         const size_t lds = ((3 * 32 + 1) * 16) * sizeof(float4) + 6 * 9 * 66 * sizeof(float);
-        hipLaunchKernelGGL(k_dec_b<2>, dim3(a.rows), dim3(128), lds, st, a);
+        hipLaunchKernelGGL((k_dec_b<2, 2>), dim3(a.rows), dim3(128), lds, st, a);
     }
 }
 

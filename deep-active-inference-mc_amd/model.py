@@ -49,6 +49,10 @@ class _Engine:
         rc = self.lib.efe_create(C.byref(self.ctx), device_index)
         if rc != 0:
             raise RuntimeError(f'efe_create failed with code {rc}')
+        # development hook: EFE_ENGINE_OPTS="name=value,..." applies efe_set_option to every context (kernel A/B experiments)
+        for kv in filter(None, os.environ.get('EFE_ENGINE_OPTS', '').split(',')):
+            k, v = kv.split('=')
+            self.check(self.lib.efe_set_option(self.ctx, k.encode(), int(v)))
 
     def check(self, rc):
         if rc != 0:
