@@ -206,12 +206,19 @@ def main():
     assert torch.isfinite(G).all()
     prof = model.prof_read() if not a.no_prof else {}
     breakdown = {}
-    NB = 3
-    if not a.no_prof:                                   # per-class breakdown: mean of NB extra, un-timed steps
-        model.prof_enable(True)
-        for k in range(NB):
-            step(a.warmup + a.steps + k)
-        breakdown = {k_: (ms / NB, n // NB) for k_, (ms, n) in model.prof_read().items()}
+    NB = 2
+    if not a.no_prof:
+        # per-class breakdown from extra, un-timed steps, ONE class at a time: event pairs around every launch of a step slow
+        # all of its kernels down by ~10 % (the sum no longer matched ms_per_step)
+        kk = a.warmup + a.steps
+        for c in model.PROF_CLASSES:
+            if c.startswith('unused'):
+                continue
+            model.prof_enable(True, classes=[c])
+            for _ in range(NB):
+                step(kk); kk += 1
+            ms, n = model.prof_read()[c]
+            breakdown[c] = (ms / NB, n // NB)
     model.prof_enable(False)
     if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)

@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
     // wave -> (row group rp, parity group pg).  pg 0 contracts 5 tap-tiles per row, pg 1 only 4, and waves w and w+4 share a
     // SIMD: flip pg for the upper four waves so every SIMD gets one heavy and one light wave (otherwise two SIMDs of the CU
     // carry 25 % more MFMA work than the other two and everyone waits for them at the strip barrier).
-    const int rp = w >> 1, pg = (w ^ (w >> 2)) & 1;
+    const int rp = w >> 1, pg = (NW == 8 ? (w ^ (w >> 2)) : w) & 1;
     const int img = blockIdx.x;
 
     const int mg = a.m0 + img;
@@ -401,7 +401,10 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
 #pragma unroll
             for (int t9 = 0; t9 < 9; ++t9) v += tv[t9];
             const float pr = 1.0f / (1.0f + EFE_EXP(-v));
-            if (po) po[oh * 64 + ow] = pr;
+            if (po) {           // address rebuilt here from a laundered lane index: hoisted out of the strip loop it is a spilled VGPR pair
+                int owl = ow; asm volatile("" : "+v"(owl));
+                (po + oh * 64)[owl] = pr;
+            }
             if (mode == 0) part += -(1.0f - pr) * EFE_LOG(D1 - pr) - pr * EFE_LOG(D0 + pr);
             else           // target = 1 for image rows h < 32, 0 below (NCHW broadcast of the port)
                 part += (oh < 32) ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f) : pr * logf(D0) + (1.0f - pr) * logf(D1);
@@ -429,13 +432,14 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
 
 void launch_dec_b(const DecBArgs& a, hipStream_t st) {
     const size_t lds4 = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 66 * sizeof(float);
-    if (!(a.dbg & 24)) {        // default: 8 waves per workgroup, one strip row each, 4 waves per SIMD
+    const size_t lds2 = ((3 * 32 + 1) * 16) * sizeof(float4) + 6 * 9 * 66 * sizeof(float);
+    if (!(a.dbg & 24)) {        // default: 2-row strips, four one-row waves per workgroup, 38 KiB LDS: four workgroups (four independent
+                                // barrier domains) and 16 waves per CU.  Measured 0.795 of the fp32 MFMA peak (k_dec_b alone, 19200 images)
+        hipLaunchKernelGGL((k_dec_b<2, 1>), dim3(a.rows), dim3(256), lds2, st, a);
+    } else if (a.dbg & 8) {     // 4-row strips, eight one-row waves, two workgroups per CU: 0.767
         hipLaunchKernelGGL((k_dec_b<4, 1>), dim3(a.rows), dim3(512), lds4, st, a);
-    } else if (a.dbg & 16) {    // 4-wave workgroups, 4-row strips, two rows per wave (measured 4 % slower; kept for A/B)
+    } else {                    // 4-row strips, four two-row waves (8 waves per CU): 0.738
         hipLaunchKernelGGL((k_dec_b<4, 2>), dim3(a.rows), dim3(256), lds4, st, a);
-    } else {                    // 2-wave workgroups, 2-row strips (measured 9 % slower; kept for A/B)
-        const size_t lds = ((3 * 32 + 1) * 16) * sizeof(float4) + 6 * 9 * 66 * sizeof(float);
-        hipLaunchKernelGGL((k_dec_b<2, 2>), dim3(a.rows), dim3(128), lds, st, a);
     }
 }
 

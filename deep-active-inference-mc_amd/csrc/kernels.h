@@ -86,7 +86,7 @@ struct DecBArgs {
     int store0;           // groups with pidx == 0 store their image at slot t*S + sample
     float* val;           // [batch] per-image pixel sum (entropy sum, or log-likelihood sum)
     float* po;            // [slots][rows_per_group][4096] stored images
-    int dbg;              // experiments only: 2 = skip gather/epilogue math, 16 = 4-wave workgroups, 8 = 2-wave / 2-row strips
+    int dbg;              // experiments only: 2 = skip gather/epilogue math, 8 = 4-row strips / 8 waves, 16 = 4-row strips / 4 waves
     long long* tl;        // EFE_PHASE_CLK builds only: per-workgroup phase cycle sums [rows][8]
 };
 // fused encoder trunk: o [rows][64][64] -> conv1..conv4 (+ReLU) -> out [rows][576] in NHWC (p*64 + c) order

@@ -4,6 +4,7 @@
 namespace efe {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
 // Dense layer:  Y^T[co, m] = act(bias[co] + sum_ci W[co,ci] * X[m, ci])  (+ MC-dropout)
@@ -45,26 +46,64 @@ __global__ void __launch_bounds__(256) k_dense(const GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.0f;
 
-    const float4* wp = reinterpret_cast<const float4*>(a.Wp) + ((size_t)mt0 * KC) * 64 + lane;
-#pragma unroll 2
-    for (int kc = 0; kc < KC; ++kc) {
-        float4 av[MT], bv[NT];
+    // Software-pipelined contraction: the operand fragments of chunk kc + PD are requested before the MFMAs of chunk kc issue
+    // (an unpipelined loop exposes one L2 round trip per chunk: 25 us for a 512 x 512 layer whose MFMAs take 7 us).  Weights
+    // come through a buffer resource (SGPR base + SGPR chunk offset + one lane VGPR), activations through the row pointer.
+    constexpr int PD = 4;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wp), 0, 0x7fffffff, 0x00020000);
+    const unsigned wl = (unsigned)lane * 16u;
+    auto wload = [&](int mt, int kc) -> float4 {
+        const uint4v v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((mt0 + mt) * KC + kc) * 64) * 16u, 0);
+        return __builtin_bit_cast(float4, v);
+    };
+    float4 aq[PD][MT], bq[PD][NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt] = wp[(size_t)(mt * KC + kc) * 64];
+    for (int p_ = 0; p_ < PD; ++p_) {
+        const int kc = p_ < KC ? p_ : KC - 1;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const float4*>(xp[nt] + kc * 8);
+        for (int mt = 0; mt < MT; ++mt) aq[p_][mt] = wload(mt, kc);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int nt = 0; nt < NT; ++nt) bq[p_][nt] = *reinterpret_cast<const float4*>(xp[nt] + kc * 8);
+    }
+    for (int kc0 = 0; kc0 < KC; kc0 += PD) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
-            }
+        for (int p_ = 0; p_ < PD; ++p_) {
+            const int kc = kc0 + p_;
+            if (kc >= KC) break;                       // uniform
+            float4 av[MT], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = aq[p_][mt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bq[p_][nt];
+            const int kn = kc + PD < KC ? kc + PD : KC - 1;        // clamped: the tail re-reads the last chunk instead of branching
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) aq[p_][mt] = wload(mt, kn);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bq[p_][nt] = *reinterpret_cast<const float4*>(xp[nt] + kn * 8);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
+                }
+        }
     }
 
     // ---- epilogue: C/D layout col = lane&31 (batch row), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (feature)
+    // The biases are fetched up front: a global load between the stores below would wait (s_waitcnt vmcnt(0), the counter
+    // retires in order) for every store issued before it -- ~2 us of write latency per bias quad, 18 us for a K = 16 layer.
+    float4 bbq[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = (mt0 + mt) * 32 + 8 * g4 + 4 * h;
+            bbq[mt][g4] = (co < a.cout) ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         if (!pv[nt]) continue;
@@ -84,7 +123,7 @@ __global__ void __launch_bounds__(256) k_dense(const GemmArgs a) {
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int co = (mt0 + mt) * 32 + 8 * g4 + 4 * h;
                 if (co < a.cout) {
-                    const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
+                    const float4 bb = bbq[mt][g4];
                     float v[4] = {acc[mt][nt][4 * g4 + 0] + bb.x, acc[mt][nt][4 * g4 + 1] + bb.y,
                                   acc[mt][nt][4 * g4 + 2] + bb.z, acc[mt][nt][4 * g4 + 3] + bb.w};
                     if (a.relu) {
