@@ -39,7 +39,12 @@ constexpr int DA_BIAS = 257 * 16;          // float4 index of the two bias vecto
 #else
 #define EFE_X_BAR() __syncthreads()
 #endif
-__global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
+// NTW = 32-pixel tiles per wave: 2 = four waves of 64 features x 64 pixels (256 VGPRs, 2 waves per SIMD); 1 = eight waves of
+// 64 x 32 (128 VGPRs, 4 waves per SIMD).
+template <int NTW>
+__global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) {
+    constexpr int NTHR = 512 / NTW;
+    constexpr int NPH = 2048 / NTHR;                  // float4s per thread of each image half
     int tlk = 0; (void)tlk;
 #ifdef EFE_PHASE_CLK
     long long phs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
@@ -60,12 +65,17 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
     int* const slot = reinterpret_cast<int*>(sm + DA_BIAS + 32);
     if (tid == 0) slot[0] = 2 * (int)gridDim.x + atomicAdd(a.queue, 1);
     int nimg = (int)blockIdx.x + (int)gridDim.x;
-    f32x4 pfa[8], pfb[8];                                              // next image, in flight during compute
+    // next image, in flight during compute.  The 8-wave form keeps only NPB of the second half's NPH pieces in registers (128-VGPR
+    // budget) and fetches the last ones when the image is staged (the other three waves of the SIMD cover that latency).
+    constexpr int NPB = NTW == 1 ? NPH - 2 : NPH;
+    f32x4 pfa[NPH], pfb[NPB];
     f32x4* smv = reinterpret_cast<f32x4*>(sm);
     {
         const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)blockIdx.x * 4096;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) { pfa[it] = X[it * 256 + tid]; pfb[it] = X[(it + 8) * 256 + tid]; }
+        for (int it = 0; it < NPH; ++it) pfa[it] = X[it * NTHR + tid];
+#pragma unroll
+        for (int it = 0; it < NPB; ++it) pfb[it] = X[(it + NPH) * NTHR + tid];
     }
     if (tid < 16) sm[256 * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     // biases live in LDS: a global bias load inside an epilogue forces s_waitcnt vmcnt(0), i.e. waits for every store
@@ -84,11 +94,21 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
         // this wave's 64 pixels / input positions: image rows 4w .. 4w+3, two 32-pixel tiles of two rows each
         const int j = tl_ & 31, h = (tl_ >> 5) & 1;
         const int pcol = j & 15;
-        const int prow0 = 4 * w + (j >> 4);                            // tile nt covers rows prow0 + 2*nt
-        {   // swz(it*16 + (tid>>4), tid&15) = it*256 + sbase: one address register, immediate offsets
+        const int prow0 = 2 * NTW * w + (j >> 4);                      // tile nt covers rows prow0 + 2*nt
+        {   // swz(it*(NTHR/16) + (tid>>4), tid&15) = it*NTHR + sbase: one address register, immediate offsets
             const int sbase = (tl_ >> 4) * 16 + ((tl_ & 15) ^ ((tl_ >> 4) & 15));
 #pragma unroll
-            for (int it = 0; it < 8; ++it) { smv[sbase + it * 256] = pfa[it]; smv[sbase + (it + 8) * 256] = pfb[it]; }
+            for (int it = 0; it < NPH; ++it) smv[sbase + it * NTHR] = pfa[it];
+#pragma unroll
+            for (int it = 0; it < NPB; ++it) smv[sbase + (it + NPH) * NTHR] = pfb[it];
+            if (NPB < NPH) {
+                const f32x4* Xc = reinterpret_cast<const f32x4*>(a.x4) + (size_t)img * 4096;
+                f32x4 late[NPH - NPB + 1];
+#pragma unroll
+                for (int it = NPB; it < NPH; ++it) late[it - NPB] = (Xc + (it + NPH) * NTHR)[tl_];
+#pragma unroll
+                for (int it = NPB; it < NPH; ++it) smv[sbase + (it + NPH) * NTHR] = late[it - NPB];
+            }
         }
 #endif
         EFE_X_BAR();
@@ -101,23 +121,25 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
         {   // request the next image now (clamped on the last pass: unconditional loads keep pf[] in registers)
             const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)((more && !(a.dbg & 2)) ? nimg : img) * 4096;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) { pfa[it] = (X + it * 256)[tl_]; pfb[it] = (X + (it + 8) * 256)[tl_]; }
+            for (int it = 0; it < NPH; ++it) pfa[it] = (X + it * NTHR)[tl_];
+#pragma unroll
+            for (int it = 0; it < NPB; ++it) pfb[it] = (X + (it + NPH) * NTHR)[tl_];
         }
 #endif
 
-        f32x16 acc[2][2];
+        f32x16 acc[2][NTW];
         // ---------------- layer 1: out[oh,ow] = sum_{kh,kw} in[oh+1-kh, ow+1-kw] . W[:, :, kh, kw] --------------
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
-        tap_loop<2, 2>(acc, 9, W1, sm, h, [&](int t, int (&bs)[2], int (&sw)[2], int& wt) {
+        tap_loop_pd<2, NTW, 1>(acc, 9, W1, sm, h, [&](int t, int (&bs)[NTW], int (&sw)[NTW], int& wt) {
             const int kh = t / 3, kw = t - kh * 3;
             wt = t;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NTW; ++nt) {
                 const int sy = prow0 + 2 * nt + 1 - kh, sx = pcol + 1 - kw;
                 const bool ok = sy >= 0 && sy < 16 && sx >= 0 && sx < 16;
                 const int sp = ok ? sy * 16 + sx : 256;
@@ -131,8 +153,8 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
 #ifndef EFE_X_NOEPI1          // timing experiment (wrong results): no layer-1 epilogue
         // bias + ReLU, written back IN PLACE as the input image of layer 2 (same swizzled layout)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int pix = 64 * w + 32 * nt + j;
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int pix = 32 * NTW * w + 32 * nt + j;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -160,17 +182,17 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
-            tap_loop<2, 2>(acc, (1 + ph) * (1 + pw), W2, sm, h, ConvT2Addr<2>{ph, pw, prow0, 2, pcol, 16, 16, 256}, ConvWIdx{});
+            tap_loop_pd<2, NTW, 1>(acc, (1 + ph) * (1 + pw), W2, sm, h, ConvT2Addr<NTW>{ph, pw, prow0, 2, pcol, 16, 16, 256}, ConvWIdx{});
             TL(5);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NTW; ++nt) {
                 // y2 layout (float4 units): [parity][8 channel groups][256 input positions][2 quads] -- for one (mt, g4) the 64
                 // lanes (position j of this wave's tile, quad h) write 1 KiB contiguous; the NHWC order would split every
                 // store into 32 scattered 32-byte pieces
-                float4* yp = reinterpret_cast<float4*>(Y) + (size_t)par * 4096 + ((4 * w + 2 * nt) * 16 + j) * 2 + h;
+                float4* yp = reinterpret_cast<float4*>(Y) + (size_t)par * 4096 + ((2 * NTW * w + 2 * nt) * 16 + j) * 2 + h;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -206,9 +228,17 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
 
 void launch_dec_a(const DecAArgs& a, hipStream_t st) {
     static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)k_dec_a, hipFuncAttributeMaxDynamicSharedMemorySize, (257 * 16 + 33) * sizeof(float4)); once = true; }
-    const int grid = a.rows < 512 ? a.rows : 512;         // persistent: 2 workgroups per CU, images strided by the grid
-    hipLaunchKernelGGL(k_dec_a, dim3(grid), dim3(256), (257 * 16 + 33) * sizeof(float4), st, a);
+    const size_t lds = (257 * 16 + 33) * sizeof(float4);
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)(k_dec_a<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)(k_dec_a<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        once = true;
+    }
+    const int grid = a.rows < 512 ? a.rows : 512;         // persistent: 2 workgroups per CU
+    // default: four waves of 64 features x 64 pixels (0.872 of the fp32 MFMA peak alone, 19200 images).  dbg bit 2: eight waves of
+    // 64 x 32 (0.881 alone, no gain inside the rollout; kept for A/B)
+    if (a.dbg & 4) hipLaunchKernelGGL((k_dec_a<1>), dim3(grid), dim3(512), lds, st, a);
+    else           hipLaunchKernelGGL((k_dec_a<2>), dim3(grid), dim3(256), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -70,7 +70,7 @@ struct DecAArgs {
     const float* w2; const float* b2;
     int rows;
     int* queue;           // zero-initialised ticket counter of this launch: images beyond the first two per workgroup are claimed dynamically
-    int dbg;              // timing experiments only (0 in production): 2 = skip next-image prefetch
+    int dbg;              // experiments only (0 in production): 2 = skip next-image prefetch, 4 = eight-wave workgroups
     long long* tl;        // timeline experiments only (EFE_TIMELINE builds): s_memtime stamps of workgroup 0 / wave 0
 };
 // fused decoder, stage B: y2 -> ConvT(64,32,s2)+ReLU -> ConvT(32,1,s1)+Sigmoid -> per-image reduction (+ image store)

@@ -174,6 +174,15 @@ __device__ __forceinline__ void tap_loop(f32x16 (&acc)[MT][NT], const int ntaps,
 }
 
 
+// explicit prefetch distance (kernels with 4 waves per SIMD and a tight VGPR budget use PD = 1 for narrow tiles too)
+template <int MT, int NT, int PD, class AddrFn, class WIdx>
+__device__ __forceinline__ void tap_loop_pd(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
+                                            const float4* sm, const int h, AddrFn addr, WIdx widx) {
+    TapPipe<MT, NT, 8, PD> p;
+    p.begin(Wl, sm, h, addr, widx);
+    p.run(acc, ntaps, Wl, sm, h, addr, widx);
+}
+
 template <int MT, int NT, int KC, class AddrFn, class WIdx>
 __device__ __forceinline__ void tap_loop_kc(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
                                             const float4* sm, const int h, AddrFn addr, WIdx widx) {
