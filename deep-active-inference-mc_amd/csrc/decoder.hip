@@ -309,9 +309,9 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
     if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];
     float w4f[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int co = (e & 3) + 8 * (e >> 2) + 4 * h;
-        w4f[e] = ((lane & 15) < 9) ? a.w4[(lane & 15) * 32 + co] : 0.f;   // A_b[i = tap = lane&15], b>>1 = h
+    for (int g4 = 0; g4 < 4; ++g4) {                   // register e holds channel co = (e&3) + 8*(e>>2) + 4h: four contiguous floats per e>>2
+        const float4 q = ((lane & 15) < 9) ? reinterpret_cast<const float4*>(a.w4 + (lane & 15) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+        w4f[4 * g4] = q.x; w4f[4 * g4 + 1] = q.y; w4f[4 * g4 + 2] = q.z; w4f[4 * g4 + 3] = q.w;   // A_b[i = tap = lane&15], b>>1 = h
     }
     if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < DB_YROWS * 9 * 2; i += NTHR) sT[(i >> 1) * TS + (i & 1) * (TS - 1)] = 0.f;   // the pad columns (never rewritten)

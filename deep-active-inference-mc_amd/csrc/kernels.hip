@@ -206,43 +206,78 @@ void launch_trans_post(const TransPostArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// EFE term combine (torchmodel.py:278-298).  Thread = batch row; the loops
-// over samples and stages run in the reference's order so fp32 rounding follows it.
+// EFE term combine (torchmodel.py:278-298).  Every partial sum is formed in the
+// reference's order (samples inside a stage, then stages), so fp32 rounding follows it; only the
+// independent per-(stage, sample, row) pieces are evaluated in parallel (one thread per batch row
+// running all D*S*22 loads back to back took 60 us).
+//   phase 1: thread = (stage t, sample i, row): reward term, -entropy sum, the two image-entropy sums
+//   phase 2: thread = (stage t, row): sums over the samples in order
+//   phase 3: thread = row: sums over the stages in order
 // ---------------------------------------------------------------------------------------------
-__global__ void k_terms(const TermsArgs a) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.R) return;
-    const int S = a.S, R = a.R;
+template <int TERMS_RB>              // rows per workgroup
+__global__ void __launch_bounds__(256) k_terms(const TermsArgs a) {
+    extern __shared__ float sh[];                       // [D*S][RB][4] then [D][RB][6]
+    const int S = a.S, R = a.R, D = a.D;
+    const int r0 = blockIdx.x * TERMS_RB;
+    float* p1s = sh;
+    float* p2s = sh + (size_t)D * S * TERMS_RB * 4;
     const float C = 2.8378770664093453f;   // log(2*pi*e), torchutils.py:19
-    float sG = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, p1 = 0.f, p2 = 0.f;
-    for (int t = 0; t < a.D; ++t) {
+    for (int idx = threadIdx.x; idx < D * S * TERMS_RB; idx += blockDim.x) {
+        const int rr = idx % TERMS_RB, ti = idx / TERMS_RB;
+        const int t = ti / S, i = ti - t * S;
+        const int r = r0 + rr;
+        if (r >= R) continue;
         const float* val = a.val + (size_t)t * 3 * S * R;
+        const float* tr = a.tr + (((size_t)t * 2 * S + i) * R + r) * 32 + 10;
+        const float* en = a.enc + (((size_t)t * S + i) * R + r) * 32 + 10;
+        float h = 0.f;
+        for (int k = 0; k < 10; ++k) h += 0.5f * (C + tr[k]) + 0.5f * (C + en[k]);
+        p1s[idx * 4 + 0] = val[(size_t)i * R + r] * (1.0f / 4096.0f) * 10.0f;   // mean over pixels * 10 (torchmodel.py:212)
+        p1s[idx * 4 + 1] = -h;
+        p1s[idx * 4 + 2] = val[(size_t)(S + i) * R + r];
+        p1s[idx * 4 + 3] = val[(size_t)(2 * S + i) * R + r];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < D * TERMS_RB; idx += blockDim.x) {
+        const int rr = idx % TERMS_RB, t = idx / TERMS_RB;
         float t0 = 0.f, t1 = 0.f, t21 = 0.f, t22 = 0.f;
         for (int i = 0; i < S; ++i) {
-            t0 += val[(size_t)i * R + r] * (1.0f / 4096.0f) * 10.0f;   // mean over pixels * 10 (torchmodel.py:212)
-            const float* tr = a.tr + (((size_t)t * 2 * S + i) * R + r) * 32 + 10;
-            const float* en = a.enc + (((size_t)t * S + i) * R + r) * 32 + 10;
-            float h = 0.f;
-            for (int k = 0; k < 10; ++k) h += 0.5f * (C + tr[k]) + 0.5f * (C + en[k]);
-            t1 += -h;
+            const float* q = p1s + ((size_t)(t * S + i) * TERMS_RB + rr) * 4;
+            t0 += q[0]; t1 += q[1];
         }
         t0 /= (float)S; t1 /= (float)S;
-        for (int jj = 0; jj < S; ++jj) {
-            t21 += val[(size_t)(S + jj) * R + r];
-            t22 += val[(size_t)(2 * S + jj) * R + r];
+        for (int i = 0; i < S; ++i) {
+            const float* q = p1s + ((size_t)(t * S + i) * TERMS_RB + rr) * 4;
+            t21 += q[2]; t22 += q[3];
         }
         t21 /= (float)S; t22 /= (float)S;
         const float t2 = t21 - t22;
-        const float G = -t0 + t1 + t2;
-        s0 += t0; s1 += t1; s2 += t2; sG += G; p1 = t21; p2 = t22;
+        float* o = p2s + (size_t)idx * 6;
+        o[0] = t0; o[1] = t1; o[2] = t2; o[3] = -t0 + t1 + t2; o[4] = t21; o[5] = t22;
     }
-    a.G[r] = sG;
-    a.terms[r] = s0; a.terms[R + r] = s1; a.terms[2 * R + r] = s2;
-    if (a.t2parts) { a.t2parts[r] = p1; a.t2parts[R + r] = p2; }
+    __syncthreads();
+    if (threadIdx.x < TERMS_RB && r0 + (int)threadIdx.x < R) {
+        const int rr = threadIdx.x, r = r0 + rr;
+        float sG = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, p1 = 0.f, p2 = 0.f;
+        for (int t = 0; t < D; ++t) {
+            const float* o = p2s + ((size_t)t * TERMS_RB + rr) * 6;
+            s0 += o[0]; s1 += o[1]; s2 += o[2]; sG += o[3]; p1 = o[4]; p2 = o[5];
+        }
+        a.G[r] = sG;
+        a.terms[r] = s0; a.terms[R + r] = s1; a.terms[2 * R + r] = s2;
+        if (a.t2parts) { a.t2parts[r] = p1; a.t2parts[R + r] = p2; }
+    }
 }
 
 void launch_terms(const TermsArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_terms, dim3((a.R + 127) / 128), dim3(128), 0, st, a);
+    auto bytes = [&](int rb) { return ((size_t)a.D * a.S * rb * 4 + (size_t)a.D * rb * 6) * sizeof(float); };
+    if (bytes(4) <= 48 * 1024) {
+        hipLaunchKernelGGL(k_terms<4>, dim3((a.R + 3) / 4), dim3(256), bytes(4), st, a);
+    } else {                     // very deep / many-sample calls: one row per workgroup, LDS limit raised (D*S up to ~9000)
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute((const void*)(k_terms<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); once = true; }
+        hipLaunchKernelGGL(k_terms<1>, dim3(a.R), dim3(256), bytes(1), st, a);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
