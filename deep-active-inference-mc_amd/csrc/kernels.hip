@@ -18,15 +18,21 @@ typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 // B[k = l>>5][j = l&31]).  Used for the small layers (transition / habit / decoder head / encoder head);
 // the 256 -> 16384 layer has its own LDS-staged kernel (decoder.hip: k_fc4).
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT>
+// SK = 1: the 4 waves of a workgroup own 4 different row tiles.  SK = 4 (every layer with K >= 128, whatever the batch size, so that
+// the fp32 summation order never depends on how many rows are in flight): the 4 waves split K of ONE tile four ways and wave 0 adds
+// the partial accumulators in wave order through LDS -- a 512 x 512 layer over 2560 rows is then 1280 workgroups of 64-MFMA chains
+// (5 per CU, evenly) instead of 320 of 256-MFMA chains (1.25 per CU: the kernel took two rounds, 24 us for 9 us of MFMA work).
+template <int MT, int NT, int SK>
 __global__ void __launch_bounds__(256) k_dense(const GemmArgs a) {
+    __shared__ float red[SK == 1 ? 1 : 3 * MT * NT * 16 * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
     const int KC = a.cin >> 3;
     const int mt0 = blockIdx.y * MT;
-    const int row0 = (blockIdx.x * 4 + wave) * (NT * 32);
-    if (row0 >= a.n_pix) return;                      // wave-uniform
+    const int row0 = (SK == 1 ? blockIdx.x * 4 + wave : blockIdx.x) * (NT * 32);
+    if (row0 >= a.n_pix) return;                      // wave-uniform (workgroup-uniform when SK = 4)
+    const int kcb = SK == 1 ? 0 : (wave * KC) / SK, kce = SK == 1 ? KC : ((wave + 1) * KC) / SK;   // this wave's chunk range
 
     bool pv[NT];
     const float* xp[NT];
@@ -59,23 +65,23 @@ __global__ void __launch_bounds__(256) k_dense(const GemmArgs a) {
     float4 aq[PD][MT], bq[PD][NT];
 #pragma unroll
     for (int p_ = 0; p_ < PD; ++p_) {
-        const int kc = p_ < KC ? p_ : KC - 1;
+        const int kc = kcb + p_ < kce ? kcb + p_ : kce - 1;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) aq[p_][mt] = wload(mt, kc);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bq[p_][nt] = *reinterpret_cast<const float4*>(xp[nt] + kc * 8);
     }
-    for (int kc0 = 0; kc0 < KC; kc0 += PD) {
+    for (int kc0 = kcb; kc0 < kce; kc0 += PD) {
 #pragma unroll
         for (int p_ = 0; p_ < PD; ++p_) {
             const int kc = kc0 + p_;
-            if (kc >= KC) break;                       // uniform
+            if (kc >= kce) break;                      // uniform
             float4 av[MT], bv[NT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) av[mt] = aq[p_][mt];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bv[nt] = bq[p_][nt];
-            const int kn = kc + PD < KC ? kc + PD : KC - 1;        // clamped: the tail re-reads the last chunk instead of branching
+            const int kn = kc + PD < kce ? kc + PD : kce - 1;      // clamped: the tail re-reads the last chunk instead of branching
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) aq[p_][mt] = wload(mt, kn);
 #pragma unroll
@@ -91,6 +97,27 @@ __global__ void __launch_bounds__(256) k_dense(const GemmArgs a) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
                 }
         }
+    }
+
+    if (SK > 1) {                                      // split-K: partial tiles of waves 1..3 -> LDS, wave 0 adds them in wave order
+        if (wave > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[(((wave - 1) * MT * NT + mt * NT + nt) * 16 + e) * 64 + lane] = acc[mt][nt][e];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int ws = 0; ws < 3; ++ws)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[mt][nt][e] += red[((ws * MT * NT + mt * NT + nt) * 16 + e) * 64 + lane];
     }
 
     // ---- epilogue: C/D layout col = lane&31 (batch row), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (feature)
@@ -143,15 +170,16 @@ __global__ void __launch_bounds__(256) k_dense(const GemmArgs a) {
     }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int SK>
 static void launch_dn(const GemmArgs& a, hipStream_t st) {
-    const int rows_per_wg = 4 * NT * 32;
+    const int rows_per_wg = (SK == 1 ? 4 : 1) * NT * 32;
     dim3 grid((a.n_pix + rows_per_wg - 1) / rows_per_wg, (a.mtiles + MT - 1) / MT);
-    hipLaunchKernelGGL((k_dense<MT, NT>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_dense<MT, NT, SK>), grid, dim3(256), 0, st, a);
 }
 
 void launch_dense(int MT, int NT, const GemmArgs& a, hipStream_t st) {
-#define EFE_CASE(M_, N_) if (MT == M_ && NT == N_) { launch_dn<M_, N_>(a, st); return; }
+    const bool sk = a.cin >= 128;         // a property of the layer only (see k_dense)
+#define EFE_CASE(M_, N_) if (MT == M_ && NT == N_) { if (sk) launch_dn<M_, N_, 4>(a, st); else launch_dn<M_, N_, 1>(a, st); return; }
     EFE_CASE(1, 1)
     EFE_CASE(2, 1)
     EFE_CASE(1, 2)
