@@ -217,6 +217,25 @@ def test_chunking_invariance(models):
     assert torch.equal(G1, G2) and torch.equal(po1, po2)
 
 
+@pytest.mark.parametrize('opt,val', [('dbg_b', 8), ('dbg_b', 16), ('dbg_a', 4)])
+def test_kernel_variants_agree(models, opt, val):
+    """the alternative workgroup shapes of the decoder kernels (4-row strips / 8 waves, 4-row strips / 4 waves for
+    k_dec_b; 8-wave k_dec_a) compute the same images bit for bit and the same pixel sums up to the order in which
+    a thread adds its pixels (fp32: a few ulp of a ~2.8e3 sum)."""
+    m = models(1234, 1.15, 13)
+    o = synth.make_frames(33, 10)
+    pi = np.eye(4, dtype=np.float32)[np.arange(10) % 4]
+    G1, t1, po1 = m.calculate_G_repeated(o, pi, steps=2, samples=3, stage=5)
+    m.set_option(opt, val)
+    try:
+        G2, t2, po2 = m.calculate_G_repeated(o, pi, steps=2, samples=3, stage=5)
+    finally:
+        m.set_option(opt, 0)
+    assert torch.equal(po1, po2)
+    np.testing.assert_allclose(c(G2), c(G1), rtol=0, atol=2e-2)
+    np.testing.assert_allclose(c(t2[0]), c(t1[0]), rtol=1e-5, atol=1e-4)
+
+
 def test_full_size_properties(models):
     """BASELINE cfg-2 shape (128 rows, S=10, D=5): size-independent properties -- determinism, finite
     outputs, duplicate rows with equal global ids give equal results, action posterior sums to one."""
