@@ -381,16 +381,25 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) T2[nt][e] = 0.f;
             }
+#ifdef EFE_X_NO_TMFMA        // timing experiment (wrong results): no tap-plane contraction
+#pragma unroll
+            for (int nt = 0; nt < RW; ++nt) T2[nt] = acc[nt];
+#else
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
 #pragma unroll
                 for (int nt = 0; nt < RW; ++nt) T2[nt] = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[nt][e], T2[nt], 0, 0, 0);
             }
+#endif
 #pragma unroll
             for (int nt = 0; nt < RW; ++nt) {
                 const f32x16 T = T2[nt];
                 // D layout: T[4b + r] = D_b[row = 4*(lane>>4) + r][col = lane&15]; pixel p = 16*(b&1) + col, and the two
                 // channel halves (b, b+2) of the same pixel sit in the same lane: add them.
+#ifdef EFE_X_NO_TWRITE        // timing experiment (wrong results): no tap-plane LDS writes
+                if (T[0] == 12345.678f) sT[lane] = T[1];
+                continue;
+#endif
                 const int tq = lane >> 4, c = lane & 15;               // this lane holds taps 4*tq + r
                 const int orow = 2 * (SR * s + RW * rp + nt) + ph;
                 float* tp = sT + ((orow % DB_YROWS) * 9 + 4 * tq) * TS + 1 + pw;
