@@ -494,45 +494,52 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    // XCD-aware mapping (workgroup b runs on XCD b % 8): feature group = b & 7, so every XCD streams ONE 2 MiB weight slice
-    // (L2-resident, 4 MiB per XCD) across all row tiles instead of thrashing over all eight.
+    // Persistent, XCD-aware and balanced: workgroup b runs on XCD b % 8 and only ever touches feature group b & 7, so every XCD
+    // streams ONE 2 MiB weight slice (L2-resident, 4 MiB per XCD).  The (row tile, feature step) pairs of a feature group are split
+    // into equal contiguous ranges over the gridDim/8 workgroups of that XCD: with one workgroup per (row tile, group) the 2400
+    // 230-us workgroups of a 19200-row launch ran as 4.7 waves over the 512 slots and the last, 70 %-full wave cost ~8 %.
     const int fgrp = blockIdx.x & 7;
-    const int row0 = (blockIdx.x >> 3) * 64;
+    const int nper = gridDim.x >> 3, k = blockIdx.x >> 3;
+    const int nsteps = ((a.n_pix + 63) / 64) * FC4_STEPS;              // (row tile, step) pairs of this feature group
+    const int q0 = (int)(((long)nsteps * k) / nper), q1 = (int)(((long)nsteps * (k + 1)) / nper);
     f32x4* smv = reinterpret_cast<f32x4*>(sm);
-    {
-        const f32x4* X = reinterpret_cast<const f32x4*>(a.X);
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int idx = it * 256 + tid;                            // 64 rows x 64 quads
-            const int r = idx >> 6, c4 = idx & 63;
-            const int gr = row0 + r;
-            smv[r * 64 + (c4 ^ (r & 15))] = (gr < a.n_pix) ? X[(size_t)gr * 64 + c4] : (f32x4)(0.f);
-        }
-    }
-    __syncthreads();
     const float4* Wl = reinterpret_cast<const float4*>(a.Wp);
-
-    // dropout keys of this lane's two rows
-    uint32_t krow[2], kstream[2], kstage[2];
-    bool rv[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int m = row0 + nt * 32 + j;
-        rv[nt] = m < a.n_pix;
-        const int mg = a.m0 + (rv[nt] ? m : 0);
-        const int g = mg / a.rows_per_group;
-        krow[nt] = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
-        const uint2 key = group_key(a.gm, g);
-        kstream[nt] = key.x; kstage[nt] = key.y;
-    }
-
     auto xaddr = [&](int t, int (&bs)[2], int (&sw)[2], int& wt) {
         wt = t;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) { bs[nt] = (nt * 32 + j) * 64 + t * 16; sw[nt] = j & 15; }
     };
+    int cur_rt = -1;
+    uint32_t krow[2] = {0, 0}, kstream[2] = {0, 0}, kstage[2] = {0, 0};
+    bool rv[2] = {false, false};
 #pragma unroll 1
-    for (int fs = 0; fs < FC4_STEPS; ++fs) {
+    for (int q = q0; q < q1; ++q) {
+        const int rt = q / FC4_STEPS, fs = q - rt * FC4_STEPS;
+        const int row0 = rt * 64;
+        if (rt != cur_rt) {                                            // (re)stage the 64-row tile: at most twice more than once per workgroup
+            if (cur_rt >= 0) __syncthreads();                          // every wave is done reading the previous tile
+            cur_rt = rt;
+            const f32x4* X = reinterpret_cast<const f32x4*>(a.X);
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int idx = it * 256 + tid;                        // 64 rows x 64 quads
+                const int r = idx >> 6, c4 = idx & 63;
+                const int gr = row0 + r;
+                smv[r * 64 + (c4 ^ (r & 15))] = (gr < a.n_pix) ? X[(size_t)gr * 64 + c4] : (f32x4)(0.f);
+            }
+            __syncthreads();
+            // dropout keys of this lane's two rows
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int m = row0 + nt * 32 + j;
+                rv[nt] = m < a.n_pix;
+                const int mg = a.m0 + (rv[nt] ? m : 0);
+                const int g = mg / a.rows_per_group;
+                krow[nt] = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
+                const uint2 key = group_key(a.gm, g);
+                kstream[nt] = key.x; kstage[nt] = key.y;
+            }
+        }
         const int mt0 = (fgrp * FC4_STEPS + fs) * 8 + 2 * w;           // this wave's first 32-feature tile
         f32x16 acc[2][2];
 #pragma unroll
@@ -572,10 +579,11 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
 }
 
 void launch_fc4(const GemmArgs& a, hipStream_t st) {
-    // grid: 64-row tiles x (512 feature tiles / (8 per step * FC4_STEPS)) feature groups
     static_assert(FC4_STEPS == 8, "512 feature tiles = 8 groups x 8 steps x 8 tiles");
-    dim3 grid(((a.n_pix + 63) / 64) * 8);
-    hipLaunchKernelGGL(k_fc4, grid, dim3(256), 64 * 64 * sizeof(float4), st, a);
+    // persistent: 2 workgroups per CU (64 KiB LDS each), 8 feature groups x (up to) 64 workgroups, each with >= 1 (row tile, step) pair
+    const int nsteps = ((a.n_pix + 63) / 64) * FC4_STEPS;
+    const int nper = nsteps < 64 ? nsteps : 64;
+    hipLaunchKernelGGL(k_fc4, dim3(8 * nper), dim3(256), 64 * 64 * sizeof(float4), st, a);
 }
 
 }  // namespace efe
