@@ -14,7 +14,10 @@ constexpr int EN_IMG = 0;                      // [64][64] input image          
 constexpr int EN_C2 = 4096;                    // [225 px][32 ch] conv2 output, 8 quads/pixel, quad ^= px & 7
 constexpr int EN_C3 = EN_C2 + 225 * 32;        // [49 px][64 ch] conv3 output, 16 quads/pixel, quad ^= px & 15
 constexpr int EN_W1 = EN_C3 + 49 * 64;         // conv1 weights [9 taps][32 ch] + bias [32]
-constexpr int EN_END = EN_W1 + 320;            // 14752 floats = 59008 B
+constexpr int EN_B2 = EN_W1 + 320;             // conv2 / conv3 / conv4 biases [32] [64] [64]: read in the epilogues from LDS (a global
+constexpr int EN_B3 = EN_B2 + 32;              // load there exposes an L2 round trip per phase and image)
+constexpr int EN_B4 = EN_B3 + 64;
+constexpr int EN_END = EN_B4 + 64;             // 14912 floats = 59648 B
 constexpr int EN_RED = EN_IMG;                 // conv4 split-K partials alias the (dead) input image
 
 __global__ void __launch_bounds__(256, 2) k_enc_trunk(const EncArgs a) {
@@ -27,6 +30,7 @@ __global__ void __launch_bounds__(256, 2) k_enc_trunk(const EncArgs a) {
 
     // conv1 weights + bias live in LDS ([tap][32 ch] so a lane's 4 channels of a chunk are one broadcast ds_read_b128)
     for (int i = tid; i < 320; i += 256) smf[EN_W1 + i] = (i < 288) ? a.w1[i] : a.b1[i - 288];
+    if (tid < 160) smf[EN_B2 + tid] = tid < 32 ? a.b2[tid] : tid < 96 ? a.b3[tid - 32] : a.b4[tid - 96];
     const float4* w1s = reinterpret_cast<const float4*>(smf + EN_W1);
     const float4* W2 = reinterpret_cast<const float4*>(a.w2) + lane;      // [9][1][4][64]
     const float4* W3 = reinterpret_cast<const float4*>(a.w3);             // [9][2][4][64] (uniform base, see TapPipe)
@@ -69,6 +73,7 @@ __global__ void __launch_bounds__(256, 2) k_enc_trunk(const EncArgs a) {
                         for (int bb = 0; bb < 3; ++bb) patch[nt][aa * 3 + bb] = ip[aa * 64 + bb];
                 }
             };
+            // (packed v_pk_fma_f32 for the two channel pairs was measured: 6 % slower than scalar FMAs here)
             auto gen_b = [&](const float (&patch)[2][9], int kc, int hq, float4 (&bv)[2]) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
@@ -109,7 +114,7 @@ __global__ void __launch_bounds__(256, 2) k_enc_trunk(const EncArgs a) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int c4 = 2 * g4 + h;
-                    const float4 bb = reinterpret_cast<const float4*>(a.b2)[c4];
+                    const float4 bb = sm4[EN_B2 / 4 + c4];
                     float4 v;
                     v.x = fmaxf(acc[nt][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[nt][4 * g4 + 1] + bb.y, 0.f);
                     v.z = fmaxf(acc[nt][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[nt][4 * g4 + 3] + bb.w, 0.f);
@@ -139,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) k_enc_trunk(const EncArgs a) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int c4 = mt * 8 + 2 * g4 + h;
-                    const float4 bb = reinterpret_cast<const float4*>(a.b3)[c4];
+                    const float4 bb = sm4[EN_B3 / 4 + c4];
                     float4 v;
                     v.x = fmaxf(acc[0][0][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[0][0][4 * g4 + 1] + bb.y, 0.f);
                     v.z = fmaxf(acc[0][0][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[0][0][4 * g4 + 3] + bb.w, 0.f);
@@ -177,7 +182,7 @@ __global__ void __launch_bounds__(256, 2) k_enc_trunk(const EncArgs a) {
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int c4 = mt * 8 + 2 * g4 + h;
-                    const float4 bb = reinterpret_cast<const float4*>(a.b4)[c4];
+                    const float4 bb = sm4[EN_B4 / 4 + c4];
                     float4 v;
                     v.x = fmaxf(acc[0][0][4 * g4 + 0] + red[(4 * g4 + 0) * 64 + lane] + bb.x, 0.f);
                     v.y = fmaxf(acc[0][0][4 * g4 + 1] + red[(4 * g4 + 1) * 64 + lane] + bb.y, 0.f);
