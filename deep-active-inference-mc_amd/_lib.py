@@ -10,7 +10,12 @@ EXPORTS = ['efe_create', 'efe_destroy', 'efe_last_error', 'efe_abi_version', 'ef
            'efe_set_option', 'efe_transition', 'efe_decoder', 'efe_encoder', 'efe_habit', 'efe_calculate_g',
            'efe_rollout', 'efe_trajectory', 'efe_simulate', 'efe_action_posterior', 'efe_last_call_macs',
            'efe_prof_enable', 'efe_prof_classes', 'efe_prof_read', 'efe_env_reset', 'efe_env_step', 'efe_env_render',
-           'efe_check_reward', 'efe_reparameterize']
+           'efe_check_reward', 'efe_reparameterize', 'efe_mcts_select', 'efe_mcts_expand', 'efe_mcts_backprop', 'efe_mcts_stop']
+
+
+class EfeMctsTree(C.Structure):
+    _fields_ = [('W', C.c_void_p), ('N', C.c_void_p), ('Qpi', C.c_void_p), ('child', C.c_void_p), ('S', C.c_void_p),
+                ('E', C.c_int32), ('cap', C.c_int32), ('A', C.c_int32), ('s_dim', C.c_int32)]
 
 
 class EfeNoise(C.Structure):
@@ -57,5 +62,10 @@ def load():
     lib.efe_env_render.argtypes = [p, f32p, f32p, C.c_void_p, C.c_int64, f32p, C.c_void_p, i, p]; lib.efe_env_render.restype = i
     lib.efe_check_reward.argtypes = [p, f32p, i, f32p, p]; lib.efe_check_reward.restype = i
     lib.efe_reparameterize.argtypes = [p, f32p, f32p, i, i, nzp, f32p, f32p, p]; lib.efe_reparameterize.restype = i
+    tp = C.POINTER(EfeMctsTree)
+    lib.efe_mcts_select.argtypes = [p, tp, p, C.c_float, i, i, p, p, p, p, f32p, f32p, p]; lib.efe_mcts_select.restype = i
+    lib.efe_mcts_expand.argtypes = [p, tp, p, p, p, f32p, f32p, p]; lib.efe_mcts_expand.restype = i
+    lib.efe_mcts_backprop.argtypes = [p, tp, p, p, p, p, p, f32p, i, f32p, i, f32p, p, p]; lib.efe_mcts_backprop.restype = i
+    lib.efe_mcts_stop.argtypes = [p, tp, p, p, i, C.c_float, p, p]; lib.efe_mcts_stop.restype = i
     _lib = lib
     return lib

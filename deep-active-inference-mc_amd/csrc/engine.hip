@@ -512,6 +512,63 @@ int efe_env_render(efe_ctx* ctx, const float* state, const float* last_r, const 
     return finish(ctx);
 }
 
+namespace {
+int mcts_tree(efe_ctx* ctx, const efe_mcts_tree* t, MctsTree& o) {
+    if (!t || !t->W || !t->N || !t->Qpi || !t->child || !t->S || t->E < 1 || t->cap < 1 || t->A < 1 || t->A > 8 || t->s_dim < 1)
+        return ctx->fail("efe_mcts: bad tree");
+    o = MctsTree{t->W, t->N, t->Qpi, t->child, t->S, t->E, t->cap, t->A, t->s_dim};
+    return 0;
+}
+}  // namespace
+
+int efe_mcts_select(efe_ctx* ctx, const efe_mcts_tree* tree, const uint8_t* active, float C, int use_prior, int max_depth,
+                    int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf, float* leaf_s, float* leaf_s_rep,
+                    void* stream) {
+    if (!ctx) return 1;
+    MctsTree t;
+    if (mcts_tree(ctx, tree, t)) return 1;
+    if (!active || !path_nodes || !path_act || !path_len || !leaf || !leaf_s || !leaf_s_rep || max_depth < 1)
+        return ctx->fail("efe_mcts_select: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_mcts_select(t, active, C, use_prior, max_depth, path_nodes, path_act, path_len, leaf, leaf_s, leaf_s_rep, (hipStream_t)stream);
+    return finish(ctx);
+}
+
+int efe_mcts_expand(efe_ctx* ctx, const efe_mcts_tree* tree, int32_t* n_nodes, const int32_t* nodes, const uint8_t* mask, const float* G,
+                    const float* ps_next, void* stream) {
+    if (!ctx) return 1;
+    MctsTree t;
+    if (mcts_tree(ctx, tree, t)) return 1;
+    if (!n_nodes || !nodes || !mask || !G || !ps_next) return ctx->fail("efe_mcts_expand: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_mcts_expand(t, n_nodes, nodes, mask, G, ps_next, (hipStream_t)stream);
+    return finish(ctx);
+}
+
+int efe_mcts_backprop(efe_ctx* ctx, const efe_mcts_tree* tree, const int32_t* path_nodes, const int32_t* path_act, const int32_t* path_len,
+                      const int32_t* leaf, const uint8_t* active, const float* sims, int n_sims, const float* q0, int max_depth,
+                      float* g_out, uint8_t* active_out, void* stream) {
+    if (!ctx) return 1;
+    MctsTree t;
+    if (mcts_tree(ctx, tree, t)) return 1;
+    if (!path_nodes || !path_act || !path_len || !leaf || !active || !sims || n_sims < 1 || !q0 || !g_out || !active_out || max_depth < 1)
+        return ctx->fail("efe_mcts_backprop: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_mcts_backprop(t, path_nodes, path_act, path_len, leaf, active, sims, n_sims, q0, max_depth, g_out, active_out, (hipStream_t)stream);
+    return finish(ctx);
+}
+
+int efe_mcts_stop(efe_ctx* ctx, const efe_mcts_tree* tree, uint8_t* active, int32_t* stop_at, int repeat, float threshold,
+                  int32_t* n_active, void* stream) {
+    if (!ctx) return 1;
+    MctsTree t;
+    if (mcts_tree(ctx, tree, t)) return 1;
+    if (!active || !stop_at || !n_active) return ctx->fail("efe_mcts_stop: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_mcts_stop(t, active, stop_at, repeat, threshold, n_active, (hipStream_t)stream);
+    return finish(ctx);
+}
+
 int64_t efe_last_call_macs(efe_ctx* ctx) { return ctx ? ctx->last_macs : 0; }
 
 int efe_prof_enable(efe_ctx* ctx, int on) {

@@ -130,6 +130,23 @@ struct TermsArgs {
 };
 void launch_terms(const TermsArgs& a, hipStream_t st);
 
+// ---- device-resident MCTS tree (mcts.hip) --------------------------------------------------------
+struct MctsTree {
+    float* W; float* N; float* Qpi;   // [E][cap][A] edge statistics of mcts.py Node (W = -sum G, N visits, Qpi habit prior)
+    int32_t* child;                   // [E][cap][A] node index of each child, -1 = not expanded
+    float* S;                         // [E][cap][s_dim] latent state of every node
+    int E, cap, A, s_dim;
+};
+void launch_mcts_select(const MctsTree& t, const uint8_t* active, float C, int use_prior, int max_depth, int32_t* path_nodes,
+                        int32_t* path_act, int32_t* path_len, int32_t* leaf, float* leaf_s, float* leaf_s_rep, hipStream_t st);
+void launch_mcts_expand(const MctsTree& t, int32_t* n_nodes, const int32_t* nodes, const uint8_t* mask, const float* G,
+                        const float* ps_next, hipStream_t st);
+void launch_mcts_backprop(const MctsTree& t, const int32_t* path_nodes, const int32_t* path_act, const int32_t* path_len,
+                          const int32_t* leaf, const uint8_t* active, const float* sims, int R, const float* q0, int max_depth,
+                          float* g_out, uint8_t* active_out, hipStream_t st);
+void launch_mcts_stop(const MctsTree& t, uint8_t* active, int32_t* stop_at, int repeat, float threshold, int32_t* n_active,
+                      hipStream_t st);
+
 void launch_pack_x(const float* pi, const float* s, float* x, int R, int pi_dim, int s_dim, hipStream_t st);
 void launch_pad16(const float* s, float* x, int R, int s_dim, hipStream_t st);
 void launch_root_post(const float* enc, const float* pi, const float* eps_inj, float* x, float* s_out, int R, int use_mean,

@@ -193,94 +193,79 @@ def _trim_path(visited, pi_dim):
 
 
 class BatchedMCTS:
-    """All tree statistics are [E, nodes, pi_dim] host tensors and every step is vectorised over the episodes
-    (no per-episode Python in the iteration loop); node states live on the device."""
+    """Lock-step planner over E episodes.  The tree statistics of every episode (mcts.py Node: W, N, Qpi,
+    children, node states) are device-resident [E, nodes, pi_dim] arrays; selection, expansion bookkeeping, back-propagation
+    and the early-stop test are one-thread-per-episode kernels behind the C ABI (`efe_mcts_*`, csrc/mcts.hip), so an
+    iteration is a stream of launches with no host round trip between the engine calls.  The host only reads the number of
+    still-active episodes (one int per iteration) and, at the end, the history needed for the reference's return tuple."""
 
     def __init__(self, model, n_episodes, params, episode_offset=0):
+        import ctypes as C
+        from . import _lib
         self.model, self.E, self.p = model, int(n_episodes), params
-        self.pi_dim = model.pi_dim
+        self.pi_dim = A = model.pi_dim
         self.ep0 = int(episode_offset)
-        self.cap = 1 + self.pi_dim * (params.repeats + 2)
+        self.cap = cap = 1 + A * (params.repeats + 2)
         self.max_depth = params.repeats + 2
-        E, A, cap = self.E, self.pi_dim, self.cap
-        self.W = torch.zeros(E, cap, A)
-        self.N = torch.zeros(E, cap, A)
-        self.Qpi = torch.zeros(E, cap, A)
-        self.child = torch.full((E, cap, A), -1, dtype=torch.long)
-        self.S = torch.zeros(E, cap, model.s_dim, device=model.device)
-        self.n_nodes = torch.ones(E, dtype=torch.long)
-        self.ar = torch.arange(E)
-        self.ar_dev = self.ar.to(model.device)
-        self.arA = torch.arange(A)
+        E, dev = self.E, model.device
+        self.W = torch.zeros(E, cap, A, device=dev)
+        self.N = torch.zeros(E, cap, A, device=dev)
+        self.Qpi = torch.zeros(E, cap, A, device=dev)
+        self.child = torch.full((E, cap, A), -1, dtype=torch.int32, device=dev)
+        self.S = torch.zeros(E, cap, model.s_dim, device=dev)
+        self.n_nodes = torch.ones(E, dtype=torch.int32, device=dev)
+        self._tree = _lib.EfeMctsTree(self.W.data_ptr(), self.N.data_ptr(), self.Qpi.data_ptr(), self.child.data_ptr(),
+                                      self.S.data_ptr(), E, cap, A, model.s_dim)
+        self._C = C
         self.pi_hot = (model.pi_one_hot if A == 4 else model.pi_one_hot_3).repeat(E, 1)
+        # per-iteration scratch + history (device)
+        R = max(1, params.repeats)
+        self.path_nodes = torch.zeros(E, self.max_depth, dtype=torch.int32, device=dev)
+        self.H_act = torch.zeros(R, E, self.max_depth, dtype=torch.int32, device=dev)
+        self.H_len = torch.zeros(R, E, dtype=torch.int32, device=dev)
+        self.H_g = torch.zeros(R, E, device=dev)
+        self.H_active = torch.zeros(R, E, dtype=torch.uint8, device=dev)
+        self.leaf = torch.zeros(E, dtype=torch.int32, device=dev)
+        self.leaf_s = torch.zeros(E, model.s_dim, device=dev)
+        self.leaf_rep = torch.zeros(E * A, model.s_dim, device=dev)
+        self.sims = torch.zeros(max(1, params.simulation_repeats), E, device=dev)
+        self.stop_at = torch.full((E,), -1, dtype=torch.int32, device=dev)
+        self.n_active = torch.zeros(1, dtype=torch.int32, device=dev)
 
-    def _scores(self, e_idx, nodes):
-        W, N = self.W[e_idx, nodes], self.N[e_idx, nodes]
-        q = W / N
-        q = q - q.min(dim=1, keepdim=True).values
-        q = q / q.sum(dim=1, keepdim=True)
-        bonus = self.p.C / N
-        if self.p.using_prior_for_exploration:
-            bonus = self.Qpi[e_idx, nodes] * bonus
-        return q + bonus
+    def _call(self, fn, *args):
+        e = self.model._ready()
+        e.check(fn(e.ctx, self._C.byref(self._tree), *args, e.stream()))
 
-    def select(self, active):
-        """tree policy for every active episode at once -> (path_nodes [E,D], path_actions [E,D], path_len [E], leaf [E]);
-        rows of inactive episodes are zeros"""
-        E = self.E
-        path_nodes = torch.zeros(E, self.max_depth, dtype=torch.long)
-        path_act = torch.zeros(E, self.max_depth, dtype=torch.long)
-        path_len = torch.zeros(E, dtype=torch.long)
-        cur = torch.zeros(E, dtype=torch.long)
-        live = active.clone()
-        d = 0
-        while bool(live.any()):
-            e_idx = self.ar[live]
-            a = torch.argmax(self._scores(e_idx, cur[e_idx]), dim=1)
-            path_nodes[e_idx, d] = cur[e_idx]
-            path_act[e_idx, d] = a
-            path_len[e_idx] = d + 1
-            nxt = self.child[e_idx, cur[e_idx], a]
-            cur[e_idx] = nxt
-            live = live.clone()
-            live[e_idx] = self.child[e_idx, nxt, 0] >= 0          # keep walking while the reached node has children
-            d += 1
-        return path_nodes, path_act, path_len, cur
+    @staticmethod
+    def _p(t):
+        import ctypes as C
+        return C.c_void_p(t.data_ptr())
 
-    def expand(self, nodes, mask):
-        """ONE engine call over E x pi_dim rows; tree bookkeeping only where mask[e]"""
-        m, E, A = self.model, self.E, self.pi_dim
-        s = self.S[self.ar_dev, nodes.to(self.S.device)].repeat_interleave(A, dim=0)
-        ro = self.ep0 * A
+    def _expand(self, nodes, mask, states_rep):
+        """ONE engine call over E x pi_dim rows (Node.expand, mcts.py:64-86); tree bookkeeping only where mask[e]"""
+        m, p_ = self.model, self._p
+        ro = self.ep0 * self.pi_dim
         if self.p.use_means:
-            G, _, ps_next, _ = m.calculate_G_mean(s, self.pi_hot, row_offset=ro)
+            G, _, ps_next, _ = m.calculate_G_mean(states_rep, self.pi_hot, row_offset=ro)
         else:
-            G, _, ps_next, _, _ = m.calculate_G(s, self.pi_hot, samples=getattr(self.p, 'samples', 1), row_offset=ro)
-        Gc = G.detach().to('cpu').reshape(E, A)
-        e_idx = self.ar[mask]
-        n = nodes[e_idx]
-        self.W[e_idx, n] -= Gc[e_idx]
-        self.N[e_idx, n] += 1.0
-        base = self.n_nodes[e_idx]
-        kids = base[:, None] + self.arA[None, :]
-        self.child[e_idx, n] = kids
-        dev = self.S.device
-        self.S[e_idx.to(dev)[:, None], kids.to(dev)] = ps_next.reshape(E, A, -1)[e_idx.to(dev)]
-        self.n_nodes[e_idx] = base + A
+            G, _, ps_next, _, _ = m.calculate_G(states_rep, self.pi_hot, samples=getattr(self.p, 'samples', 1), row_offset=ro)
+        G, ps_next = G.contiguous(), ps_next.contiguous()
+        self._call(m._engine.lib.efe_mcts_expand, p_(self.n_nodes), p_(nodes), p_(mask), p_(G), p_(ps_next))
 
-    def action_selection(self, e):
+    def action_selection(self, e, N=None, child=None):
+        N = self.N.cpu() if N is None else N
+        child = self.child.cpu() if child is None else child
         visited, node = [], 0
         while True:
-            a = int(torch.argmax(self.N[e, node]))
+            a = int(torch.argmax(N[e, node]))
             visited.append(a)
-            node = int(self.child[e, node, a])
-            if self.child[e, node, 0] < 0:
+            node = int(child[e, node, a])
+            if child[e, node, 0] < 0:
                 break
         return _trim_path(visited, self.pi_dim)
 
     def run(self, frames, o_shape=(64, 64, 1)):
-        # the tree statistics are tiny host tensors: one intra-op thread (torch's default pool = every core of the
-        # host, which turns each [E,4] reduction into a multi-millisecond fork/join on many-core boxes)
+        # the little host-side work left (habit shortcut, final path read-out) uses tiny tensors: one intra-op thread
         prev = torch.get_num_threads()
         torch.set_num_threads(1)
         try:
@@ -289,60 +274,55 @@ class BatchedMCTS:
             torch.set_num_threads(prev)
 
     def _run(self, frames, o_shape):
-        m, E, p = self.model, self.E, self.p
+        m, E, p, A, p_ = self.model, self.E, self.p, self.pi_dim, self._p
+        lib = m._engine.lib
         res = [None] * E
-        explored = torch.zeros(E, dtype=torch.long)
-        hist_paths, hist_G, hist_active = [], [], []          # per iteration: (path_act, path_len), G, active mask
         qs0_mean, _ = m.model_down.encoder(torch.as_tensor(frames).reshape(E, *o_shape), row_offset=self.ep0)
         self.S[:, 0] = qs0_mean
-        self.Qpi[:, 0] = m.model_top.encode_s(qs0_mean)[1].to('cpu')
-        active = torch.ones(E, dtype=torch.bool)
-        stop_at = torch.full((E,), -1, dtype=torch.long)
+        q_root = m.model_top.encode_s(qs0_mean)[1]
+        self.Qpi[:, 0] = q_root
+        active_h = torch.ones(E, dtype=torch.bool)
         if p.use_habit:
+            q_cpu = q_root.to('cpu')
             for e in range(E):
-                if calc_threshold(self.Qpi[e, 0], axis=0) > p.threshold:
-                    res[e] = ([int(torch.multinomial(self.Qpi[e, 0], 1))], 0, 0, [], [])
-                    active[e] = False
-        self.expand(torch.zeros(E, dtype=torch.long), active)
+                if calc_threshold(q_cpu[e], axis=0) > p.threshold:
+                    res[e] = ([int(torch.multinomial(q_cpu[e], 1))], 0, 0, [], [])
+                    active_h[e] = False
+        active = active_h.to(torch.uint8).to(m.device)
+        self._expand(torch.zeros(E, dtype=torch.int32, device=m.device), active, self.S[:, 0].repeat_interleave(A, dim=0).contiguous())
+        n_iter = 0
         for repeat in range(p.repeats):
-            rootN = self.N[:, 0]
-            dist = rootN / rootN.sum(dim=1, keepdim=True)
-            done = active & ((dist.max(dim=1).values - dist.mean(dim=1)) > p.threshold)
-            if bool(done.any()):
-                for e in self.ar[done].tolist():
-                    stop_at[e] = repeat
-                active = active & ~done
-            if not bool(active.any()):
+            self._call(lib.efe_mcts_stop, p_(active), p_(self.stop_at), repeat, float(p.threshold), p_(self.n_active))
+            if int(self.n_active.item()) == 0:          # the only host read of the iteration
                 break
-            path_nodes, path_act, path_len, leaves = self.select(active)
-            self.expand(leaves, active)
-            sims = torch.zeros(E, p.simulation_repeats)
-            leaf_states = self.S[self.ar_dev, leaves.to(self.S.device)]
-            e_idx = self.ar[active]
+            self._call(lib.efe_mcts_select, p_(active), float(p.C), 1 if p.using_prior_for_exploration else 0, self.max_depth,
+                       p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))
+            self._expand(self.leaf, active, self.leaf_rep)
+            q0 = None
             for r in range(p.simulation_repeats):
-                G, _, q0 = m.simulate_batch(leaf_states, p.simulation_depth, use_means=False, row_offset=self.ep0)
-                sims[:, r] = G.to('cpu')
-                self.Qpi[e_idx, leaves[e_idx]] = q0.to('cpu')[e_idx]
-            explored[e_idx] += p.simulation_depth * p.simulation_repeats
-            g = sims.mean(dim=1)
-            for d in range(int(path_len.max())):
-                sel = active & (path_len > d)
-                ei = self.ar[sel]
-                self.W[ei, path_nodes[ei, d], path_act[ei, d]] -= g[ei]
-                self.N[ei, path_nodes[ei, d], path_act[ei, d]] += 1
-            hist_paths.append((path_act, path_len)); hist_G.append(g); hist_active.append(active.clone())
+                G, _, q0 = m.simulate_batch(self.leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0)
+                self.sims[r].copy_(G)
+            self._call(lib.efe_mcts_backprop, p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(active),
+                       p_(self.sims), int(p.simulation_repeats), p_(q0.contiguous()), self.max_depth, p_(self.H_g[repeat]), p_(self.H_active[repeat]))
+            n_iter += 1
+        # read the history back once
+        H_act, H_len = self.H_act[:n_iter].cpu(), self.H_len[:n_iter].cpu()
+        H_g, H_active = self.H_g[:n_iter].cpu(), self.H_active[:n_iter].cpu().bool()
+        stop_at, N, child = self.stop_at.cpu(), self.N.cpu(), self.child.cpu()
         for e in range(E):
             if res[e] is not None:
                 continue
-            paths = [hist_paths[i][0][e, :int(hist_paths[i][1][e])].tolist() for i in range(len(hist_G)) if hist_active[i][e]]
-            Gs = [hist_G[i][e].item() for i in range(len(hist_G)) if hist_active[i][e]]
+            its = [i for i in range(n_iter) if H_active[i, e]]
+            paths = [H_act[i, e, :int(H_len[i, e])].tolist() for i in its]
+            Gs = [H_g[i, e].item() for i in its]
             reps = int(stop_at[e]) if stop_at[e] >= 0 else p.repeats
-            res[e] = (self.action_selection(e), reps, int(explored[e]), paths, Gs)
+            explored = len(its) * p.simulation_depth * p.simulation_repeats
+            res[e] = (self.action_selection(e, N, child), reps, explored, paths, Gs)
         return res
 
     def root_visit_distribution(self):
         """N / sum N at the roots, [E, pi_dim]: the policy-value that multi-GPU runs gather (mcts.py:177)"""
-        n = self.N[:, 0]
+        n = self.N[:, 0].cpu()
         return n / n.sum(dim=1, keepdim=True)
 
 

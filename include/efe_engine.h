@@ -122,6 +122,29 @@ int efe_env_step(efe_ctx*, float* state, float* last_r, const int32_t* actions, 
 int efe_env_render(efe_ctx*, const float* state, const float* last_r, const uint8_t* imgs, int64_t n_imgs, float* frames,
                    int32_t* err, int E, void* stream);
 
+/* ---- device-resident tree of the lock-step MCTS planner (counterpart of Node / active_inference_mcts, src/mcts.py:11-195) ----
+ * All pointers are device pointers owned by the caller.  tree = { W, N, Qpi [E][cap][A] floats, child [E][cap][A] int32
+ * (-1 = unexpanded), S [E][cap][s_dim] }.  One thread per episode; every formula in the reference's fp32 order with torch's
+ * NaN rules (an unvisited edge makes Q = 0/0).  No engine weights are involved.
+ *   efe_mcts_select  : tree policy (Node.select / probs_for_selection, :36-57) for every active episode: path_nodes / path_act
+ *                      [E][max_depth], path_len [E], leaf [E], the leaf's state [E][s_dim] and its A-fold repeat [E*A][s_dim]
+ *   efe_mcts_expand  : Node.expand bookkeeping (:64-86) where mask[e]: W[leaf] -= G, N[leaf] += 1, A children with states ps_next
+ *   efe_mcts_backprop: Qpi[leaf] = q0, g = mean_r sims[r][e], W -= g and N += 1 along the path (:91-99, 186-191);
+ *                      g_out [E] and active_out [E] are the iteration's history row
+ *   efe_mcts_stop    : early stop (:130-131, 176) active[e] &= !(max(N0/sum) - mean(N0/sum) > threshold), stop_at[e] = repeat
+ *                      for the episodes that stop now, *n_active = episodes still active */
+typedef struct efe_mcts_tree { float* W; float* N; float* Qpi; int32_t* child; float* S; int32_t E, cap, A, s_dim; } efe_mcts_tree;
+int efe_mcts_select(efe_ctx*, const efe_mcts_tree* tree, const uint8_t* active, float C, int use_prior, int max_depth,
+                    int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf, float* leaf_s, float* leaf_s_rep,
+                    void* stream);
+int efe_mcts_expand(efe_ctx*, const efe_mcts_tree* tree, int32_t* n_nodes, const int32_t* nodes, const uint8_t* mask, const float* G,
+                    const float* ps_next, void* stream);
+int efe_mcts_backprop(efe_ctx*, const efe_mcts_tree* tree, const int32_t* path_nodes, const int32_t* path_act, const int32_t* path_len,
+                      const int32_t* leaf, const uint8_t* active, const float* sims, int n_sims, const float* q0, int max_depth,
+                      float* g_out, uint8_t* active_out, void* stream);
+int efe_mcts_stop(efe_ctx*, const efe_mcts_tree* tree, uint8_t* active, int32_t* stop_at, int repeat, float threshold,
+                  int32_t* n_active, void* stream);
+
 /* introspection for benches: algorithmic MACs of the last EFE-level call. */
 int64_t efe_last_call_macs(efe_ctx*);
 
