@@ -493,3 +493,65 @@ def test_reparameterize_through_engine(models):
     ref = eps * np.exp(lv * np.float32(0.5)) + mean
     np.testing.assert_allclose(c(m.model_down.reparameterize(mean, lv, stage=3, eps=eps)), ref, rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(c(m.model_mid.reparameterize(mean, lv, stage=3)), ref, rtol=1e-4, atol=1e-5)   # device Box-Muller
+
+
+def test_mcts_tree_kernels_vs_host_torch(models):
+    """efe_mcts_select / efe_mcts_stop against the same formulas evaluated with torch on the host (the reference's
+    operation order, mcts.py:36-57, 130-131), on random trees that include unvisited edges (N = 0 -> inf / NaN scores)."""
+    import ctypes as C
+    from daimc_amd import _lib
+    m = models(1234, 1.15, 21)
+    e = m._ready()
+    E, A, cap, sd, depth = 37, 4, 21, 10, 6
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(E, cap, A, generator=g) * 3
+    N = torch.randint(0, 4, (E, cap, A), generator=g).float()
+    N[:, 0] = torch.randint(1, 6, (E, A), generator=g).float()          # roots are always visited
+    N[3, 0] = 0.0; W[3, 0] = 0.0                                        # one all-NaN root (0/0 everywhere)
+    Qpi = torch.rand(E, cap, A, generator=g)
+    child = torch.full((E, cap, A), -1, dtype=torch.int32)
+    for ep in range(E):                                                 # a random tree: node k expanded with prob. 0.6 while slots last
+        nxt = 1
+        for node in range(cap):
+            if node >= nxt:
+                break
+            if (node == 0 or torch.rand(1, generator=g).item() < 0.6) and nxt + A <= cap:
+                child[ep, node] = torch.arange(nxt, nxt + A, dtype=torch.int32)
+                nxt += A
+    S = torch.randn(E, cap, sd, generator=g)
+    active = (torch.rand(E, generator=g) < 0.8).to(torch.uint8)
+    dev = m.device
+    dW, dN, dQ, dC, dS, dA = (t.to(dev).contiguous() for t in (W, N, Qpi, child, S, active))
+    tree = _lib.EfeMctsTree(dW.data_ptr(), dN.data_ptr(), dQ.data_ptr(), dC.data_ptr(), dS.data_ptr(), E, cap, A, sd)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for use_prior in (0, 1):
+        pn = torch.zeros(E, depth, dtype=torch.int32, device=dev); pa = torch.zeros_like(pn)
+        pl = torch.zeros(E, dtype=torch.int32, device=dev); leaf = torch.zeros_like(pl)
+        ls = torch.zeros(E, sd, device=dev); lr = torch.zeros(E * A, sd, device=dev)
+        e.check(e.lib.efe_mcts_select(e.ctx, C.byref(tree), p(dA), 1.5, use_prior, depth, p(pn), p(pa), p(pl), p(leaf), p(ls), p(lr), e.stream()))
+        for ep in range(E):
+            cur, path = 0, []
+            if active[ep]:
+                while True:
+                    q = W[ep, cur] / N[ep, cur]
+                    q = q - q.min()
+                    q = q / q.sum()
+                    bonus = 1.5 / N[ep, cur]
+                    if use_prior:
+                        bonus = Qpi[ep, cur] * bonus
+                    a = int(torch.argmax(q + bonus))
+                    path.append((cur, a))
+                    cur = int(child[ep, cur, a])
+                    if child[ep, cur, 0] < 0:
+                        break
+            assert int(pl[ep]) == len(path) and int(leaf[ep]) == cur, (ep, use_prior)
+            assert [(int(pn[ep, d]), int(pa[ep, d])) for d in range(len(path))] == path, (ep, use_prior)
+            assert torch.equal(ls[ep].cpu(), S[ep, cur]) and torch.equal(lr[ep * A + A - 1].cpu(), S[ep, cur])
+    # early-stop test
+    stop_at = torch.full((E,), -1, dtype=torch.int32, device=dev); n_act = torch.zeros(1, dtype=torch.int32, device=dev)
+    act2 = dA.clone()
+    e.check(e.lib.efe_mcts_stop(e.ctx, C.byref(tree), p(act2), p(stop_at), 7, 0.2, p(n_act), e.stream()))
+    dist = N[:, 0] / N[:, 0].sum(dim=1, keepdim=True)
+    done = active.bool() & ((dist.max(dim=1).values - dist.mean(dim=1)) > 0.2)
+    assert torch.equal(act2.cpu().bool(), active.bool() & ~done)
+    assert torch.equal(stop_at.cpu() == 7, done) and int(n_act.item()) == int((active.bool() & ~done).sum())
