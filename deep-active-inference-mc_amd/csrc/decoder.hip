@@ -128,13 +128,20 @@ __global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) 
 #endif
 
         f32x16 acc[2][NTW];
+        // the accumulators start at the bias (register e of tile mt holds channel 32mt + (e&3) + 8(e>>2) + 4h) and ReLU is one
+        // integer max in the epilogue: each VALU instruction there costs ~19 cycles of wave time beside the other wave's MFMAs
+        auto acc_init = [&](int boff) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 bb = sm[DA_BIAS + boff + mt * 8 + 2 * g4 + h];
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) { acc[mt][nt][4 * g4] = bb.x; acc[mt][nt][4 * g4 + 1] = bb.y; acc[mt][nt][4 * g4 + 2] = bb.z; acc[mt][nt][4 * g4 + 3] = bb.w; }
+                }
+        };
         // ---------------- layer 1: out[oh,ow] = sum_{kh,kw} in[oh+1-kh, ow+1-kw] . W[:, :, kh, kw] --------------
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+        acc_init(0);
         tap_loop_pd<2, NTW, 1>(acc, 9, W1, sm, h, [&](int t, int (&bs)[NTW], int (&sw)[NTW], int& wt) {
             const int kh = t / 3, kw = t - kh * 3;
             wt = t;
@@ -160,10 +167,9 @@ __global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) 
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int c4 = mt * 8 + 2 * g4 + h;
-                    const float4 bb = sm[DA_BIAS + c4];
                     float4 v;
-                    v.x = fmaxf(acc[mt][nt][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[mt][nt][4 * g4 + 1] + bb.y, 0.f);
-                    v.z = fmaxf(acc[mt][nt][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[mt][nt][4 * g4 + 3] + bb.w, 0.f);
+                    v.x = relu_bits(acc[mt][nt][4 * g4 + 0]); v.y = relu_bits(acc[mt][nt][4 * g4 + 1]);
+                    v.z = relu_bits(acc[mt][nt][4 * g4 + 2]); v.w = relu_bits(acc[mt][nt][4 * g4 + 3]);
                     sm[swz(pix, c4)] = v;
                 }
         }
@@ -179,12 +185,7 @@ __global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) 
 #pragma unroll 1
         for (int par = 0; par < 4; ++par) {
             const int ph = par >> 1, pw = par & 1;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+            acc_init(16);
             tap_loop_pd<2, NTW, 1>(acc, (1 + ph) * (1 + pw), W2, sm, h, ConvT2Addr<NTW>{ph, pw, prow0, 2, pcol, 16, 16, 256}, ConvWIdx{});
             TL(5);
 #pragma unroll
@@ -197,11 +198,9 @@ __global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) 
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
-                        const int c4 = mt * 8 + 2 * g4 + h;
-                        const float4 bb = sm[DA_BIAS + 16 + c4];
                         float4 v;
-                        v.x = fmaxf(acc[mt][nt][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[mt][nt][4 * g4 + 1] + bb.y, 0.f);
-                        v.z = fmaxf(acc[mt][nt][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[mt][nt][4 * g4 + 3] + bb.w, 0.f);
+                        v.x = relu_bits(acc[mt][nt][4 * g4 + 0]); v.y = relu_bits(acc[mt][nt][4 * g4 + 1]);
+                        v.z = relu_bits(acc[mt][nt][4 * g4 + 2]); v.w = relu_bits(acc[mt][nt][4 * g4 + 3]);
 #ifdef EFE_X_NOSTORE          // timing experiment (wrong results): no y2 stores
                         keep += v.x + v.y + v.z + v.w;
 #else
