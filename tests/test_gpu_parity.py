@@ -327,6 +327,25 @@ def test_calculate_G_ten_samples_vs_oracle(models, weights_cache):
     np.testing.assert_allclose(c(po1), opo1.numpy(), rtol=1e-5, atol=1e-5)
 
 
+def test_calculate_G_many_rows_vs_oracle(models, weights_cache):
+    """M = 150, S = 4: 1800 decoder images (k_dec_a ticket queue), 600 encoder images (more than the persistent encoder
+    workgroups) and 1200 transition rows in one call, against the oracle."""
+    seed, st, M, S = 37, 6, 150, 4
+    w = weights_cache(1234, 1.15)
+    m = models(1234, 1.15, seed)
+    orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
+    s0 = PX.uniform_fill(8, (M, 10), 904, -1.0, 1.0)
+    pi0 = np.eye(4, dtype=np.float32)[np.arange(M) % 4]
+    with torch.no_grad():
+        oG, oT, ops1, ops1m, opo1 = orc.calculate_G(torch.from_numpy(s0), torch.from_numpy(pi0), S, st)
+    G, terms, ps1, ps1m, po1 = m.calculate_G(s0, pi0, samples=S, stage=st, eps=eps_calcG(seed, M, S, st))
+    np.testing.assert_allclose(c(terms[0]), oT[0].numpy(), atol=1e-3)
+    np.testing.assert_allclose(c(terms[1]), oT[1].numpy(), atol=1e-3)
+    np.testing.assert_allclose(c(G), oG.numpy(), atol=gtol(orc.last_term2_parts[0].numpy()))
+    np.testing.assert_allclose(c(po1), opo1.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c(ps1), ops1.numpy(), rtol=1e-5, atol=2e-6)
+
+
 def test_decoder_encoder_tile_tails_vs_oracle(models, weights_cache):
     """M = 257 rows: exercises the 64-row tiles of the dense kernels and the persistent image loops with a ragged tail"""
     seed, st, M = 41, 9, 257
@@ -343,6 +362,22 @@ def test_decoder_encoder_tile_tails_vs_oracle(models, weights_cache):
     # gain 1.35 drives hidden activations to O(10): fp32 summation-order noise is ~1e-6 * that
     np.testing.assert_allclose(c(mean), omean.numpy(), rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(c(lv), olv.numpy(), rtol=1e-5, atol=2e-5)
+
+
+def test_decoder_many_rows_vs_oracle(models, weights_cache):
+    """M = 1100 rows: more images than persistent workgroup slots, so k_dec_a claims images from its ticket counter and the
+    persistent k_fc4 ranges cross row tiles -- the paths the throughput bench runs, checked against the oracle."""
+    seed, st, M = 43, 4, 1100
+    w = weights_cache(1234, 1.15)
+    m = models(1234, 1.15, seed)
+    orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
+    s = PX.uniform_fill(9, (M, 10), 903, -1.5, 1.5)
+    with torch.no_grad():
+        opo = orc.decoder(torch.from_numpy(s), PX.PASS_D2A, 1, st)
+    po = m.model_down.decoder(s, stage=st, pass_=PX.PASS_D2A, sample=1)
+    np.testing.assert_allclose(c(po), opo.numpy(), rtol=1e-5, atol=1e-5)
+    po2 = m.model_down.decoder(s, stage=st, pass_=PX.PASS_D2A, sample=1)
+    assert torch.equal(po, po2)          # the dynamic image schedule does not change any bit
 
 
 def test_given_trajectory_vs_oracle(models, weights_cache):
