@@ -225,14 +225,16 @@ __global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) 
 #endif
 }
 
+constexpr size_t DA_LDS_BYTES = (257 * 16 + 33) * sizeof(float4);
+// kernels that need more than the default 64 KiB of dynamic LDS: set once per device (called from efe_create)
+int init_decoder_kernels() {
+    if (hipFuncSetAttribute((const void*)(k_dec_a<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)(k_dec_a<1>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES) != hipSuccess) return 1;
+    return 0;
+}
+
 void launch_dec_a(const DecAArgs& a, hipStream_t st) {
-    static bool once = false;
-    const size_t lds = (257 * 16 + 33) * sizeof(float4);
-    if (!once) {
-        (void)hipFuncSetAttribute((const void*)(k_dec_a<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void*)(k_dec_a<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        once = true;
-    }
+    const size_t lds = DA_LDS_BYTES;
     const int grid = a.rows < 512 ? a.rows : 512;         // persistent: 2 workgroups per CU
     // default: four waves of 64 features x 64 pixels (0.872 of the fp32 MFMA peak alone, 19200 images).  dbg bit 2: eight waves of
     // 64 x 32 (0.881 alone, no gain inside the rollout; kept for A/B)

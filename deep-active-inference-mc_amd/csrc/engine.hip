@@ -367,6 +367,7 @@ int efe_create(efe_ctx** out, int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return 2;
     if (hipSetDevice(device) != hipSuccess) return 3;
+    if (init_small_kernels() || init_decoder_kernels()) return 5;       // per device: a second context on another GPU needs them too
     efe_ctx* ctx = new efe_ctx();
     ctx->device = device;
     if (hipMalloc((void**)&ctx->zeros, 8192) != hipSuccess || hipMemset(ctx->zeros, 0, 8192) != hipSuccess) { delete ctx; return 4; }

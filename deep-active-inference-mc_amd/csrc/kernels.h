@@ -129,6 +129,8 @@ struct TermsArgs {
     float* t2parts;        // nullable [2][R]: term2_1, term2_2 (last stage; diagnostics)
 };
 void launch_terms(const TermsArgs& a, hipStream_t st);
+int init_small_kernels();       // per-device kernel attributes (dynamic LDS above 64 KiB); 0 = ok
+int init_decoder_kernels();
 
 // ---- device-resident MCTS tree (mcts.hip) --------------------------------------------------------
 struct MctsTree {

@@ -297,13 +297,15 @@ __global__ void __launch_bounds__(256) k_terms(const TermsArgs a) {
     }
 }
 
+int init_small_kernels() {      // per device, from efe_create: k_terms<1> may use up to the whole LDS
+    return hipFuncSetAttribute((const void*)(k_terms<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess;
+}
+
 void launch_terms(const TermsArgs& a, hipStream_t st) {
     auto bytes = [&](int rb) { return ((size_t)a.D * a.S * rb * 4 + (size_t)a.D * rb * 6) * sizeof(float); };
     if (bytes(4) <= 48 * 1024) {
         hipLaunchKernelGGL(k_terms<4>, dim3((a.R + 3) / 4), dim3(256), bytes(4), st, a);
     } else {                     // very deep / many-sample calls: one row per workgroup, LDS limit raised (D*S up to ~9000)
-        static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute((const void*)(k_terms<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); once = true; }
         hipLaunchKernelGGL(k_terms<1>, dim3(a.R), dim3(256), bytes(1), st, a);
     }
 }

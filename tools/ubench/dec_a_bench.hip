@@ -31,6 +31,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, w2, wn, 0.05f, lowent, 0u);
     hipLaunchKernelGGL(k_fill, dim3(1), dim3(128), 0, 0, b, (size_t)128, 0.01f, lowent, 0u);
     int* queue; hipMalloc(&queue, 4);
+    init_decoder_kernels();
     DecAArgs a{};
     a.queue = queue;
     a.x4 = x; a.y2 = y; a.w1 = w1; a.b1 = b; a.w2 = w2; a.b2 = b + 64; a.rows = rows; a.dbg = dbg; a.tl = nullptr;
