@@ -17,11 +17,11 @@ def main(d):
     out = []
     ks = glob.glob(os.path.join(d, 'kt', '**', '*kernel_stats.csv'), recursive=True)
     if ks:
-        out.append('== rocprofv3 --kernel-trace --stats (bench.py --steps 2 --warmup 1) ==')
-        out.append(f'{"kernel":62s} {"calls":>6s} {"total_us":>12s} {"avg_us":>10s} {"pct":>6s}')
+        out.append('== rocprofv3 --kernel-trace --stats (the default bench command: bench.py --steps 5 --warmup 2; the first call of a kernel is cold) ==')
+        out.append(f'{"kernel":62s} {"calls":>6s} {"total_us":>12s} {"avg_us":>10s} {"min_us":>10s} {"pct":>6s}')
         for r in csv.DictReader(open(ks[0])):
             out.append(f'{short(r["Name"]):62s} {r["Calls"]:>6s} {float(r["TotalDurationNs"]) / 1e3:12.1f} '
-                       f'{float(r["AverageNs"]) / 1e3:10.1f} {float(r["Percentage"]):6.2f}')
+                       f'{float(r["AverageNs"]) / 1e3:10.1f} {float(r["MinNs"]) / 1e3:10.1f} {float(r["Percentage"]):6.2f}')
     for sub in ('pmc_sq', 'pmc_mem', 'pmc_fetch', 'pmc_write'):
         cs = glob.glob(os.path.join(d, sub, '**', '*counter_collection.csv'), recursive=True)
         if not cs:
