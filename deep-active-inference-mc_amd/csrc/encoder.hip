@@ -8,25 +8,29 @@
 //   as broadcast LDS reads).  conv2..4 are MFMA tap contractions (v_mfma_f32_32x32x2_f32) over swizzled LDS images.
 #include "mfma_pipe.h"
 
+#ifndef EFE_ENC_WAVES
+#define EFE_ENC_WAVES 3      // waves per SIMD = workgroups per CU (47 KiB LDS, <= 168 VGPRs)
+#endif
+
 namespace efe {
 
 constexpr int EN_IMG = 0;                      // [64][64] input image                       (floats)
 constexpr int EN_C2 = 4096;                    // [225 px][32 ch] conv2 output, 8 quads/pixel, quad ^= px & 7
-constexpr int EN_C3 = EN_C2 + 225 * 32;        // [49 px][64 ch] conv3 output, 16 quads/pixel, quad ^= px & 15
-constexpr int EN_W1 = EN_C3 + 49 * 64;         // conv1 weights [9 taps][32 ch] + bias [32]
+constexpr int EN_C3 = EN_IMG;                  // [49 px][64 ch] conv3 output, 16 quads/pixel, quad ^= px & 15: aliases the input image
+                                               // (dead once conv2 is done); 3136 <= 4096 floats
+constexpr int EN_W1 = EN_C2 + 225 * 32;        // conv1 weights [9 taps][32 ch] + bias [32]
 constexpr int EN_B2 = EN_W1 + 320;             // conv2 / conv3 / conv4 biases [32] [64] [64]: read in the epilogues from LDS (a global
 constexpr int EN_B3 = EN_B2 + 32;              // load there exposes an L2 round trip per phase and image)
 constexpr int EN_B4 = EN_B3 + 64;
-constexpr int EN_END = EN_B4 + 64;             // 14912 floats = 59648 B
-constexpr int EN_RED = EN_IMG;                 // conv4 split-K partials alias the (dead) input image
+constexpr int EN_END = EN_B4 + 64;             // 11776 floats = 47104 B: three workgroups per CU
+constexpr int EN_RED = EN_C2;                  // conv4 split-K partials alias the (dead) conv2 output
 
-__global__ void __launch_bounds__(256, 2) k_enc_trunk(const EncArgs a) {
+__global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
     float4* sm4 = reinterpret_cast<float4*>(smf);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
 
     // conv1 weights + bias live in LDS ([tap][32 ch] so a lane's 4 channels of a chunk are one broadcast ds_read_b128)
     for (int i = tid; i < 320; i += 256) smf[EN_W1 + i] = (i < 288) ? a.w1[i] : a.b1[i - 288];
@@ -37,6 +41,9 @@ __global__ void __launch_bounds__(256, 2) k_enc_trunk(const EncArgs a) {
     const float4* W4 = reinterpret_cast<const float4*>(a.w4);             // [9][2][8][64]
 
     for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
+        // lane index laundered per image: hoisted out of the image loop, the per-phase LDS addresses derived from it are ~20 spilled VGPRs
+        int ll = lane; asm volatile("" : "+v"(ll));
+        const int j = ll & 31, h = ll >> 5;
         {   // stage the image (16 KiB)
             const f32x4* X = reinterpret_cast<const f32x4*>(a.o) + (size_t)img * 1024;
             f32x4* d = reinterpret_cast<f32x4*>(smf + EN_IMG);
@@ -192,12 +199,13 @@ __global__ void __launch_bounds__(256, 2) k_enc_trunk(const EncArgs a) {
                 }
             }
         }
-        __syncthreads();        // the input image buffer (aliased by the partials) is free for the next image
+        __syncthreads();        // conv3's output (aliasing the input image buffer) is consumed: the next image may be staged
     }
 }
 
 void launch_enc_trunk(const EncArgs& a, hipStream_t st) {
-    const int grid = a.rows < 512 ? a.rows : 512;
+    const int slots = 256 * EFE_ENC_WAVES;
+    const int grid = a.rows < slots ? a.rows : slots;
     hipLaunchKernelGGL(k_enc_trunk, dim3(grid), dim3(256), EN_END * sizeof(float), st, a);
 }
 
