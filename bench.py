@@ -1,18 +1,27 @@
 #!/usr/bin/env python
 """EFE rollouts/sec on MI355X (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch of synthetic input: calculate_G_repeated over 128
-rows (32 root frames x 4 actions) with 10 MC samples and depth 5 (BASELINE configs[1]), followed by
-the action posterior; at N > 1 every rank runs its own 128 rows (episodes shard with no data-path
-collective, weak scaling) and one all_gather of the [32,4] action posteriors per step is the only RCCL
-traffic.  Inputs are resident in HBM before the timed region.
+A "step" = one pass of the hot path over one batch of synthetic input: `calculate_G_repeated` over R rows (R/4 root frames
+x 4 actions) with 10 MC samples and depth 5, followed by the action posterior.
+  * N = 1: R = 128 (BASELINE configs[1], the configuration the metric is quoted on).
+  * N > 1: every rank runs 64 episodes = 256 rows (BASELINE configs[3]: 512 episodes over 8 GPUs); episodes shard with no
+    data-path collective (weak scaling) and ONE all_gather of the [64, 4] action posteriors per step is the only RCCL traffic.
+Inputs are resident in HBM before the timed region.  The timed region is exactly K steps between barrier + synchronize
+pairs; it is REPEATED (same K) until about 2.5 s of GPU time have been measured, and `ms_per_step` / `value` come from the
+median region (all region times are in the JSON), so the run is long enough to be observed from outside.
 
-  python bench.py --gpus 1 --steps 5 --warmup 2
+At N = 1 the same JSON line carries, under "extras", the second BASELINE configuration (configs[2]: full lock-step MCTS,
+64 episodes x 50 expansions x 10 samples, simulation depth 5) with its own roofline and CPU baseline.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import glob
 import json
 import os
+import re
+import statistics
 import sys
 import time
 
@@ -22,12 +31,24 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MAC_TRANS, MAC_DEC, MAC_ENC, MAC_HABIT = 541_696, 43_256_320, 3_868_960, 18_176      # per network row
 MAC_ROLLOUT = 6_739_934_560          # 51 encoder + 100 transition + 150 decoder passes
 MAC_DECB_ROW = 18_874_368 + 1_179_648   # k_dec_b: ConvTranspose2d(64,32,3,s2) 32*32*9*64*32 + ConvTranspose2d(32,1,3,s1) 64*64*9*32
 PEAK_FP32_MFMA_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, fp32 in / fp32 acc
-CLASS_MACS_PER_ROW = {               # algorithmic MACs per network row, by kernel class
-    'dec_dense_16384': 256 * 16384, 'dec_a_convT1_convT2': 2 * 256 * 9 * 64 * 64, 'dec_b_convT3_final_reduce': MAC_DECB_ROW,
-}
+DOM = 'dec_b_convT3_final_reduce'
+
+
+def class_macs_per_step(R, D, S):
+    """algorithmic MACs of one rollout step, by kernel class (rows of each network x MACs per row)"""
+    dec_rows, enc_rows, tr_rows = D * 3 * S * R, D * S * R + R, D * 2 * S * R
+    return {
+        'transition_mlp': tr_rows * MAC_TRANS,
+        'dec_dense_small': dec_rows * (10 * 256 + 2 * 256 * 256),
+        'dec_dense_16384': dec_rows * 256 * 16384,
+        'dec_a_convT1_convT2': dec_rows * 2 * 256 * 9 * 64 * 64,
+        DOM: dec_rows * MAC_DECB_ROW,
+        'encoder': enc_rows * MAC_ENC,
+    }
 
 
 def synth_frames(n, device, seed=0):
@@ -59,13 +80,23 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(depth, samples, target_s=12.0):
-    """The oracle (CPU restatement of the reference's own torch op sequence, torch RNG like the reference)
-    timed on this host's cores on a bounded sample of the same workload."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(depth, samples, budget_s=14.0):
+    """The oracle (CPU restatement of the reference's own torch op sequence, torch RNG like the reference) timed on this
+    host's cores on a bounded sample of the same workload: >= 3 timed repeats on all usable cores (median + spread) and one
+    1-thread figure.  BASELINE.md section 4 records the restatement-vs-reference time cross-check."""
     from oracle import synth
     from oracle.efe_oracle import OracleModel, TorchNoise
     cores = usable_cores()
-    torch.set_num_threads(cores)
     m = OracleModel(synth.make_weights(1234, 1.15), TorchNoise())
 
     def run(rows, d, s):
@@ -75,77 +106,164 @@ def cpu_baseline(depth, samples, target_s=12.0):
         with torch.no_grad():
             m.calculate_G_repeated(o, pi, d, False, s, 0)
         return time.perf_counter() - t
+
+    torch.set_num_threads(cores)
     run(4, 1, 1)                                   # warm-up (thread pools, oneDNN primitives)
     t_unit = run(8, 1, 1)                          # 8 rows x 1 stage x 1 sample
     per_row_full = t_unit / 8 * depth * samples    # estimated seconds per full rollout row
-    rows = int(min(128, max(4, target_s / max(per_row_full, 1e-4))))
+    reps = 3
+    rows = int(min(128, max(4, budget_s / reps / max(per_row_full, 1e-4))))
     rows -= rows % 4
-    print(f'[bench] cpu_baseline: {cores} threads, unit pass {t_unit:.3f}s, timing {rows} rows', file=sys.stderr, flush=True)
-    dt = run(rows, depth, samples)
-    return {'value': rows / dt, 'unit': 'rollouts/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{rows} rows x depth {depth} x {samples} MC samples, 1 timed pass after warm-up, torch-CPU eager '
-                      f'oracle (oracle/efe_oracle.py, torch RNG like the reference), {dt:.2f} s'}
+    print(f'[bench] cpu_baseline: {cores} threads, unit pass {t_unit:.3f}s, timing {reps} x {rows} rows', file=sys.stderr, flush=True)
+    times = [run(rows, depth, samples) for _ in range(reps)]
+    rates = sorted(rows / t for t in times)
+    torch.set_num_threads(1)
+    t1 = run(4, depth, samples)                    # one root (4 rows) on ONE thread
+    torch.set_num_threads(cores)
+    return {'value': statistics.median(rates), 'unit': 'rollouts/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
+            'repeats': reps, 'min': rates[0], 'max': rates[-1], 'one_thread_value': 4 / t1,
+            'sample': f'{reps} timed passes of {rows} rows x depth {depth} x {samples} MC samples after warm-up (median; '
+                      f'{sum(times):.1f} s), plus 4 rows on 1 thread ({t1:.1f} s); torch-CPU eager oracle '
+                      f'(oracle/efe_oracle.py, torch RNG like the reference)'}
 
 
-def bench_mcts(a, model, device, world, rank, dist):
+def mcts_flops_per_decision(samples, repeats=50, depth=5):
+    """algorithmic FLOPs of one planning decision: (repeats + 1) expansions of 4 rows x calculate_G(S) + repeats simulations
+    (depth habit + transition steps, then a depth-row single-sample trajectory G) -- SURVEY 8a-12"""
+    g_row = samples * (2 * MAC_TRANS + 3 * MAC_DEC + MAC_ENC)
+    sim = depth * (MAC_HABIT + MAC_TRANS) + depth * (MAC_TRANS + 3 * MAC_DEC + MAC_ENC)
+    return 2.0 * ((repeats + 1) * 4 * g_row + repeats * sim)
+
+
+def cpu_baseline_mcts(samples, depth=5, repeats_sample=3):
+    """BASELINE configs[2] on the CPU as the reference would run it: ONE episode at a time through the oracle planner
+    (oracle/mcts_oracle.py), torch RNG.  Bounded sample: `repeats_sample` planner iterations (+ the root expansion) instead
+    of 50; decisions/s is extrapolated by algorithmic FLOPs (every iteration costs the same)."""
+    from oracle import synth
+    from oracle import mcts_oracle as MO
+    from oracle.efe_oracle import OracleModel, TorchNoise
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    m = OracleModel(synth.make_weights(1234, 1.15), TorchNoise())
+    p = MO.Params(repeats=repeats_sample, simulation_depth=depth, use_means=False, threshold=2.0, samples=samples)
+    frame = torch.from_numpy(synth.make_frames(6, 1)[0])
+    MO.plan(m, frame, MO.Params(repeats=1, simulation_depth=2, use_means=False, threshold=2.0, samples=1), 0)     # warm-up
+    t = time.perf_counter()
+    MO.plan(m, frame, p, 0)
+    dt = time.perf_counter() - t
+    frac = mcts_flops_per_decision(samples, repeats_sample, depth) / mcts_flops_per_decision(samples, 50, depth)
+    return {'value': frac / dt, 'unit': 'decisions/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
+            'sample': f'one episode, {repeats_sample} of 50 planner iterations (+ root expansion), {samples} MC samples, simulation depth {depth}: '
+                      f'{dt:.1f} s, extrapolated to a full decision by algorithmic FLOPs (x{1 / frac:.1f}); sequential single-episode '
+                      f'oracle planner (oracle/mcts_oracle.py over oracle/efe_oracle.py), torch RNG like the reference'}
+
+
+def natural_key(path):
+    return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.basename(path))]
+
+
+def committed_traffic(kernel='k_dec_b'):
+    """HBM bytes per image of the dominant kernel from the newest committed PMC profile (profiles/rN_vM_rocprof_summary.txt,
+    newest = highest (round, version) in natural order).  -> (bytes_per_image, file name) or (None, None)"""
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_v*_rocprof_summary.txt')), key=natural_key)
+    for best in reversed(files):
+        m_ = re.search(r'== HBM traffic \(JSON\) ==\n(\{.*\})', open(best).read())
+        if not m_:
+            continue
+        tj = json.loads(m_.group(1)).get(kernel)
+        if tj:
+            return tj['hbm_read_bytes_per_image'] + tj['hbm_write_bytes_per_image'], os.path.basename(best)
+    return None, None
+
+
+def timed_regions(step, steps, k0, sync, min_total_s=2.5, max_regions=40):
+    """time EXACTLY `steps` steps between sync() pairs; repeat the region until min_total_s of measured time.
+    -> (list of region seconds (max over ranks is taken by the caller), next step index)"""
+    out, k = [], k0
+    while True:
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(k); k += 1
+        sync()
+        out.append(time.perf_counter() - t0)
+        if sum(out) >= min_total_s or len(out) >= max_regions:
+            return out, k
+
+
+def bench_mcts(a, model, device, world, rank, dist, steps, warmup, with_cpu):
     """BASELINE configs[2]/[3]: E episodes per GPU, each a full MCTS decision (50 expansions with S MC samples,
-    simulation depth 5, use_means=False, early stop disabled), planned in lock-step; the root visit distributions
-    are gathered across ranks.  One decision ~ 51 expansions x 4 rows x 2.694 GFLOP + 50 x 1.35 GFLOP ~ 617 GFLOP."""
+    simulation depth 5, use_means=False, early stop disabled so every episode does all 50), planned in lock-step; the root
+    visit distributions are gathered across ranks."""
     import daimc_amd
     E = a.episodes
     p = daimc_amd.MCTS_Params()
     p.repeats, p.simulation_depth, p.use_means, p.threshold, p.samples = 50, 5, False, 2.0, a.samples
     frames = synth_frames(E, device, seed=200 + rank)
 
-    def step():
+    def step(_k):
         out, distn = daimc_amd.active_inference_mcts_batch(model, frames, p, o_shape=(1, 64, 64), episode_offset=rank * E)
         if world > 1:
             daimc_amd.gather_action_posteriors(distn.to(device), world * E)
         return out
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    for k in range(warmup):
+        step(k)
+    model.prof_enable(True, classes=[DOM])
+    regions, _ = timed_regions(step, steps, 0, sync, min_total_s=1.5, max_regions=6)
+    ms_dom, n_dom = model.prof_read()[DOM]
+    model.prof_enable(False)
     if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor(regions, device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
-        dec = world * E * a.steps / dt
-        gflop_dec = (51 * 4 * a.samples * 134_721_312 * 2 + 50 * (5 * (18_176 + 541_696) + 5 * 134_179_616) * 2) / 1e9
-        print(json.dumps({'metric': 'MCTS decisions/sec (50 expansions, %d MC samples, sim depth 5)' % a.samples, 'value': dec,
-                          'unit': 'decisions/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
-                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                          'config': {'workload': f'lock-step MCTS, {E} episodes per GPU (BASELINE configs[2])', 'episodes_per_gpu': E},
-                          'rollout_equivalents_per_s': dec * gflop_dec / 13.480, 'achieved_tflops_total': dec * gflop_dec / 1e3}))
-    if world > 1:
-        dist.destroy_process_group()
+        regions = [float(x) for x in t]
+    dt = statistics.median(regions)
+    dec = world * E * steps / dt
+    fl = mcts_flops_per_decision(a.samples)
+    out = {'metric': 'MCTS decisions/sec (50 expansions, %d MC samples, sim depth 5)' % a.samples, 'value': dec,
+           'unit': 'decisions/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * dt / steps,
+           'timed_regions': len(regions), 'region_ms': [round(1e3 * x, 3) for x in regions],
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': f'lock-step MCTS, {E} episodes per GPU x 50 expansions x {a.samples} MC samples, simulation depth 5 '
+                                  f'(BASELINE configs[2])', 'episodes_per_gpu': E},
+           'gflop_per_decision': fl / 1e9, 'rollout_equivalents_per_s': dec * fl / (2 * MAC_ROLLOUT),
+           'achieved_tflops_total': dec * fl / 1e12}
+    # whole-workload roofline (the planner is many launches; its dominant kernel is the same k_dec_b) + the dominant kernel alone
+    n_img = len(regions) * steps * 51 * 3 * a.samples * 4 * E + len(regions) * steps * 50 * 3 * 5 * E     # decoder images in the timed regions
+    ach_dom = 2 * MAC_DECB_ROW * n_img / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
+    out['roofline'] = {'bound': 'mfma', 'kernel': 'whole decision (all kernels); k_dec_b alone under "dominant"',
+                       'achieved': dec * fl / 1e12 / world, 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s',
+                       'frac': dec * fl / 1e12 / world / PEAK_FP32_MFMA_TF, 'traffic': None,
+                       'dominant': {'kernel': 'k_dec_b', 'achieved': ach_dom, 'frac': ach_dom / PEAK_FP32_MFMA_TF, 'launches': int(n_dom),
+                                    'avg_launch_ms': ms_dom / max(n_dom, 1)}}
+    if with_cpu:
+        out['cpu_baseline'] = cpu_baseline_mcts(a.samples)
+        out['speedup_vs_cpu_baseline'] = dec / out['cpu_baseline']['value']
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--rows', type=int, default=128)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--rows', type=int, default=0, help='rollout rows per GPU (default: 128 at N = 1 = BASELINE configs[1]; 256 = 64 episodes at N > 1 = configs[3])')
     ap.add_argument('--samples', type=int, default=10)
     ap.add_argument('--depth', type=int, default=5)
     ap.add_argument('--dec-chunk', type=int, default=0)
     ap.add_argument('--opt', action='append', default=[], help='engine option name=value')
     ap.add_argument('--workload', default='rollout', choices=['rollout', 'mcts'],
-                    help="'mcts' = BASELINE configs[2]: full lock-step MCTS (50 expansions, 10 samples, sim depth 5) over 64 episodes/GPU (secondary metric)")
+                    help="'mcts' = only BASELINE configs[2]: full lock-step MCTS (50 expansions, 10 samples, sim depth 5) over 64 episodes/GPU")
     ap.add_argument('--episodes', type=int, default=64)
     ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path on a 1-GPU box')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-prof', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the configs[2] (MCTS) leg of the default N = 1 run')
+    ap.add_argument('--single-region', action='store_true', help='time the K steps once (no repeats)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -165,7 +283,8 @@ def main():
     torch.cuda.set_device(device)
 
     import daimc_amd
-    R, S, D = a.rows, a.samples, a.depth
+    R = a.rows or (128 if world == 1 else 256)
+    S, D = a.samples, a.depth
     model = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device=device, seed=1, row_offset=rank * R)
     if a.dec_chunk:
         model.set_option('dec_chunk', a.dec_chunk)
@@ -173,7 +292,13 @@ def main():
         k_, v_ = kv.split('=')
         model.set_option(k_, int(v_))
     if a.workload == 'mcts':
-        return bench_mcts(a, model, device, world, rank, dist)
+        out = bench_mcts(a, model, device, world, rank, dist, max(1, min(a.steps, 3)), max(1, min(a.warmup, 1)), world == 1 and not a.no_cpu)
+        if rank == 0:
+            print(json.dumps(out))
+        if use_dist:
+            dist.destroy_process_group()
+        return
+    model.reserve(R, D, S)                                       # steady-state steps never hipMalloc
     frames = synth_frames(R // 4, device, seed=100 + rank)
     o = frames.repeat_interleave(4, dim=0).contiguous()          # row 4i+a = (root i, action a), util.py:56-60
     pi = torch.eye(4, device=device).repeat(R // 4, 1).contiguous()
@@ -185,32 +310,30 @@ def main():
             daimc_amd.gather_action_posteriors(P, world * (R // 4))      # the only RCCL traffic: [R/4, 4] floats per rank
         return G
 
+    def sync():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+
     print(f'[bench] rank {rank}: model ready, warm-up', file=sys.stderr, flush=True)
     for k in range(a.warmup):
         step(k)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    DOM = 'dec_b_convT3_final_reduce'
+    sync()
+    grows0 = model.arena_stats()['grow_count']
     if not a.no_prof:
-        model.prof_enable(True, classes=[DOM])     # HIP events around the dominant kernel only (3 launches per step)
+        model.prof_enable(True, classes=[DOM])     # HIP events around the dominant kernel only (one launch per step)
+    regions, kk = timed_regions(step, a.steps, a.warmup, sync, min_total_s=0.0 if a.single_region else 2.5)
+    G = step(kk); kk += 1
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        G = step(a.warmup + k)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    print(f'[bench] rank {rank}: timed region {dt:.3f}s', file=sys.stderr, flush=True)
+    print(f'[bench] rank {rank}: {len(regions)} timed regions of {a.steps} steps, {sum(regions):.3f}s', file=sys.stderr, flush=True)
     assert torch.isfinite(G).all()
+    assert model.arena_stats()['grow_count'] == grows0, 'the scratch arena grew inside the timed region'
     prof = model.prof_read() if not a.no_prof else {}
     breakdown = {}
-    NB = 2
+    NB = 3
     if not a.no_prof:
         # per-class breakdown from extra, un-timed steps, ONE class at a time: event pairs around every launch of a step slow
         # all of its kernels down by ~10 % (the sum no longer matched ms_per_step)
-        kk = a.warmup + a.steps
         for c in model.PROF_CLASSES:
             if c.startswith('unused'):
                 continue
@@ -221,54 +344,60 @@ def main():
             breakdown[c] = (ms / NB, n // NB)
     model.prof_enable(False)
     if use_dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor(regions, device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # per region: the slowest rank
+        regions = [float(x) for x in t]
+    dt = statistics.median(regions)
 
+    out = None
     if rank == 0:
         value = world * R * a.steps / dt
+        cfg = 'BASELINE configs[1]' if (world == 1 and R == 128) else ('BASELINE configs[3]: 64 episodes per GPU' if R == 256 else 'custom size')
         out = {
             'metric': 'EFE rollouts/sec (64x64 dSprites, 10 MC-samples, depth 5)', 'value': value, 'unit': 'rollouts/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'calculate_G_repeated: {R} rows ({R // 4} roots x 4 actions) x depth {D} x {S} MC samples per GPU '
-                                   f'(BASELINE configs[1]) + action posterior' + (' + all_gather of posteriors' if world > 1 else ''),
+                                   f'({cfg}) + action posterior' + (' + all_gather of posteriors' if use_dist else ''),
                        'rows_per_gpu': R, 'samples': S, 'depth': D, 'parallelism': f'episodes sharded x{world}, weights replicated'},
+            'timed_regions': len(regions), 'region_ms': [round(1e3 * x, 3) for x in regions],
+            'ms_per_step_min': 1e3 * min(regions) / a.steps, 'ms_per_step_max': 1e3 * max(regions) / a.steps,
             'achieved_tflops_total': value * 2 * MAC_ROLLOUT / 1e12,
+            'frac_of_fp32_mfma_peak_whole_step': value * 2 * MAC_ROLLOUT / 1e12 / world / PEAK_FP32_MFMA_TF,
         }
         if prof:
-            name = 'dec_b_convT3_final_reduce'
-            ms, n = prof[name]
-            rows_per_launch = (a.steps * D * 3 * S * R) / max(n, 1)
+            ms, n = prof[DOM]
+            rows_per_launch = D * 3 * S * R                      # one k_dec_b launch per step (dec_chunk >= rows)
+            launches_per_step = n / max(1, (len(regions) * a.steps + 1))
+            rows_per_launch /= max(launches_per_step, 1)
             ach = (2 * MAC_DECB_ROW * rows_per_launch) / (ms / max(n, 1) * 1e-3) / 1e12 if ms > 0 else 0.0
             out['roofline'] = {'bound': 'mfma', 'kernel': 'k_dec_b (ConvTranspose2d 64->32 s2 + ConvTranspose2d 32->1 + sigmoid + per-image reduction, fused)',
                                'achieved': ach, 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TF,
                                'traffic': None, 'launches': int(n), 'avg_launch_ms': ms / max(n, 1),
                                'flops_per_launch': 2 * MAC_DECB_ROW * rows_per_launch}
-            # HBM bytes of the dominant kernel from the committed PMC profile (tools/gpu_profile.sh -> profiles/*_summary.txt)
-            try:
-                import glob
-                import re
-                best = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*rocprof_summary.txt')))[-1]
-                m_ = re.search(r'== HBM traffic \(JSON\) ==\n(\{.*\})', open(best).read())
-                tj = json.loads(m_.group(1))['k_dec_b']
-                out['roofline']['traffic'] = (tj['hbm_read_bytes_per_image'] + tj['hbm_write_bytes_per_image']) * rows_per_launch
-                out['roofline']['traffic_source'] = os.path.basename(best) + ' (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, per image x images per launch)'
-            except Exception:
-                pass
+            bpi, src = committed_traffic('k_dec_b')
+            if bpi is not None:
+                out['roofline']['traffic'] = bpi * rows_per_launch
+                out['roofline']['traffic_source'] = src + ' (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, per image x images per launch)'
             tot = sum(v[0] for v in breakdown.values())
+            macs = class_macs_per_step(R, D, S)
             kern = {}
             for k_, (ms_, n_) in breakdown.items():
                 if n_ == 0:
                     continue
                 e = {'ms': round(ms_, 3), 'launches': int(n_), 'share': round(ms_ / tot, 4) if tot else 0}
-                if k_ in CLASS_MACS_PER_ROW and ms_ > 0:
-                    e['tflops'] = round(2 * CLASS_MACS_PER_ROW[k_] * D * 3 * S * R / (ms_ * 1e-3) / 1e12, 2)
+                if k_ in macs and ms_ > 0:
+                    e['tflops'] = round(2 * macs[k_] / (ms_ * 1e-3) / 1e12, 2)
+                    e['frac_of_fp32_mfma_peak'] = round(e['tflops'] / PEAK_FP32_MFMA_TF, 4)
                 kern[k_] = e
             out['kernels_one_step'] = kern
         if world == 1 and not a.no_cpu:
             out['cpu_baseline'] = cpu_baseline(D, S)
             out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+    if world == 1 and not a.no_extras and not a.force_dist:
+        mc = bench_mcts(a, model, device, 1, 0, None, 3, 1, not a.no_cpu)
+        out['extras'] = {'mcts_cfg3': mc}
+    if rank == 0:
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

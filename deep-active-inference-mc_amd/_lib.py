@@ -10,7 +10,9 @@ EXPORTS = ['efe_create', 'efe_destroy', 'efe_last_error', 'efe_abi_version', 'ef
            'efe_set_option', 'efe_transition', 'efe_decoder', 'efe_encoder', 'efe_habit', 'efe_calculate_g',
            'efe_rollout', 'efe_trajectory', 'efe_simulate', 'efe_action_posterior', 'efe_last_call_macs',
            'efe_prof_enable', 'efe_prof_classes', 'efe_prof_read', 'efe_env_reset', 'efe_env_step', 'efe_env_render',
-           'efe_check_reward', 'efe_reparameterize', 'efe_mcts_select', 'efe_mcts_expand', 'efe_mcts_backprop', 'efe_mcts_stop']
+           'efe_check_reward', 'efe_reparameterize', 'efe_mcts_select', 'efe_mcts_expand', 'efe_mcts_backprop', 'efe_mcts_stop',
+           'efe_build_id', 'efe_reserve', 'efe_rollout_scratch_bytes', 'efe_arena_stats', 'efe_env_new_image']
+ABI_VERSION = 2
 
 
 class EfeMctsTree(C.Structure):
@@ -24,6 +26,26 @@ class EfeNoise(C.Structure):
 
 
 _lib = None
+_ops = None
+OPS_PATH = os.path.join(HERE, 'libefe_torch_ops.so')
+
+
+def load_ops():
+    """torch.ops.efe -- the custom-op registration library (csrc/torch_ops.cpp) over the C ABI.  Loud if missing or stale."""
+    global _ops
+    if _ops is not None:
+        return _ops
+    load()                                    # the engine library first (same checks), so the ops library resolves against it
+    import torch
+    from . import build as _build
+    if not os.path.exists(OPS_PATH):
+        raise ImportError(f'{OPS_PATH} not built: run `python -c "import __graft_entry__ as g; g.build()"`')
+    want, have = _build.ops_digest(), _build._stamp(OPS_PATH, 'EFE_OPS_BUILD_ID')
+    if want != have:
+        raise ImportError(f'{OPS_PATH} is stale: built from sources {have}, the sources here are {want}; re-run build()')
+    torch.ops.load_library(OPS_PATH)
+    _ops = torch.ops.efe
+    return _ops
 
 
 def load():
@@ -34,12 +56,22 @@ def load():
         raise ImportError(f'{LIB_PATH} not built: run `python -c "import __graft_entry__ as g; g.build()"` '
                           '(hipcc --offload-arch=gfx950); there is no CPU fallback')
     lib = C.CDLL(LIB_PATH)
+    lib.efe_abi_version.argtypes = []; lib.efe_abi_version.restype = C.c_int
+    if lib.efe_abi_version() != ABI_VERSION:
+        raise ImportError(f'{LIB_PATH}: ABI version {lib.efe_abi_version()} != {ABI_VERSION} (stale build: re-run build())')
+    lib.efe_build_id.argtypes = []; lib.efe_build_id.restype = C.c_char_p
+    if not os.environ.get('EFE_LIB_PATH'):
+        # a shipped binary must come from the sources next to it: compare the digest compiled into it
+        from . import build as _build
+        want, have = _build.source_digest(), lib.efe_build_id().decode()
+        if want != have:
+            raise ImportError(f'{LIB_PATH} is stale: built from sources {have}, the sources here are {want}; '
+                              're-run `python -c "import __graft_entry__ as g; g.build()"`')
     p, i, f32p = C.c_void_p, C.c_int, C.c_void_p
     nzp = C.POINTER(EfeNoise)
     lib.efe_create.argtypes = [C.POINTER(p), i]; lib.efe_create.restype = i
     lib.efe_destroy.argtypes = [p]; lib.efe_destroy.restype = None
     lib.efe_last_error.argtypes = [p]; lib.efe_last_error.restype = C.c_char_p
-    lib.efe_abi_version.argtypes = []; lib.efe_abi_version.restype = i
     lib.efe_set_weight.argtypes = [p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), i]; lib.efe_set_weight.restype = i
     lib.efe_commit_weights.argtypes = [p]; lib.efe_commit_weights.restype = i
     lib.efe_set_option.argtypes = [p, C.c_char_p, C.c_int64]; lib.efe_set_option.restype = i
@@ -51,7 +83,11 @@ def load():
     lib.efe_calculate_g.restype = i
     lib.efe_rollout.argtypes = [p, f32p, f32p, i, i, i, i, i, nzp, f32p, f32p, f32p, f32p, p]; lib.efe_rollout.restype = i
     lib.efe_trajectory.argtypes = [p, f32p, f32p, f32p, f32p, f32p, i, nzp, f32p, f32p, p]; lib.efe_trajectory.restype = i
-    lib.efe_simulate.argtypes = [p, f32p, i, i, i, nzp, f32p, f32p, f32p, p]; lib.efe_simulate.restype = i
+    lib.efe_simulate.argtypes = [p, f32p, i, i, i, nzp, f32p, f32p, f32p, f32p, f32p, p]; lib.efe_simulate.restype = i
+    lib.efe_reserve.argtypes = [p, C.c_int64]; lib.efe_reserve.restype = i
+    lib.efe_rollout_scratch_bytes.argtypes = [p, i, i, i]; lib.efe_rollout_scratch_bytes.restype = C.c_int64
+    lib.efe_arena_stats.argtypes = [p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.efe_arena_stats.restype = i
+    lib.efe_env_new_image.argtypes = [p, f32p, i, nzp, p]; lib.efe_env_new_image.restype = i
     lib.efe_action_posterior.argtypes = [p, f32p, i, i, C.c_float, f32p, f32p, p]; lib.efe_action_posterior.restype = i
     lib.efe_last_call_macs.argtypes = [p]; lib.efe_last_call_macs.restype = C.c_int64
     lib.efe_prof_enable.argtypes = [p, i]; lib.efe_prof_enable.restype = i

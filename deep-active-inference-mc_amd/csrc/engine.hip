@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/efe_engine.h"
@@ -50,8 +51,18 @@ struct efe_ctx {
     float *enc_w1 = nullptr, *enc_b1 = nullptr, *dec_wf = nullptr;
     float dec_bf = 0.f;
     float* zeros = nullptr;
-    std::vector<void*> owned;
+    std::vector<void*> owned;      // lives as long as the context
+    std::vector<void*> wbufs;      // packed weights of the current commit (freed by the next one)
     Arena arena;
+    // One scratch arena per context: calls are serialised by `mu` (host threads) and ordered across streams by `done_ev`
+    // (a call on a different stream than the previous one first waits for that call's last kernel), so the arena reset at the
+    // start of a call never races with work still in flight.
+    std::mutex mu;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    hipEvent_t done_ev = nullptr;
+    size_t high_water = 0;         // largest arena use of any call so far (bytes)
+    int64_t arena_grows = 0;       // number of hipMalloc calls the arena has made
     int64_t dec_chunk = 32768, enc_chunk = 32768, dbg_a = 0, dbg_b = 0;
     int64_t arena_align = 256;
     void* tl_buf = nullptr;   // EFE_TIMELINE experiments: device buffer of 64 int64 stamps (option "tl_buf" = device pointer)
@@ -76,6 +87,7 @@ struct efe_ctx {
         ev_spans.push_back({cls, {a, b}});
     }
 
+    std::string pending;      // error raised inside a launch helper, reported by finish()
     int fail(const std::string& m) { err = m; return 1; }
 
     // bump allocator over a list of device blocks; grows (synchronously) on first use at a new size
@@ -84,7 +96,11 @@ struct efe_ctx {
         while (true) {
             if (arena.cur < arena.blocks.size()) {
                 auto& b = arena.blocks[arena.cur];
-                if (arena.off + bytes <= b.second) { void* p = b.first + arena.off; arena.off += bytes; arena.used_total += bytes; return p; }
+                if (arena.off + bytes <= b.second) {
+                    void* p = b.first + arena.off; arena.off += bytes; arena.used_total += bytes;
+                    if (arena.used_total > high_water) high_water = arena.used_total;
+                    return p;
+                }
                 arena.cur++; arena.off = 0;
                 continue;
             }
@@ -92,6 +108,7 @@ struct efe_ctx {
             char* p = nullptr;
             if (hipMalloc((void**)&p, sz) != hipSuccess) { err = "arena hipMalloc failed"; return nullptr; }
             arena.blocks.push_back({p, sz});
+            ++arena_grows;
         }
     }
     template <class T> T* allocT(size_t n) { return reinterpret_cast<T*>(alloc(n * sizeof(T))); }
@@ -116,8 +133,8 @@ int upload_packed(efe_ctx* ctx, Layer& L, int ntaps, int cout, int cin, Get get,
                     }
     std::vector<float> b((size_t)L.mtiles * 32, 0.f);
     for (int co = 0; co < cout; ++co) b[co] = bias_src[bias_perm ? bias_perm[co] : co];
-    HIPCHK(hipMalloc((void**)&L.Wp, p.size() * 4)); ctx->owned.push_back(L.Wp);
-    HIPCHK(hipMalloc((void**)&L.bias, b.size() * 4)); ctx->owned.push_back(L.bias);
+    HIPCHK(hipMalloc((void**)&L.Wp, p.size() * 4)); ctx->wbufs.push_back(L.Wp);
+    HIPCHK(hipMalloc((void**)&L.bias, b.size() * 4)); ctx->wbufs.push_back(L.bias);
     HIPCHK(hipMemcpy(L.Wp, p.data(), p.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(L.bias, b.data(), b.size() * 4, hipMemcpyHostToDevice));
     return 0;
@@ -164,7 +181,7 @@ void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float*
         int MT = L.mtiles == 1 ? 1 : 2, NT = 2;
         const long tiles22 = (long)((L.mtiles + MT - 1) / MT) * ((M + 63) / 64);
         if (tiles22 < 2048) { NT = 1; if (tiles22 * 2 < 2048) MT = 1; }
-        launch_dense(MT, NT, a, st);
+        if (launch_dense(MT, NT, a, st)) ctx->pending = "launch_dense: unsupported tile shape";
     }
     ctx->prof_end(e0, st);
 }
@@ -337,20 +354,35 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
     return 0;
 }
 
-int check_ready(efe_ctx* ctx) {
+// Start of an engine call on stream `st`: the scratch arena is reused from its start, so work of the previous call that is still
+// in flight on ANOTHER stream must finish first (same stream: stream order already guarantees it).
+int check_ready(efe_ctx* ctx, hipStream_t st) {
     if (!ctx) return 1;
     if (!ctx->committed) return ctx->fail("weights not committed");
     if (hipSetDevice(ctx->device) != hipSuccess) return ctx->fail("hipSetDevice failed");
+    if (ctx->have_last && ctx->last_stream != st) {
+        if (hipStreamWaitEvent(st, ctx->done_ev, 0) != hipSuccess) return ctx->fail("hipStreamWaitEvent failed");
+    }
     ctx->arena.reset();
     ctx->last_macs = 0;
     return 0;
 }
 
-int finish(efe_ctx* ctx) {
+int finish(efe_ctx* ctx, hipStream_t st) {
+    if (!ctx->pending.empty()) { ctx->err = ctx->pending; ctx->pending.clear(); return 1; }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ctx->fail(std::string("kernel launch: ") + hipGetErrorString(e));
+    if (hipEventRecord(ctx->done_ev, st) != hipSuccess) return ctx->fail("hipEventRecord failed");
+    ctx->last_stream = st; ctx->have_last = true;
+    return 0;
+}
+int finish(efe_ctx* ctx) {          // calls that use no engine scratch (environment, tree kernels, helpers)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ctx->fail(std::string("kernel launch: ") + hipGetErrorString(e));
     return 0;
 }
+
+#define EFE_LOCK(ctx) std::lock_guard<std::mutex> lock_((ctx)->mu)
 
 }  // namespace
 
@@ -359,7 +391,15 @@ int finish(efe_ctx* ctx) {
 // =====================================================================================================
 extern "C" {
 
-int efe_abi_version(void) { return 1; }
+int efe_abi_version(void) { return 2; }
+
+#ifndef EFE_BUILD_ID
+#define EFE_BUILD_ID "unstamped"
+#endif
+const char* efe_build_id(void) {
+    static const char stamp[] = "EFE_BUILD_ID=" EFE_BUILD_ID;      // the marker lets build.py read the stamp from the file without dlopen
+    return stamp + 13;
+}
 
 int efe_create(efe_ctx** out, int device) {
     if (!out) return 1;
@@ -372,6 +412,7 @@ int efe_create(efe_ctx** out, int device) {
     ctx->device = device;
     if (hipMalloc((void**)&ctx->zeros, 8192) != hipSuccess || hipMemset(ctx->zeros, 0, 8192) != hipSuccess) { delete ctx; return 4; }
     ctx->owned.push_back(ctx->zeros);
+    if (hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(ctx->zeros); delete ctx; return 6; }
     *out = ctx;
     return 0;
 }
@@ -381,7 +422,9 @@ void efe_destroy(efe_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->done_ev) (void)hipEventDestroy(ctx->done_ev);
     for (void* p : ctx->owned) (void)hipFree(p);
+    for (void* p : ctx->wbufs) (void)hipFree(p);
     for (auto& b : ctx->arena.blocks) (void)hipFree(b.first);
     delete ctx;
 }
@@ -390,6 +433,7 @@ const char* efe_last_error(efe_ctx* ctx) { return ctx ? ctx->err.c_str() : "null
 
 int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const int64_t* shape, int ndim) {
     if (!ctx || !key || !data_host || !shape || ndim < 1 || ndim > 4) return 1;
+    EFE_LOCK(ctx);
     HostTensor t;
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
@@ -401,6 +445,7 @@ int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const 
 
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return 1;
+    EFE_LOCK(ctx);
     if (!strcmp(name, "dec_chunk")) { if (value < 1) return ctx->fail("dec_chunk < 1"); ctx->dec_chunk = value; return 0; }
     if (!strcmp(name, "tl_buf")) { ctx->tl_buf = (void*)(intptr_t)value; return 0; }
     if (!strcmp(name, "dbg_a")) { ctx->dbg_a = value; return 0; }
@@ -412,7 +457,15 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
 
 int efe_commit_weights(efe_ctx* ctx) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     HIPCHK(hipSetDevice(ctx->device));
+    // a re-commit replaces the packed buffers of the previous one: wait for work that may still read them, then free them
+    if (!ctx->wbufs.empty()) {
+        HIPCHK(hipDeviceSynchronize());
+        for (void* p : ctx->wbufs) (void)hipFree(p);
+        ctx->wbufs.clear();
+    }
+    ctx->committed = false;
     // habit net (torchmodel.py:19-25)
     if (pack_linear(ctx, ctx->top[0], "top.qpi_net.0", 128, 10, nullptr, nullptr)) return 1;
     if (pack_linear(ctx, ctx->top[1], "top.qpi_net.2", 128, 128, nullptr, nullptr)) return 1;
@@ -429,8 +482,8 @@ int efe_commit_weights(efe_ctx* ctx) {
         if (!w || !b) return 1;
         std::vector<float> w1(288);
         for (int t = 0; t < 9; ++t) for (int co = 0; co < 32; ++co) w1[t * 32 + co] = w->data[co * 9 + t];
-        HIPCHK(hipMalloc((void**)&ctx->enc_w1, 288 * 4)); ctx->owned.push_back(ctx->enc_w1);
-        HIPCHK(hipMalloc((void**)&ctx->enc_b1, 32 * 4)); ctx->owned.push_back(ctx->enc_b1);
+        HIPCHK(hipMalloc((void**)&ctx->enc_w1, 288 * 4)); ctx->wbufs.push_back(ctx->enc_w1);
+        HIPCHK(hipMalloc((void**)&ctx->enc_b1, 32 * 4)); ctx->wbufs.push_back(ctx->enc_b1);
         HIPCHK(hipMemcpy(ctx->enc_w1, w1.data(), 288 * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(ctx->enc_b1, b->data.data(), 32 * 4, hipMemcpyHostToDevice));
     }
@@ -477,26 +530,37 @@ int efe_commit_weights(efe_ctx* ctx) {
         if (!w || !b) return 1;
         std::vector<float> wf(288);
         for (int t = 0; t < 9; ++t) for (int ci = 0; ci < 32; ++ci) wf[t * 32 + ci] = w->data[ci * 9 + t];
-        HIPCHK(hipMalloc((void**)&ctx->dec_wf, 288 * 4)); ctx->owned.push_back(ctx->dec_wf);
+        HIPCHK(hipMalloc((void**)&ctx->dec_wf, 288 * 4)); ctx->wbufs.push_back(ctx->dec_wf);
         HIPCHK(hipMemcpy(ctx->dec_wf, wf.data(), 288 * 4, hipMemcpyHostToDevice));
         ctx->dec_bf = b->data[0];
     }
-    ctx->raw.clear();
+    // the host copies stay: a caller may update a single tensor with efe_set_weight and commit again
     ctx->committed = true;
     return 0;
 }
 
 int efe_env_reset(efe_ctx* ctx, float* state, float* last_r, int E, const efe_noise* nz, void* stream) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     if (!state || !last_r || !nz || E < 1) return ctx->fail("efe_env_reset: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     launch_env_reset(state, last_r, E, (uint32_t)nz->seed, (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, (hipStream_t)stream);
     return finish(ctx);
 }
 
+int efe_env_new_image(efe_ctx* ctx, float* state, int E, const efe_noise* nz, void* stream) {
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
+    if (!state || !nz || E < 1) return ctx->fail("efe_env_new_image: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    launch_env_new_image(state, E, (uint32_t)nz->seed, (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, (hipStream_t)stream);
+    return finish(ctx);
+}
+
 int efe_env_step(efe_ctx* ctx, float* state, float* last_r, const int32_t* actions, int E, int repeats, const efe_noise* nz,
                  int32_t* round_changed, void* stream) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     if (!state || !last_r || !actions || !nz || E < 1 || repeats < 1) return ctx->fail("efe_env_step: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     launch_env_step(state, last_r, actions, round_changed, E, repeats, (uint32_t)nz->seed, (uint32_t)(nz->seed >> 32), nz->stage,
@@ -507,6 +571,7 @@ int efe_env_step(efe_ctx* ctx, float* state, float* last_r, const int32_t* actio
 int efe_env_render(efe_ctx* ctx, const float* state, const float* last_r, const uint8_t* imgs, int64_t n_imgs, float* frames,
                    int32_t* err, int E, void* stream) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     if (!state || !last_r || !imgs || !frames || n_imgs < 1 || E < 1) return ctx->fail("efe_env_render: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     launch_env_render(state, last_r, imgs, (long)n_imgs, frames, err, E, (hipStream_t)stream);
@@ -526,6 +591,7 @@ int efe_mcts_select(efe_ctx* ctx, const efe_mcts_tree* tree, const uint8_t* acti
                     int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf, float* leaf_s, float* leaf_s_rep,
                     void* stream) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     MctsTree t;
     if (mcts_tree(ctx, tree, t)) return 1;
     if (!active || !path_nodes || !path_act || !path_len || !leaf || !leaf_s || !leaf_s_rep || max_depth < 1)
@@ -538,6 +604,7 @@ int efe_mcts_select(efe_ctx* ctx, const efe_mcts_tree* tree, const uint8_t* acti
 int efe_mcts_expand(efe_ctx* ctx, const efe_mcts_tree* tree, int32_t* n_nodes, const int32_t* nodes, const uint8_t* mask, const float* G,
                     const float* ps_next, void* stream) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     MctsTree t;
     if (mcts_tree(ctx, tree, t)) return 1;
     if (!n_nodes || !nodes || !mask || !G || !ps_next) return ctx->fail("efe_mcts_expand: bad arguments");
@@ -550,6 +617,7 @@ int efe_mcts_backprop(efe_ctx* ctx, const efe_mcts_tree* tree, const int32_t* pa
                       const int32_t* leaf, const uint8_t* active, const float* sims, int n_sims, const float* q0, int max_depth,
                       float* g_out, uint8_t* active_out, void* stream) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     MctsTree t;
     if (mcts_tree(ctx, tree, t)) return 1;
     if (!path_nodes || !path_act || !path_len || !leaf || !active || !sims || n_sims < 1 || !q0 || !g_out || !active_out || max_depth < 1)
@@ -562,6 +630,7 @@ int efe_mcts_backprop(efe_ctx* ctx, const efe_mcts_tree* tree, const int32_t* pa
 int efe_mcts_stop(efe_ctx* ctx, const efe_mcts_tree* tree, uint8_t* active, int32_t* stop_at, int repeat, float threshold,
                   int32_t* n_active, void* stream) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     MctsTree t;
     if (mcts_tree(ctx, tree, t)) return 1;
     if (!active || !stop_at || !n_active) return ctx->fail("efe_mcts_stop: bad arguments");
@@ -574,6 +643,7 @@ int64_t efe_last_call_macs(efe_ctx* ctx) { return ctx ? ctx->last_macs : 0; }
 
 int efe_prof_enable(efe_ctx* ctx, int on) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     ctx->prof = (on < 0) ? 0xFFFFFFFFu : (unsigned)on;       // < 0 = all classes, otherwise a bitmask (bit c = class c)
     ctx->ev_used = 0;
     ctx->ev_spans.clear();
@@ -584,6 +654,7 @@ int efe_prof_classes(void) { return PROF_NCLS; }
 
 int efe_prof_read(efe_ctx* ctx, double* ms, int64_t* launches) {
     if (!ctx || !ms || !launches) return 1;
+    EFE_LOCK(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
     for (int i = 0; i < PROF_NCLS; ++i) { ms[i] = 0.0; launches[i] = 0; }
@@ -600,9 +671,11 @@ int efe_prof_read(efe_ctx* ctx, double* ms, int64_t* launches) {
 // ---- network level -------------------------------------------------------------------------------------
 int efe_transition(efe_ctx* ctx, const float* pi, const float* s0, int M, const efe_noise* nz, const float* eps,
                    float* ps1, float* mean, float* logvar, void* stream) {
-    if (check_ready(ctx)) return 1;
-    if (!pi || !s0 || !nz || M < 1) return ctx->fail("efe_transition: bad arguments");
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
+    if (check_ready(ctx, st)) return 1;
+    if (!pi || !s0 || !nz || M < 1) return ctx->fail("efe_transition: bad arguments");
     float* x = ctx->allocT<float>((size_t)M * 16);
     float* tr = ctx->allocT<float>((size_t)M * 32);
     if (!x || !tr) return 1;
@@ -612,13 +685,15 @@ int efe_transition(efe_ctx* ctx, const float* pi, const float* s0, int M, const 
     if (run_mid(ctx, x, 0, M, tr, nc, st)) return 1;
     launch_split_enc(tr, mean, logvar, M, st);
     if (ps1) launch_root_post(tr, nullptr, eps, nullptr, ps1, M, 0, nc.k0, nc.k1, nz->pass, nz->sample, nz->stage, nz->row_offset, st);
-    return finish(ctx);
+    return finish(ctx, st);
 }
 
 int efe_decoder(efe_ctx* ctx, const float* s, int M, const efe_noise* nz, float* po, void* stream) {
-    if (check_ready(ctx)) return 1;
-    if (!s || !nz || !po || M < 1) return ctx->fail("efe_decoder: bad arguments");
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
+    if (check_ready(ctx, st)) return 1;
+    if (!s || !nz || !po || M < 1) return ctx->fail("efe_decoder: bad arguments");
     float* x = ctx->allocT<float>((size_t)M * 16);
     float* val = ctx->allocT<float>((size_t)M);
     if (!x || !val) return 1;
@@ -626,13 +701,15 @@ int efe_decoder(efe_ctx* ctx, const float* s, int M, const efe_noise* nz, float*
     NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;
     nc.gm = GroupMap{1, 1, {nz->pass, 0, 0}, nz->stage, nz->sample};
     if (run_decoder(ctx, x, M, nc, 0, 1, val, po, st)) return 1;
-    return finish(ctx);
+    return finish(ctx, st);
 }
 
 int efe_encoder(efe_ctx* ctx, const float* o, int M, const efe_noise* nz, const float* eps, float* s, float* mean, float* logvar, void* stream) {
-    if (check_ready(ctx)) return 1;
-    if (!o || !nz || M < 1) return ctx->fail("efe_encoder: bad arguments");
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
+    if (check_ready(ctx, st)) return 1;
+    if (!o || !nz || M < 1) return ctx->fail("efe_encoder: bad arguments");
     float* enc = ctx->allocT<float>((size_t)M * 32);
     if (!enc) return 1;
     NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;
@@ -640,24 +717,27 @@ int efe_encoder(efe_ctx* ctx, const float* o, int M, const efe_noise* nz, const 
     if (run_encoder(ctx, o, M, nc, enc, st)) return 1;
     launch_split_enc(enc, mean, logvar, M, st);
     if (s) launch_root_post(enc, nullptr, eps, nullptr, s, M, 0, nc.k0, nc.k1, nz->pass, nz->sample, nz->stage, nz->row_offset, st);
-    return finish(ctx);
+    return finish(ctx, st);
 }
 
 int efe_habit(efe_ctx* ctx, const float* s, int M, float* logits, float* q, float* logq, void* stream) {
-    if (check_ready(ctx)) return 1;
-    if (!s || M < 1) return ctx->fail("efe_habit: bad arguments");
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
+    if (check_ready(ctx, st)) return 1;
+    if (!s || M < 1) return ctx->fail("efe_habit: bad arguments");
     float* x = ctx->allocT<float>((size_t)M * 16);
     float* l32 = ctx->allocT<float>((size_t)M * 32);
     if (!x || !l32) return 1;
     launch_pad16(s, x, M, S_DIM, st);
     if (run_habit(ctx, x, M, l32, st)) return 1;
     launch_softmax4(l32, logits, q, logq, M, PI_DIM, st);
-    return finish(ctx);
+    return finish(ctx, st);
 }
 
 int efe_check_reward(efe_ctx* ctx, const float* o, int M, float* out, void* stream) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     if (!o || !out || M < 1) return ctx->fail("efe_check_reward: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     launch_check_reward(o, out, M, (hipStream_t)stream);
@@ -667,6 +747,7 @@ int efe_check_reward(efe_ctx* ctx, const float* o, int M, float* out, void* stre
 int efe_reparameterize(efe_ctx* ctx, const float* mean, const float* logvar, int M, int n, const efe_noise* nz, const float* eps,
                        float* out, void* stream) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     if (!mean || !logvar || !nz || !out || M < 1 || n < 1) return ctx->fail("efe_reparameterize: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     launch_reparam(mean, logvar, eps, out, M, n, (uint32_t)nz->seed, (uint32_t)(nz->seed >> 32), nz->pass, nz->sample, nz->stage,
@@ -677,9 +758,11 @@ int efe_reparameterize(efe_ctx* ctx, const float* mean, const float* logvar, int
 // ---- EFE level -----------------------------------------------------------------------------------------
 int efe_calculate_g(efe_ctx* ctx, const float* s0, const float* pi0, int M, int samples, int mean_mode, const efe_noise* nz,
                     const float* eps, float* G, float* terms, float* ps1, float* ps1_mean, float* po1, float* t2parts, void* stream) {
-    if (check_ready(ctx)) return 1;
-    if (!s0 || !pi0 || !nz || !G || M < 1 || samples < 1 || samples > 65535) return ctx->fail("efe_calculate_g: bad arguments");
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
+    if (check_ready(ctx, st)) return 1;
+    if (!s0 || !pi0 || !nz || !G || M < 1 || samples < 1 || samples > 65535) return ctx->fail("efe_calculate_g: bad arguments");
     float* x = ctx->allocT<float>((size_t)M * 16);
     if (!x) return 1;
     launch_pack_x(pi0, s0, x, M, PI_DIM, S_DIM, st);
@@ -688,14 +771,16 @@ int efe_calculate_g(efe_ctx* ctx, const float* s0, const float* pi0, int M, int 
     io.k0 = (uint32_t)nz->seed; io.k1 = (uint32_t)(nz->seed >> 32); io.stage0 = nz->stage; io.row_offset = nz->row_offset;
     io.eps = eps; io.G = G; io.terms = terms; io.ps1 = ps1; io.ps1_mean = ps1_mean; io.po1 = po1; io.t2parts = t2parts;
     if (run_core(ctx, io, st)) return 1;
-    return finish(ctx);
+    return finish(ctx, st);
 }
 
 int efe_rollout(efe_ctx* ctx, const float* o, const float* pi, int M, int steps, int samples, int calc_mean, int per_stage_mean,
                 const efe_noise* nz, const float* eps, float* sum_G, float* sum_terms, float* po1, void* stream) {
-    if (check_ready(ctx)) return 1;
-    if (!o || !pi || !nz || !sum_G || M < 1 || steps < 1 || samples < 1 || samples > 65535) return ctx->fail("efe_rollout: bad arguments");
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
+    if (check_ready(ctx, st)) return 1;
+    if (!o || !pi || !nz || !sum_G || M < 1 || steps < 1 || samples < 1 || samples > 65535) return ctx->fail("efe_rollout: bad arguments");
     const uint32_t k0 = (uint32_t)nz->seed, k1 = (uint32_t)(nz->seed >> 32);
     float* enc0 = ctx->allocT<float>((size_t)M * 32);
     float* x = ctx->allocT<float>((size_t)M * 16);
@@ -713,7 +798,7 @@ int efe_rollout(efe_ctx* ctx, const float* o, const float* pi, int M, int steps,
     io.eps = eps ? eps + (size_t)M * 10 : nullptr;
     io.G = sum_G; io.terms = sum_terms; io.po1 = po1;
     if (run_core(ctx, io, st)) return 1;
-    return finish(ctx);
+    return finish(ctx, st);
 }
 
 static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, const float* mean_traj, const float* lv_traj,
@@ -732,19 +817,24 @@ static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_
 
 int efe_trajectory(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, const float* ps1_mean_traj, const float* ps1_logvar_traj,
                    const float* pi0_traj, int T, const efe_noise* nz, const float* eps, float* G, void* stream) {
-    if (check_ready(ctx)) return 1;
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    if (check_ready(ctx, st)) return 1;
     if (!s0_traj || !ps1_traj || !ps1_mean_traj || !ps1_logvar_traj || !pi0_traj || !nz || !G || T < 1)
         return ctx->fail("efe_trajectory: bad arguments");
     if (trajectory_impl(ctx, s0_traj, ps1_traj, ps1_mean_traj, ps1_logvar_traj, pi0_traj, T, (uint32_t)nz->seed,
-                        (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, eps, G, (hipStream_t)stream)) return 1;
-    return finish(ctx);
+                        (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, eps, G, st)) return 1;
+    return finish(ctx, st);
 }
 
 int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int use_means, const efe_noise* nz,
-                 float* G_mean, float* pi0, float* Qpi0, void* stream) {
-    if (check_ready(ctx)) return 1;
-    if (!starting_s || !nz || !G_mean || !pi0 || E < 1 || depth < 1 || depth > 65535) return ctx->fail("efe_simulate: bad arguments");
+                 const float* eps, const float* u, float* G_mean, float* pi0, float* Qpi0, void* stream) {
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
+    if (check_ready(ctx, st)) return 1;
+    if (!starting_s || !nz || !G_mean || !pi0 || E < 1 || depth < 1 || depth > 65535) return ctx->fail("efe_simulate: bad arguments");
     const uint32_t k0 = (uint32_t)nz->seed, k1 = (uint32_t)(nz->seed >> 32);
     const int T = depth;
     float* s_cur = ctx->allocT<float>((size_t)2 * E * 10);
@@ -762,31 +852,88 @@ int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int us
     HIPCHK(hipMemcpyAsync(s_cur, starting_s, (size_t)E * 10 * 4, hipMemcpyDeviceToDevice, st));
     float* cur = s_cur; float* nxt = s_cur + (size_t)E * 10;
     for (int t = 0; t < T; ++t) {
-        const size_t mark_cur = ctx->arena.cur, mark_off = ctx->arena.off;   // per-step scratch is recycled
+        const size_t mark_cur = ctx->arena.cur, mark_off = ctx->arena.off, mark_used = ctx->arena.used_total;   // per-step scratch is recycled
         launch_pad16(cur, x16, E, S_DIM, st);
         if (run_habit(ctx, x16, E, l32, st)) return 1;
         launch_softmax4(l32, nullptr, q, nullptr, E, PI_DIM, st);
-        launch_sample_action(q, pit, (t == 0) ? Qpi0 : nullptr, E, PI_DIM, k0, k1, (uint32_t)t, nz->stage, nz->row_offset, nullptr, st);
+        launch_sample_action(q, pit, (t == 0) ? Qpi0 : nullptr, E, PI_DIM, k0, k1, (uint32_t)t, nz->stage, nz->row_offset,
+                             u ? u + (size_t)t * E : nullptr, st);
         launch_scatter_pi(pit, pi0, E, T, t, PI_DIM, st);
         launch_pack_x(pit, cur, x16, E, PI_DIM, S_DIM, st);
         NoiseCfg nc; nc.k0 = k0; nc.k1 = k1; nc.rows_per_group = E; nc.row_offset = nz->row_offset;
         nc.gm = GroupMap{1, 1, {PASS_SIM, 0, 0}, nz->stage, (uint32_t)t};
         if (run_mid(ctx, x16, 0, E, tr, nc, st)) return 1;
-        launch_sim_post(tr, nullptr, s0t, ps1t, mt, lvt, nxt, cur, E, T, t, use_means, k0, k1, nz->stage, nz->row_offset, st);
+        launch_sim_post(tr, eps ? eps + (size_t)t * E * 10 : nullptr, s0t, ps1t, mt, lvt, nxt, cur, E, T, t, use_means, k0, k1, nz->stage,
+                        nz->row_offset, st);
         std::swap(cur, nxt);
-        ctx->arena.cur = mark_cur; ctx->arena.off = mark_off;
+        ctx->arena.cur = mark_cur; ctx->arena.off = mark_off; ctx->arena.used_total = mark_used;
     }
-    if (trajectory_impl(ctx, s0t, ps1t, mt, lvt, pi0, E * T, k0, k1, nz->stage, nz->row_offset * (uint32_t)T, nullptr, Gt, st)) return 1;
+    if (trajectory_impl(ctx, s0t, ps1t, mt, lvt, pi0, E * T, k0, k1, nz->stage, nz->row_offset * (uint32_t)T,
+                        eps ? eps + (size_t)T * E * 10 : nullptr, Gt, st)) return 1;
     launch_mean_rows(Gt, G_mean, E, T, st);
-    return finish(ctx);
+    return finish(ctx, st);
 }
 
 int efe_action_posterior(efe_ctx* ctx, const float* sum_G, int n_groups, int n, float temperature, float* P, float* logP, void* stream) {
     if (!ctx) return 1;
+    EFE_LOCK(ctx);
     if (!sum_G || !P || !logP || n_groups < 1 || n < 1 || n > 8) return ctx->fail("efe_action_posterior: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     launch_posterior(sum_G, P, logP, n_groups, n, temperature, (hipStream_t)stream);
     return finish(ctx);
+}
+
+// ---- scratch management --------------------------------------------------------------------------------
+int efe_reserve(efe_ctx* ctx, int64_t bytes) {
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
+    if (bytes < 0) return ctx->fail("efe_reserve: bytes < 0");
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t have = 0;
+    for (auto& b : ctx->arena.blocks) have += b.second;
+    if (ctx->arena.blocks.size() <= 1 && have >= (size_t)bytes) return 0;
+    // one block that holds everything: a bump allocation never has to skip to the next block (no fragmentation, no growth)
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& b : ctx->arena.blocks) (void)hipFree(b.first);
+    ctx->arena.blocks.clear();
+    ctx->arena.reset();
+    const size_t sz = std::max((size_t)bytes, have);
+    char* p = nullptr;
+    if (hipMalloc((void**)&p, sz) != hipSuccess) return ctx->fail("efe_reserve: hipMalloc failed");
+    ctx->arena.blocks.push_back({p, sz});
+    return 0;
+}
+
+int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples) {
+    // mirrors the allocations of efe_rollout (run_encoder for the root, run_core: run_mid per stage, run_decoder, run_encoder);
+    // tests/test_gpu_parity.py::test_reserve_no_growth keeps it honest
+    if (!ctx || M < 1 || steps < 1 || samples < 1) return 0;
+    const size_t A = (size_t)ctx->arena_align;
+    const int64_t dec_chunk = ctx->dec_chunk, enc_chunk = ctx->enc_chunk;
+    auto al = [A](size_t b) { return (b + A - 1) / A * A; };
+    const size_t R = (size_t)M, D = (size_t)steps, S = (size_t)samples;
+    size_t t = 0;
+    auto enc = [&](size_t N) { const size_t C = std::min<size_t>((size_t)enc_chunk, N); t += al(C * 576 * 4) + 2 * al(C * 256 * 4); };
+    t += al(R * 32 * 4) + al(R * 16 * 4);                     // enc0, x
+    enc(R);                                                   // root encode
+    t += al(D * 2 * S * R * 32 * 4) + al(D * 3 * S * R * 16 * 4) + al(2 * R * 16 * 4) + al(D * 3 * S * R * 4)
+       + al(D * S * R * 4096 * 4) + al(D * S * R * 32 * 4) + al(3 * R * 4);
+    t += D * 2 * al(2 * S * R * 512 * 4);                     // h1, h2 per stage
+    {   const size_t N = D * 3 * S * R, C = std::min<size_t>((size_t)dec_chunk, N);
+        t += 2 * al(N * 256 * 4) + al(C * 16384 * 4) + al(C * 65536 * 4) + al(((N + C - 1) / C) * 4); }
+    enc(D * S * R);
+    return (int64_t)(t + ((size_t)1 << 20));
+}
+
+int efe_arena_stats(efe_ctx* ctx, int64_t* capacity_bytes, int64_t* high_water_bytes, int64_t* grow_count) {
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
+    size_t have = 0;
+    for (auto& b : ctx->arena.blocks) have += b.second;
+    if (capacity_bytes) *capacity_bytes = (int64_t)have;
+    if (high_water_bytes) *high_water_bytes = (int64_t)ctx->high_water;
+    if (grow_count) *grow_count = ctx->arena_grows;
+    return 0;
 }
 
 }  // extern "C"

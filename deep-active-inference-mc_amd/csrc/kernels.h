@@ -103,7 +103,7 @@ void launch_fc4(const GemmArgs& a, hipStream_t st);      // Linear(256,16384)+Re
 void launch_dec_a(const DecAArgs& a, hipStream_t st);
 void launch_dec_b(const DecBArgs& a, hipStream_t st);
 
-void launch_dense(int MT, int NT, const GemmArgs& a, hipStream_t st);
+int launch_dense(int MT, int NT, const GemmArgs& a, hipStream_t st);   // 0 = launched, 1 = unsupported tile shape
 
 struct TransPostArgs {
     const float* tr;       // [2S][R][32] (mean 0..9, logvar 10..19); group order T1_0..T1_{S-1}, T2_0..T2_{S-1}
@@ -170,6 +170,7 @@ void launch_reparam(const float* mean, const float* logvar, const float* eps_inj
                     uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, hipStream_t st);
 void launch_env_step(float* state, float* last_r, const int* actions, int* round_changed, int E, int repeats,
                      uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset, hipStream_t st);
+void launch_env_new_image(float* state, int E, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset, hipStream_t st);
 void launch_env_reset(float* state, float* last_r, int E, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset, hipStream_t st);
 void launch_env_render(const float* state, const float* last_r, const unsigned char* imgs, long n_imgs, float* frames, int* err,
                        int E, hipStream_t st);

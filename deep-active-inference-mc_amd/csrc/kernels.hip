@@ -177,15 +177,15 @@ static void launch_dn(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((k_dense<MT, NT, SK>), grid, dim3(256), 0, st, a);
 }
 
-void launch_dense(int MT, int NT, const GemmArgs& a, hipStream_t st) {
+int launch_dense(int MT, int NT, const GemmArgs& a, hipStream_t st) {
     const bool sk = a.cin >= 128;         // a property of the layer only (see k_dense)
-#define EFE_CASE(M_, N_) if (MT == M_ && NT == N_) { if (sk) launch_dn<M_, N_, 4>(a, st); else launch_dn<M_, N_, 1>(a, st); return; }
+#define EFE_CASE(M_, N_) if (MT == M_ && NT == N_) { if (sk) launch_dn<M_, N_, 4>(a, st); else launch_dn<M_, N_, 1>(a, st); return 0; }
     EFE_CASE(1, 1)
     EFE_CASE(2, 1)
     EFE_CASE(1, 2)
     EFE_CASE(2, 2)
 #undef EFE_CASE
-    abort();
+    return 1;                              // no such tile shape: reported by the caller, never a process abort
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -576,6 +576,18 @@ void launch_env_step(float* state, float* last_r, const int* actions, int* round
                      uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset, hipStream_t st) {
     hipLaunchKernelGGL(k_env_step, dim3((E + 127) / 128), dim3(128), 0, st, state, last_r, actions, round_changed, E, repeats,
                        k0, k1, stage, game_offset);
+}
+
+// new_image_all (game_environment.py:83-88): fresh latents, accumulated reward (slot 6) and last_r untouched
+__global__ void k_env_new_image(float* state, int E, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int sizes[6] = {1, 3, 6, 40, 32, 32};
+    float* s = state + (size_t)e * 7;
+    for (int k = 0; k < 6; ++k) s[k] = (float)env_randint(k0, k1, game_offset + e, stage, k, sizes[k]);
+}
+void launch_env_new_image(float* state, int E, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset, hipStream_t st) {
+    hipLaunchKernelGGL(k_env_new_image, dim3((E + 127) / 128), dim3(128), 0, st, state, E, k0, k1, stage, game_offset);
 }
 
 __global__ void k_env_reset(float* state, float* last_r, int E, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t game_offset) {

@@ -3,7 +3,7 @@
 // updates one episode's tree, so a planning iteration needs no host round trip between the engine calls.
 //
 // Every formula is evaluated in the reference's fp32 operation order (mcts.py:36-57, 82-99, 130-135):
-//   Q = W / N;  Qn = (Q - min Q) / sum(Q - min Q)  (sum left to right);  score = Qn + C / N  (or Qn + Qpi * (C / N))
+//   Q = W / N;  Qn = (Q - min Q) / sum(Q - min Q)  (sum left to right);  score = Qn + C / N  (or Qn + (C * Qpi) / N, mcts.py:45)
 // with torch's NaN rules (min and argmax propagate / prefer NaN, first index wins ties): an unvisited edge gives 0/0.
 #include "kernels.h"
 
@@ -44,8 +44,8 @@ __global__ void k_mcts_select(const MctsTree t, const uint8_t* active, float C, 
             float sum = 0.f;
             for (int i = 0; i < A; ++i) { q[i] = q[i] - qmin; sum = (i == 0) ? q[i] : sum + q[i]; }
             for (int i = 0; i < A; ++i) {
-                float bonus = C / t.N[o + i];
-                if (use_prior) bonus = rounded(t.Qpi[o + i] * bonus);
+                // mcts.py:45-47: `C * Qpi * 1.0 / N` evaluates left to right as ((C * Qpi) * 1.0) / N; without the prior (C * 1.0) / N
+                const float bonus = use_prior ? rounded(C * t.Qpi[o + i]) / t.N[o + i] : C / t.N[o + i];
                 sc[i] = rounded(q[i] / sum) + bonus;
             }
             const int a = argmax_nan_first(sc, A);

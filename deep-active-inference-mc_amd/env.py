@@ -26,7 +26,7 @@ def synthetic_sprite_bank(n=3581):
 
 
 class Game:
-    def __init__(self, games_no, *, model=None, device=None, imgs=None, seed=0, game_offset=0):
+    def __init__(self, games_no, *, model=None, device=None, imgs=None, seed=0, game_offset=0, init_stage=None):
         self.games_no = int(games_no)
         if model is not None:
             self._engine = model._engine
@@ -42,13 +42,19 @@ class Game:
         self.seed, self.game_offset, self._stage = int(seed), int(game_offset), 0
         self.current_s = torch.zeros(self.games_no, 7, device=self.device)
         self.last_r = torch.zeros(self.games_no, device=self.device)
-        self.randomize_environment_all()
+        self.new_image_all(init_stage)  # game_environment.py:21: fresh latents, reward 0, last_r 0 (randomisation is an explicit call, train.py:107)
 
     def _nz(self, stage):
         if stage is None:
             stage = self._stage
             self._stage += 1
         return _lib.EfeNoise(self.seed, int(stage), 9, 0, self.game_offset)
+
+    def new_image_all(self, stage=None):
+        """game_environment.py:83-88: new latents for every game; accumulated reward and last_r are kept"""
+        e = self._engine
+        nz = self._nz(stage)
+        e.check(e.lib.efe_env_new_image(e.ctx, _ptr(self.current_s), self.games_no, C.byref(nz), e.stream()))
 
     def randomize_environment_all(self, stage=None):
         """game_environment.py:72-75"""

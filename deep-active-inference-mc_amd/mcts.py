@@ -64,8 +64,9 @@ class Node:
         q = self.Q()
         q = q - q.min()
         q = q / q.sum()
-        bonus = self.C / self.N
-        return q + (self.Qpi * bonus if self.using_prior_for_exploration else bonus)
+        if self.using_prior_for_exploration:
+            return q + self.C * self.Qpi * 1.0 / self.N       # ((C * Qpi) * 1.0) / N, the reference's fp32 order (mcts.py:45)
+        return q + self.C * 1.0 / self.N
 
     def _pick(self, scores, deterministic):
         return int(torch.argmax(scores)) if deterministic else int(torch.multinomial(scores, 1))

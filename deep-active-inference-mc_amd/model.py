@@ -3,7 +3,9 @@ for the EFE hot path, backed by the HIP engine through the C ABI of include/efe_
 
 Same attribute names, method names, argument meaning and return tuples as the reference, so
 `src/mcts.py` / `src/util.py`-style callers are drop-in.  PyTorch is used only for device memory
-and streams; every network evaluation and every EFE reduction runs in libefe_mi355x.so.
+and streams; every network evaluation and every EFE reduction runs in libefe_mi355x.so, reached through the
+`torch.ops.efe.*` custom ops (csrc/torch_ops.cpp -> libefe_torch_ops.so) that are registered over the C ABI; the
+ctypes binding of the same ABI (_lib.py) serves context management, the tree / environment kernels and the ABI tests.
 There is no CPU fallback: constructing a model without a HIP device raises.
 
 Noise: the reference draws MC-dropout masks and normals from torch's unseeded global generator; here
@@ -42,6 +44,7 @@ class _Engine:
 
     def __init__(self, device_index):
         self.lib = _lib.load()
+        self.ops = _lib.load_ops()
         if not torch.cuda.is_available():
             raise RuntimeError('deep-active-inference-mc_amd needs a HIP device (MI355X); there is no CPU fallback')
         self.device = torch.device('cuda', device_index)
@@ -49,6 +52,7 @@ class _Engine:
         rc = self.lib.efe_create(C.byref(self.ctx), device_index)
         if rc != 0:
             raise RuntimeError(f'efe_create failed with code {rc}')
+        self.h = int(self.ctx.value)              # context handle as the torch.ops.efe ops take it
         # development hook: EFE_ENGINE_OPTS="name=value,..." applies efe_set_option to every context (kernel A/B experiments)
         for kv in filter(None, os.environ.get('EFE_ENGINE_OPTS', '').split(',')):
             k, v = kv.split('=')
@@ -132,10 +136,7 @@ class ModelTop(_Module):
         m = self._owner
         e = m._ready()
         s0 = e.tensor(s0, (-1, m.s_dim))
-        M = s0.shape[0]
-        logits, q, logq = e.empty(M, 4), e.empty(M, 4), e.empty(M, 4)
-        e.check(e.lib.efe_habit(e.ctx, _ptr(s0), M, _ptr(logits), _ptr(q), _ptr(logq), e.stream()))
-        return logits, q, logq
+        return e.ops.habit(e.h, s0)
 
 
 class ModelMid(_Module):
@@ -155,10 +156,10 @@ class ModelMid(_Module):
         pi = e.tensor(pi, (-1, m.pi_dim)); s0 = e.tensor(s0, (-1, m.s_dim))
         M = s0.shape[0]
         nz = m._noise(stage, pass_, sample, row_offset)
-        ps1, mean, logvar = e.empty(M, 10), e.empty(M, 10), e.empty(M, 10)
+        if eps is None and m.eps_source is not None:
+            eps = m._src_eps(M, 10, pass_, sample, nz.stage, row_offset)
         eps_t = e.tensor(eps, (M, 10)) if eps is not None else None
-        e.check(e.lib.efe_transition(e.ctx, _ptr(pi), _ptr(s0), M, C.byref(nz), _ptr(eps_t), _ptr(ps1), _ptr(mean), _ptr(logvar), e.stream()))
-        return ps1, mean, logvar
+        return e.ops.transition(e.h, pi, s0, m._seed64(), nz.stage, pass_, sample, nz.row_offset, eps_t)
 
     def transition(self, pi, s0, **kw):
         _, mean, logvar = self.transition_with_sample(pi, s0, **kw)
@@ -184,11 +185,11 @@ class ModelDown(_Module):
         o = e.tensor(o, (-1, 1, 64, 64))
         M = o.shape[0]
         nz = m._noise(stage, pass_, sample, row_offset)
-        mean, logvar = e.empty(M, 10), e.empty(M, 10)
-        s = e.empty(M, 10) if _want_s else None
+        if eps is None and _want_s and m.eps_source is not None:
+            eps = m._src_eps(M, 10, pass_, sample, nz.stage, row_offset)
         eps_t = e.tensor(eps, (M, 10)) if eps is not None else None
-        e.check(e.lib.efe_encoder(e.ctx, _ptr(o), M, C.byref(nz), _ptr(eps_t), _ptr(s), _ptr(mean), _ptr(logvar), e.stream()))
-        return s, mean, logvar
+        s, mean, logvar = e.ops.encoder(e.h, o, m._seed64(), nz.stage, pass_, sample, nz.row_offset, eps_t, bool(_want_s))
+        return (s if _want_s else None), mean, logvar
 
     def encoder(self, o, **kw):
         kw.setdefault('pass_', PASS_ROOT)
@@ -201,9 +202,7 @@ class ModelDown(_Module):
         s = e.tensor(s, (-1, m.s_dim))
         M = s.shape[0]
         nz = m._noise(stage, pass_, sample, row_offset)
-        po = e.empty(M, 1, 64, 64)
-        e.check(e.lib.efe_decoder(e.ctx, _ptr(s), M, C.byref(nz), _ptr(po), e.stream()))
-        return po
+        return e.ops.decoder(e.h, s, m._seed64(), nz.stage, pass_, sample, nz.row_offset)
 
 
 class ActiveInferenceModel:
@@ -228,6 +227,13 @@ class ActiveInferenceModel:
         self._stage = 0
         self._weights_dirty = True
         self.precision = torch.float32
+        # Optional injected-noise mode (parity tests): callables with the signatures of the Philox mirror,
+        #   eps_source(seed, rows, n, pass_, sample, stage, row_offset) -> float32 [rows, n] normals
+        #   u_source(seed, rows, pass_, sample, stage, row_offset)      -> float32 [rows] uniforms in (0,1)
+        # When set, every call that was not given explicit `eps` builds them from the source instead of using the device
+        # generator (same Philox stream, but Box-Muller evaluated by the source's libm: bit-equal normals on both sides).
+        self.eps_source = None
+        self.u_source = None
         self.model_top = ModelTop(self)
         self.model_mid = ModelMid(self)
         self.model_down = ModelDown(self)
@@ -287,6 +293,20 @@ class ActiveInferenceModel:
             self._weights_dirty = False
         return e
 
+    def reserve(self, rows, steps, samples):
+        """pre-size the engine's scratch arena for calculate_G_repeated(rows, steps, samples): later calls never hipMalloc"""
+        e = self._ready()
+        need = int(e.lib.efe_rollout_scratch_bytes(e.ctx, int(rows), int(steps), int(samples)))
+        e.check(e.lib.efe_reserve(e.ctx, need))
+        return need
+
+    def arena_stats(self):
+        """-> dict(capacity_bytes, high_water_bytes, grow_count)"""
+        e = self._engine
+        cap, hw, gr = C.c_int64(), C.c_int64(), C.c_int64()
+        e.check(e.lib.efe_arena_stats(e.ctx, C.byref(cap), C.byref(hw), C.byref(gr)))
+        return {'capacity_bytes': cap.value, 'high_water_bytes': hw.value, 'grow_count': gr.value}
+
     def set_option(self, name, value):
         e = self._engine
         e.check(e.lib.efe_set_option(e.ctx, name.encode(), int(value)))
@@ -337,6 +357,19 @@ class ActiveInferenceModel:
             self._stage += n
         return int(stage)
 
+    def _src_eps(self, rows, n, pass_, sample, stage, row_offset):
+        ro = self.row_offset if row_offset is None else int(row_offset)
+        return np.asarray(self.eps_source(self.seed, rows, n, pass_, sample, int(stage), ro), dtype=np.float32)
+
+    def _src_eps_calcG(self, M, S, stage, row_offset):
+        """[3S, M, 10]: T1_0..T1_{S-1}, T2_*, D2B_* (layout of efe_calculate_g)"""
+        return np.stack([self._src_eps(M, 10, pas, i, stage, row_offset) for pas in (PASS_T1, PASS_T2, PASS_D2B) for i in range(S)], 0)
+
+    def _seed64(self):
+        """the 64-bit noise seed as the signed integer a torch op schema carries"""
+        s = self.seed & 0xFFFFFFFFFFFFFFFF
+        return s - (1 << 64) if s >= (1 << 63) else s
+
     def _noise(self, stage, pass_, sample, row_offset=None):
         return _lib.EfeNoise(self.seed, self._take_stage(stage), pass_, sample,
                              self.row_offset if row_offset is None else int(row_offset))
@@ -346,20 +379,17 @@ class ActiveInferenceModel:
         """torchmodel.py:210-212 on an arbitrary image batch [M,1,64,64] -> [M] (the rollout path computes the same
         expression inside the fused decoder epilogue)"""
         e = self._ready()
-        o = e.tensor(o, (-1, 1, 64, 64))
-        out = e.empty(o.shape[0])
-        e.check(e.lib.efe_check_reward(e.ctx, _ptr(o), o.shape[0], _ptr(out), e.stream()))
-        return out
+        return e.ops.check_reward(e.h, e.tensor(o, (-1, 1, 64, 64)))
 
     def _reparameterize(self, mean, logvar, stage=None, pass_=PASS_ROOT, sample=0, eps=None, row_offset=None):
         e = self._ready()
         mean = e.tensor(mean); logvar = e.tensor(logvar)
         M, n = mean.shape[0], mean.shape[1]
         nz = self._noise(stage, pass_, sample, row_offset)
-        out = e.empty(M, n)
+        if eps is None and self.eps_source is not None:
+            eps = self._src_eps(M, n, pass_, sample, nz.stage, row_offset)
         eps_t = e.tensor(eps, (M, n)) if eps is not None else None
-        e.check(e.lib.efe_reparameterize(e.ctx, _ptr(mean), _ptr(logvar), M, n, C.byref(nz), _ptr(eps_t), _ptr(out), e.stream()))
-        return out
+        return e.ops.reparameterize(e.h, mean, logvar, self._seed64(), nz.stage, pass_, sample, nz.row_offset, eps_t)
 
     def imagine_future_from_o(self, o0, pi):
         """torchmodel.py:216-220"""
@@ -379,13 +409,14 @@ class ActiveInferenceModel:
         s0 = e.tensor(s0, (-1, self.s_dim)); pi0 = e.tensor(pi0, (-1, self.pi_dim))
         M = s0.shape[0]
         nz = self._noise(stage, 0, 0, row_offset)
-        G, terms = e.empty(M), e.empty(3, M)
-        ps1, ps1_mean, po1 = e.empty(M, 10), e.empty(M, 10), e.empty(M, 1, 64, 64)
         S = 1 if _mean_mode else int(samples)
+        if S < 1:
+            raise RuntimeError('efe engine: samples must be >= 1')
+        if eps is None and self.eps_source is not None:
+            eps = self._src_eps_calcG(M, S, nz.stage, row_offset)
         eps_t = e.tensor(eps, (3 * S, M, 10)) if eps is not None else None
-        parts = e.empty(2, M) if _parts is not None else None
-        e.check(e.lib.efe_calculate_g(e.ctx, _ptr(s0), _ptr(pi0), M, S, 1 if _mean_mode else 0, C.byref(nz), _ptr(eps_t),
-                                      _ptr(G), _ptr(terms), _ptr(ps1), _ptr(ps1_mean), _ptr(po1), _ptr(parts), e.stream()))
+        G, terms, ps1, ps1_mean, po1, parts = e.ops.calculate_g(e.h, s0, pi0, S, bool(_mean_mode), self._seed64(), nz.stage,
+                                                                nz.row_offset, eps_t)
         if _parts is not None:
             _parts.append(parts)
         if _mean_mode:
@@ -402,12 +433,21 @@ class ActiveInferenceModel:
         M = o.shape[0]
         if pi.shape[0] != M:
             raise ValueError('o and pi must have the same number of rows')
+        steps, samples = int(steps), int(samples)
+        if steps < 1 or samples < 1:
+            raise RuntimeError('efe engine: steps and samples must be >= 1')
         nz = self._noise(self._take_stage(stage, steps), 0, 0, row_offset)
-        sum_G, sum_terms, po1 = e.empty(M), e.empty(3, M), e.empty(M, 1, 64, 64)
+        S_eff = 1 if (per_stage_mean and calc_mean) else samples
+        if eps is None and self.eps_source is not None:
+            parts = [self._src_eps(M, 10, PASS_ROOT, 0, nz.stage, row_offset).reshape(-1)]
+            parts += [self._src_eps_calcG(M, S_eff, nz.stage + t, row_offset).reshape(-1) for t in range(steps)]
+            eps = np.concatenate(parts)
         eps_t = e.tensor(eps).reshape(-1) if eps is not None else None
-        e.check(e.lib.efe_rollout(e.ctx, _ptr(o), _ptr(pi), M, int(steps), int(samples), 1 if calc_mean else 0,
-                                  1 if per_stage_mean else 0, C.byref(nz), _ptr(eps_t), _ptr(sum_G), _ptr(sum_terms), _ptr(po1),
-                                  e.stream()))
+        if eps_t is not None and eps_t.numel() != M * 10 + steps * 3 * S_eff * M * 10:
+            raise ValueError(f'eps has {eps_t.numel()} elements, efe_rollout expects M*10 + steps*3*S*M*10 = '
+                             f'{M * 10 + steps * 3 * S_eff * M * 10}')
+        sum_G, sum_terms, po1 = e.ops.rollout(e.h, o, pi, steps, samples, bool(calc_mean), bool(per_stage_mean), self._seed64(), nz.stage,
+                                              nz.row_offset, eps_t)
         return sum_G, [sum_terms[0], sum_terms[1], sum_terms[2]], po1
 
     def calculate_G_repeated(self, o, pi, steps=1, calc_mean=False, samples=10, *, stage=None, eps=None, row_offset=None):
@@ -429,34 +469,42 @@ class ActiveInferenceModel:
         lv = e.tensor(ps1_logvar_traj, (-1, 10)); pi0 = e.tensor(pi0_traj, (-1, 4))
         T = s0.shape[0]
         nz = self._noise(stage, 0, 0, row_offset)
-        G = e.empty(T)
+        if eps is None and self.eps_source is not None:
+            eps = self._src_eps_calcG(T, 1, nz.stage, row_offset)      # the T1 slot is unused in trajectory mode
         eps_t = e.tensor(eps, (3, T, 10)) if eps is not None else None
-        e.check(e.lib.efe_trajectory(e.ctx, _ptr(s0), _ptr(ps1), _ptr(mean), _ptr(lv), _ptr(pi0), T, C.byref(nz), _ptr(eps_t), _ptr(G), e.stream()))
-        return G
+        return e.ops.trajectory(e.h, s0, ps1, mean, lv, pi0, self._seed64(), nz.stage, nz.row_offset, eps_t)
 
-    def simulate_batch(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None):
-        """mcts_step_simulate for E lock-step episodes -> (G[E], pi0[E,depth,4], Qpi0[E,4])"""
+    def simulate_batch(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None, eps=None, u=None):
+        """mcts_step_simulate for E lock-step episodes -> (G[E], pi0[E,depth,4], Qpi0[E,4]).
+        eps: optional injected normals, flat [depth*E*10 (step transitions)] + [3*E*depth*10 (trajectory T1/T2/D2B)];
+        u: optional injected action uniforms [depth, E]."""
         e = self._ready()
         s = e.tensor(starting_s, (-1, 10))
-        E = s.shape[0]
+        E, T = s.shape[0], int(depth)
         nz = self._noise(stage, 0, 0, row_offset)
-        G, pi0, q0 = e.empty(E), e.empty(E, depth, 4), e.empty(E, 4)
-        e.check(e.lib.efe_simulate(e.ctx, _ptr(s), E, int(depth), 1 if use_means else 0, C.byref(nz), _ptr(G), _ptr(pi0), _ptr(q0), e.stream()))
-        return G, pi0, q0
+        ro = self.row_offset if row_offset is None else int(row_offset)
+        if eps is None and self.eps_source is not None:
+            parts = [self._src_eps(E, 10, PASS_SIM, t, nz.stage, ro).reshape(-1) for t in range(T)]
+            parts.append(self._src_eps_calcG(E * T, 1, nz.stage, ro * T).reshape(-1))
+            eps = np.concatenate(parts)
+        if u is None and self.u_source is not None:
+            u = np.stack([np.asarray(self.u_source(self.seed, E, PASS_HABIT, t, nz.stage, ro), dtype=np.float32) for t in range(T)], 0)
+        eps_t = e.tensor(eps).reshape(-1) if eps is not None else None
+        if eps_t is not None and eps_t.numel() != 4 * T * E * 10:
+            raise ValueError(f'eps has {eps_t.numel()} elements, efe_simulate expects depth*E*10 + 3*E*depth*10 = {4 * T * E * 10}')
+        u_t = e.tensor(u, (T, E)) if u is not None else None
+        return e.ops.simulate(e.h, s, T, bool(use_means), self._seed64(), nz.stage, nz.row_offset, eps_t, u_t)
 
-    def mcts_step_simulate(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None):
+    def mcts_step_simulate(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None, eps=None, u=None):
         """torchmodel.py:354-393 -> (float G, pi0[depth,4], Qpi[4])"""
-        G, pi0, q0 = self.simulate_batch(self._engine.tensor(starting_s, (1, 10)), depth, use_means, stage=stage, row_offset=row_offset)
+        G, pi0, q0 = self.simulate_batch(self._engine.tensor(starting_s, (1, 10)), depth, use_means, stage=stage, row_offset=row_offset,
+                                         eps=eps, u=u)
         return G[0].item(), pi0[0], q0[0]
 
     def action_posterior(self, sum_G, single_values=4, temperature=10.0):
         """softmax_multi_with_log(-sum_G, 4) (/root/reference/src/util.py:46-53,68) -> (P, logP) [n,4] on device"""
         e = self._ready()
-        g = e.tensor(sum_G).reshape(-1)
-        n = g.numel() // single_values
-        P, logP = e.empty(n, single_values), e.empty(n, single_values)
-        e.check(e.lib.efe_action_posterior(e.ctx, _ptr(g), n, single_values, float(temperature), _ptr(P), _ptr(logP), e.stream()))
-        return P, logP
+        return e.ops.action_posterior(e.h, e.tensor(sum_G).reshape(-1), int(single_values), float(temperature))
 
     PROF_CLASSES = ('transition_mlp', 'dec_dense_small', 'dec_dense_16384', 'unused3', 'dec_a_convT1_convT2',
                     'dec_b_convT3_final_reduce', 'unused6', 'encoder', 'other')

@@ -12,7 +12,12 @@
  *   - no ownership transfer: the caller allocates every input/output buffer; the engine owns only
  *     its packed weights and a scratch arena.  Calls are stream-ordered on `stream` (a hipStream_t
  *     passed as void*; NULL = default stream) and return without synchronising, unless the arena must
- *     grow (first call at a new size).  One context per device per host thread.
+ *     grow (first call at a new size; efe_reserve pre-sizes it so that steady-state calls never hipMalloc).
+ *   - threading / streams: a context has ONE scratch arena.  Entry points take a per-context mutex, so
+ *     several host threads may share a context (their calls serialise); a call issued on a different
+ *     stream than the previous call first waits (hipStreamWaitEvent) for that call's last kernel, so
+ *     switching streams is safe and costs one event wait.  For concurrent execution on several streams
+ *     use one context per stream (weights are 21 MB).
  *   - return value: 0 on success, non-zero on error (efe_last_error() gives the message).
  *   - noise: MC-dropout masks / normals / action uniforms are a pure function of
  *     (seed, stage, pass, sample, global row = row_offset + r, element) -- see csrc/philox.h --
@@ -33,17 +38,28 @@ typedef struct efe_ctx efe_ctx;
 int efe_create(efe_ctx** out, int device);                       /* ActiveInferenceModel.__init__, torchmodel.py:150-165 */
 void efe_destroy(efe_ctx* ctx);
 const char* efe_last_error(efe_ctx* ctx);
-int efe_abi_version(void);
+int efe_abi_version(void);                                       /* 2 */
+/* hex digest of the sources this library was compiled from (build.py stamps it; the Python loader refuses a library whose
+ * digest differs from the sources next to it, so a stale shipped binary fails loudly). */
+const char* efe_build_id(void);
 
 /* weights: reference state_dict tensors (host, reference layout), key = "<top|mid|down>.<state_dict key>",
  * e.g. "down.po_net.13.weight" (ConvTranspose2d [Cin,Cout,3,3]).  Replaces load_weights,
  * torchmodel.py:173-177 (the .pth unpickling stays in Python).  efe_commit_weights packs them into the
- * MFMA fragment-major device layout. */
+ * MFMA fragment-major device layout.  The host copies are kept: after a commit a caller may update any subset of
+ * tensors with efe_set_weight and commit again; the packed buffers of the previous commit are freed (no growth). */
 int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const int64_t* shape, int ndim);
 int efe_commit_weights(efe_ctx* ctx);
 
 /* options: "dec_chunk" (decoder rows per launch group), "enc_chunk". */
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value);
+
+/* scratch arena: efe_reserve makes the arena one block of >= bytes (synchronises once); efe_rollout_scratch_bytes is what
+ * efe_rollout(M, steps, samples) needs with the current chunk options; efe_arena_stats reports capacity, the largest use
+ * of any call so far and how many hipMalloc calls the arena has made (outputs may be NULL). */
+int efe_reserve(efe_ctx* ctx, int64_t bytes);
+int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples);
+int efe_arena_stats(efe_ctx* ctx, int64_t* capacity_bytes, int64_t* high_water_bytes, int64_t* grow_count);
 
 typedef struct efe_noise {
     uint64_t seed;
@@ -100,9 +116,11 @@ int efe_trajectory(efe_ctx*, const float* s0_traj, const float* ps1_traj, const 
 /* mcts_step_simulate (torchmodel.py:354-393) for E lock-step episodes: habit-policy rollout of `depth`
  * steps from starting_s[E,10], then G over each trajectory.  Noise rows: steps use global row
  * row_offset+e (sample = t); trajectory rows use (row_offset+e)*depth + t.
+ * eps: optional injected normals [depth][E][10] (the transition of step t) followed by [3][E*depth][10] (the trajectory's
+ *      T1 slot (unused), T2, D2B -- the layout of efe_trajectory); u: optional injected action uniforms [depth][E].
  * outputs: G_mean[E], pi0[E,depth,4] one-hot, Qpi0[E,4] (habit posterior of the first step). */
 int efe_simulate(efe_ctx*, const float* starting_s, int E, int depth, int use_means, const efe_noise* nz,
-                 float* G_mean, float* pi0, float* Qpi0, void* stream);
+                 const float* eps, const float* u, float* G_mean, float* pi0, float* Qpi0, void* stream);
 
 /* softmax_multi_with_log(-sum_G, n) (/root/reference/src/util.py:46-53,68): action posterior. */
 int efe_action_posterior(efe_ctx*, const float* sum_G /*[n_groups*n]*/, int n_groups, int n, float temperature,
@@ -112,11 +130,14 @@ int efe_action_posterior(efe_ctx*, const float* sum_G /*[n_groups*n]*/, int n_gr
  * state [E,7] = (colour, shape, scale, orientation, x, y, accumulated reward), last_r [E]; all device pointers.
  * No engine weights are involved: these calls work on any context.
  *   efe_env_reset : randomize_environment_all (:72-75), latents / reward / last_r drawn from Philox(seed, stage).
+ *   efe_env_new_image: new_image_all (:83-88): fresh latents from Philox(seed, stage); reward slot and last_r untouched
+ *                   (what the reference constructor calls, :21).
  *   efe_env_step  : pi_to_action(actions[e], e, repeats) for every game (:113-169); a finished round resamples the
  *                   latents (new_image, :84-87) from Philox(seed, stage); round_changed [E] may be NULL.
  *   efe_env_render: s_to_o (:44-54): frames[e] = imgs[index(state[e])] (uint8 -> float, imgs is [n_imgs,64,64] uint8)
  *                   with the reward bar; err[e] = 1 where |last_r| > 1 (the reference raises ValueError), may be NULL. */
 int efe_env_reset(efe_ctx*, float* state, float* last_r, int E, const efe_noise* nz, void* stream);
+int efe_env_new_image(efe_ctx*, float* state, int E, const efe_noise* nz, void* stream);
 int efe_env_step(efe_ctx*, float* state, float* last_r, const int32_t* actions, int E, int repeats, const efe_noise* nz,
                  int32_t* round_changed, void* stream);
 int efe_env_render(efe_ctx*, const float* state, const float* last_r, const uint8_t* imgs, int64_t n_imgs, float* frames,

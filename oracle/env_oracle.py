@@ -1,6 +1,6 @@
 """ORACLE -- test infrastructure only.  CPU restatement (numpy, per-game loops) of the Dynamic-dSprites environment
 of /root/reference/src/game_environment.py, rows the engine mirrors in csrc/kernels.hip (k_env_*):
-  randomize_environment_all (:72-75), tick (:113-117), up/down/left/right (:119-152), pi_to_action (:154-169),
+  new_image_all (:83-88), randomize_environment_all (:72-75), tick (:113-117), up/down/left/right (:119-152), pi_to_action (:154-169),
   new_image (:84-87), s_to_index / s_to_o (:39-54; the port's index rule dot(s, [1,3,6,40,32,32]) is replicated as is).
 Random latents come from the Philox stream (tag 0x60, pass 9) instead of torch's global generator.
 Pinned against the reference Game itself (patched np.load / torch.randint / torch.rand) by oracle/make_golden.py."""
@@ -35,6 +35,15 @@ def reset(seed, n_games, stage, game_offset=0):
         s[e, 6] = np.float32(-10.0) + np.float32(env_u(seed, g, stage, 6)) * np.float32(20.0)
         last_r[e] = np.float32(-1.0) + np.float32(env_u(seed, g, stage, 7)) * np.float32(2.0)
     return s, last_r
+
+
+def new_image_all(seed, s, stage, game_offset=0):
+    """new_image_all (:83-88), in place: fresh latents for every game; the accumulated reward (slot 6) is carried over.
+    What the reference constructor calls (:21) on a zero state: reward 0, last_r 0."""
+    for e in range(len(s)):
+        for k in range(6):
+            s[e, k] = env_randint(seed, game_offset + e, stage, k)
+    return s
 
 
 def step(seed, s, last_r, actions, repeats, stage, game_offset=0):

@@ -309,6 +309,68 @@ def main():
                  all_paths=ap, all_paths_G=np.asarray(all_G, dtype=np.float64), **meta)
             report[f'mcts_{tag}'] = dict(path=[int(x) for x in path], reps=int(reps), n_paths=len(all_paths))
 
+        # ---------------- tree policy with the habit prior in the exploration bonus (mcts.py:44-45) ---------------
+        params = ref_mcts.MCTS_Params()
+        params.repeats, params.simulation_depth, params.use_means, params.threshold = 7, 3, True, 0.9
+        params.using_prior_for_exploration = True
+        frame = torch.from_numpy(synth.make_frames(24, 1)[0, 0][:, :, None].copy())
+        inj.stage = 200
+        inj.p_enc(PX.PASS_ROOT, 0, inj.stage, 0, with_eps=False); inj.stage += 1
+        path, reps, explored, all_paths, all_G = ref_mcts.active_inference_mcts(model, frame, params, o_shape=(1, 64, 64))
+        assert not inj.q
+        ap = np.full((len(all_paths), 10), -1, dtype=np.int64)
+        for i, p_ in enumerate(all_paths):
+            ap[i, :len(p_)] = [int(x) for x in p_]
+        save('mcts_prior', frame=frame, repeats=7, simulation_depth=3, use_means=True, threshold=0.9, stage=200,
+             final_path=np.asarray(path, dtype=np.int64), repeats_done=reps, states_explored=explored,
+             all_paths=ap, all_paths_G=np.asarray(all_G, dtype=np.float64), **meta)
+        report['mcts_prior'] = dict(path=[int(x) for x in path], reps=int(reps), n_paths=len(all_paths))
+
+        # ---------------- BASELINE configs[2] shape: Node.expand(samples=10), 8 independent episodes ---------------
+        # The reference planner hard-wires expand(samples=1) (mcts.py:172,184) although Node.expand takes `samples` (mcts.py:64):
+        # the default is patched to 10 here, nothing else.  Episode e draws its noise at global rows 4e+a (expansions), e
+        # (root encode, simulate steps) and e*depth+t (trajectory), exactly what the lock-step planner uses.
+        E_B, S_B, REP_B, DEP_B, THR_B = 8, 10, 8, 5, 0.3
+        orig_expand = ref_mcts.Node.expand
+        orig_init = ref_mcts.Node.__init__
+        created = []
+
+        def expand10(self, use_means=False, samples=S_B):
+            return orig_expand(self, use_means=use_means, samples=samples)
+
+        def init_capture(self, *a, **k):
+            orig_init(self, *a, **k)
+            created.append(self)
+        ref_mcts.Node.expand = expand10
+        ref_mcts.Node.__init__ = init_capture
+        frames_b = synth.make_frames(25, E_B)
+        fp = np.full((E_B, REP_B + 2), -1, dtype=np.int64); apb = np.full((E_B, REP_B, REP_B + 2), -1, dtype=np.int64)
+        agb = np.zeros((E_B, REP_B), dtype=np.float64); npaths = np.zeros(E_B, dtype=np.int64)
+        repd = np.zeros(E_B, dtype=np.int64); expl = np.zeros(E_B, dtype=np.int64); rootN = np.zeros((E_B, 4), dtype=np.float32)
+        for e in range(E_B):
+            params = ref_mcts.MCTS_Params()
+            params.repeats, params.simulation_depth, params.use_means, params.threshold = REP_B, DEP_B, False, THR_B
+            state['ro'], state['episode'] = 4 * e, e
+            inj.stage = 300
+            inj.p_enc(PX.PASS_ROOT, 0, inj.stage, e, with_eps=False); inj.stage += 1
+            del created[:]
+            frame = torch.from_numpy(frames_b[e, 0][:, :, None].copy())
+            path, reps, explored, all_paths, all_G = ref_mcts.active_inference_mcts(model, frame, params, o_shape=(1, 64, 64))
+            assert not inj.q
+            fp[e, :len(path)] = [int(x) for x in path]
+            for i, p_ in enumerate(all_paths):
+                apb[e, i, :len(p_)] = [int(x) for x in p_]
+            agb[e, :len(all_G)] = all_G
+            npaths[e], repd[e], expl[e] = len(all_paths), reps, explored
+            rootN[e] = created[0].N.numpy()
+        ref_mcts.Node.expand = orig_expand
+        ref_mcts.Node.__init__ = orig_init
+        state['ro'], state['episode'] = 0, 0
+        save('mcts_batch_s10', frames=frames_b, episodes=E_B, samples=S_B, repeats=REP_B, simulation_depth=DEP_B, threshold=THR_B,
+             stage=300, final_path=fp, all_paths=apb, all_paths_G=agb, n_paths=npaths, repeats_done=repd, states_explored=expl,
+             root_N=rootN, **meta)
+        report['mcts_batch_s10'] = dict(reps=[int(x) for x in repd], n_paths=[int(x) for x in npaths])
+
     with open(os.path.join(GOLD, 'MANIFEST.json'), 'w') as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print(json.dumps(report, indent=1))

@@ -58,6 +58,8 @@ def main():
     G, T, REPEATS = 6, 6, 2
     with contextlib.redirect_stdout(io.StringIO()):
         games = Game(G)                                   # __init__ draws (new_image_all) use stage 1000
+        s_init, r_init = games.current_s.numpy().copy(), games.last_r.numpy().copy()
+        assert np.array_equal(s_init, EV.new_image_all(SEED, np.zeros((G, 7), np.float32), 1000)) and not r_init.any(), 'constructor mismatch'
         ctx.update(stage=0, k=0, rand_blk=6)
         games.randomize_environment_all()
     np.load = np_load
@@ -88,7 +90,7 @@ def main():
         f = games.current_frame_all().numpy().copy()
         assert np.array_equal(EV.render(os_, or_, bank), f)
         states.append(os_.copy()); rs.append(or_.copy()); frames.append(f[..., 0]); changed.append(ch)
-    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'env.npz'), seed=SEED, s_reset=s_reset, r_reset=r_reset, s_in=s_in,
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'env.npz'), seed=SEED, s_init=s_init, r_init=r_init, init_stage=1000, s_reset=s_reset, r_reset=r_reset, s_in=s_in,
                         r_in=r_in, frames_in=frames_in[..., 0], actions=actions, repeats=REPEATS, states=np.stack(states),
                         last_r=np.stack(rs), frames=np.stack(frames), changed=np.stack(changed))
     print('env golden written; rounds finished per step:', [int(c.sum()) for c in changed])

@@ -64,3 +64,31 @@ def test_host_softmax_matches_golden(golden):
     P, logP = softmax_multi_with_log(-g['sum_G'], 4)
     np.testing.assert_allclose(P, g['Ppi'], rtol=1e-6)
     np.testing.assert_allclose(logP, g['logPpi'], rtol=1e-6, atol=1e-6)
+
+
+def test_torch_ops_library_registers_every_op():
+    """torch.ops.efe.* (SURVEY 8b item 1): the registration library builds, loads without a GPU and carries the schemas;
+    no CPU kernel exists, so a CPU call is a loud NotImplementedError (no fallback)."""
+    import torch
+    import __graft_entry__ as ge
+    ge.build()
+    from daimc_amd import _lib
+    ops = _lib.load_ops()
+    want = {'transition', 'decoder', 'encoder', 'habit', 'calculate_g', 'rollout', 'trajectory', 'simulate', 'action_posterior',
+            'check_reward', 'reparameterize'}
+    for n in want:
+        schema = str(getattr(ops, n).default._schema)
+        assert schema.startswith(f'efe::{n}(int ctx, Tensor'), schema
+    assert 'Tensor? eps' in str(ops.calculate_g.default._schema) and 'int row_offset' in str(ops.rollout.default._schema)
+    with pytest.raises(NotImplementedError):
+        ops.habit(1, torch.zeros(2, 10))
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """a binary whose embedded source digest differs from the sources next to it must not load"""
+    from daimc_amd import _lib, build
+    assert build._stamp(_lib.LIB_PATH, 'EFE_BUILD_ID') == build.source_digest()
+    monkeypatch.setattr(build, 'source_digest', lambda files=None: '0' * 16)
+    monkeypatch.setattr(_lib, '_lib', None)
+    with pytest.raises(ImportError, match='stale'):
+        _lib.load()

@@ -11,6 +11,8 @@ from oracle import env_oracle as EV
 def test_env_oracle_vs_reference_fixture():
     g = load_golden('env')
     seed = int(g['seed'])
+    assert np.array_equal(EV.new_image_all(seed, np.zeros((6, 7), np.float32), int(g['init_stage'])), g['s_init'])   # constructor state
+    assert not g['r_init'].any() and not g['s_init'][:, 6].any()
     s, r = EV.reset(seed, 6, 0)
     assert np.array_equal(s, g['s_reset']) and np.array_equal(r, g['r_reset'])
     bank = EV.sprite_bank()
@@ -35,7 +37,9 @@ def test_env_render_rejects_out_of_range_reward():
 def test_env_kernels_vs_reference_fixture():
     import daimc_amd
     g = load_golden('env')
-    games = daimc_amd.Game(6, device='cuda:0', seed=int(g['seed']))
+    games = daimc_amd.Game(6, device='cuda:0', seed=int(g['seed']), init_stage=int(g['init_stage']))
+    # the constructor is new_image_all (game_environment.py:21): fresh latents, reward 0, last_r 0
+    assert np.array_equal(games.current_s.cpu().numpy(), g['s_init']) and np.array_equal(games.last_r.cpu().numpy(), g['r_init'])
     games.randomize_environment_all(stage=0)
     assert np.array_equal(games.current_s.cpu().numpy(), g['s_reset']) and np.array_equal(games.last_r.cpu().numpy(), g['r_reset'])
     games.current_s.copy_(torch.from_numpy(g['s_in'])); games.last_r.copy_(torch.from_numpy(g['r_in']))

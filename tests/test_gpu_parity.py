@@ -4,6 +4,8 @@
 Tolerances (fp32, stated per SURVEY 8c): network outputs rtol 1e-5 / atol 2e-6 (+ sigmoid outputs atol 1e-5);
 term0/term1 atol 1e-3; term2 and G: atol = 5e-6 * max(|term2_1|, 1) + 1e-3 (term2 is a cancelling
 difference of two 4096-pixel sums)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -31,8 +33,16 @@ def models(weights_cache):
         m = cache[key]
         m.seed = int(seed)
         m.row_offset = 0
+        m.eps_source, m.u_source = None, None
         return m
     return get
+
+
+def inject(m):
+    """injected-noise mode for whole planners: every call builds its normals / uniforms from the numpy Philox mirror, so both
+    sides consume bit-identical noise (the device generator's Box-Muller differs from numpy's libm by an ulp)"""
+    m.eps_source, m.u_source = PX.normals, PX.uniforms
+    return m
 
 
 def _model(g, models):
@@ -151,26 +161,34 @@ def test_rollout4_vs_golden(golden, models, name):
 def test_simulate_vs_golden(golden, models, name):
     g = golden(name)
     m = _model(g, models)
-    G, pi0, q = m.mcts_step_simulate(g['start'], int(g['depth']), use_means=bool(g['use_means']), stage=int(g['stage']),
-                                     row_offset=int(g['episode']))
+    seed, st, ep, T = int(g['nseed']), int(g['stage']), int(g['episode']), int(g['depth'])
+    # injected normals / uniforms in the layout of efe_simulate: step transitions, then the trajectory's (T1 unused, T2, D2B)
+    eps = np.concatenate([PX.normals(seed, 1, 10, PX.PASS_SIM, t, st, ep).reshape(-1) for t in range(T)]
+                         + [eps_calcG(seed, T, 1, st, ep * T).reshape(-1)])
+    u = np.stack([PX.uniforms(seed, 1, PX.PASS_HABIT, t, st, ep) for t in range(T)])
+    G, pi0, q = m.mcts_step_simulate(g['start'], T, use_means=bool(g['use_means']), stage=st, row_offset=ep, eps=eps, u=u)
     assert np.array_equal(c(pi0), g['pi0'])                 # same actions sampled (Philox uniform + habit posterior)
     np.testing.assert_allclose(c(q), g['Qpi'], rtol=1e-5, atol=1e-6)
-    assert abs(G - float(g['G'])) < 0.05                    # device-generated normals (no injection on this path)
+    assert abs(G - float(g['G'])) < gtol(np.array([2800.0]))
+    # device-generated noise (Philox + Box-Muller on the GPU): same actions, G within the libm difference of the normals
+    G2, pi02, _ = m.mcts_step_simulate(g['start'], T, use_means=bool(g['use_means']), stage=st, row_offset=ep)
+    assert np.array_equal(c(pi02), g['pi0']) and abs(G2 - float(g['G'])) < 5e-3
 
 
-@pytest.mark.parametrize('name', ['mcts_means', 'mcts_samples'])
+@pytest.mark.parametrize('name', ['mcts_means', 'mcts_samples', 'mcts_prior'])
 def test_mcts_vs_golden(golden, models, name):
     import daimc_amd
     g = golden(name)
-    m = _model(g, models)
+    m = inject(_model(g, models))
     p = daimc_amd.MCTS_Params()
     p.repeats, p.simulation_depth, p.use_means, p.threshold = int(g['repeats']), int(g['simulation_depth']), bool(g['use_means']), float(g['threshold'])
+    p.using_prior_for_exploration = (name == 'mcts_prior')
     m._stage = int(g['stage'])
     path, reps, explored, all_paths, all_G = daimc_amd.active_inference_mcts(m, torch.from_numpy(g['frame']), p, o_shape=(1, 64, 64))
     assert reps == int(g['repeats_done']) and explored == int(g['states_explored'])
     ref_paths = [[int(a) for a in row if a >= 0] for row in g['all_paths']]
     assert [[int(a) for a in pth] for pth in all_paths] == ref_paths
-    np.testing.assert_allclose(np.array(all_G), g['all_paths_G'], atol=0.05)
+    np.testing.assert_allclose(np.array(all_G), g['all_paths_G'], atol=gtol(np.array([2800.0])))
     assert [int(a) for a in path] == [int(a) for a in g['final_path']]
 
 
@@ -255,36 +273,42 @@ def test_full_size_properties(models):
     assert not torch.equal(G1, G3)
 
 
-def test_dropout_statistics(models):
-    """device-Philox mode validated statistically: mean of G over many noise stages vs the oracle's"""
-    seed = 5
+def test_device_noise_mode_vs_oracle(models, weights_cache):
+    """production noise mode (masks AND normals generated on the device from Philox, nothing injected) against the oracle
+    consuming the same Philox stream through the numpy mirror: the only difference is Box-Muller's libm (an ulp on the
+    normals), so G agrees to ~1e-3 per stage; checked over 6 noise stages, which also shows the MC spread between stages
+    is real (stages differ by far more than the tolerance)."""
+    seed, S = 5, 4
+    w = weights_cache(1234, 1.0)
     m = models(1234, 1.0, seed)
+    orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
     s0 = np.tile(PX.uniform_fill(9, (1, 10), 77, -1, 1), (4, 1))
     gs = []
-    for st in range(48):
-        G, _, _, _, _ = m.calculate_G(s0, m.pi_one_hot, samples=4, stage=st)
+    for st in range(6):
+        G, _, _, _, _ = m.calculate_G(s0, m.pi_one_hot, samples=S, stage=st)
+        with torch.no_grad():
+            oG = orc.calculate_G(torch.from_numpy(s0), torch.eye(4), S, st)[0]
+        np.testing.assert_allclose(c(G), oG.numpy(), atol=gtol(orc.last_term2_parts[0].numpy()) + 4e-3)
         gs.append(c(G))
     gs = np.stack(gs)
-    assert np.isfinite(gs).all()
-    se = gs.std(0) / np.sqrt(len(gs))
-    # rows differ only by the action; spread across stages is MC noise -> std error bounded
-    assert (se < 10).all()
+    assert (gs.std(0) > 0.05).all()          # different stages = different MC noise
 
 
-@pytest.mark.parametrize('name', ['mcts_means', 'mcts_samples'])
+@pytest.mark.parametrize('name', ['mcts_means', 'mcts_samples', 'mcts_prior'])
 def test_batched_mcts_single_episode_equals_golden(golden, models, name):
     """the lock-step planner with E = 1 reproduces the reference's single-episode decision"""
     import daimc_amd
     g = golden(name)
-    m = _model(g, models)
+    m = inject(_model(g, models))
     p = daimc_amd.MCTS_Params()
     p.repeats, p.simulation_depth, p.use_means, p.threshold = int(g['repeats']), int(g['simulation_depth']), bool(g['use_means']), float(g['threshold'])
+    p.using_prior_for_exploration = (name == 'mcts_prior')
     m._stage = int(g['stage'])
     out, dist = daimc_amd.active_inference_mcts_batch(m, torch.from_numpy(g['frame'])[None], p, o_shape=(1, 64, 64))
     path, reps, explored, all_paths, all_G = out[0]
     assert reps == int(g['repeats_done']) and explored == int(g['states_explored'])
     assert all_paths == [[int(a) for a in row if a >= 0] for row in g['all_paths']]
-    np.testing.assert_allclose(np.array(all_G), g['all_paths_G'], atol=0.05)
+    np.testing.assert_allclose(np.array(all_G), g['all_paths_G'], atol=gtol(np.array([2800.0])))
     assert [int(a) for a in path] == [int(a) for a in g['final_path']]
     np.testing.assert_allclose(dist.sum(1).numpy(), 1.0, rtol=1e-6)
 
@@ -473,7 +497,7 @@ def test_simulate_batch_vs_oracle_per_episode(models, weights_cache):
     """E lock-step episodes == E independent reference-style simulations (global episode keys)"""
     seed, st, E, T = 71, 12, 3, 4
     w = weights_cache(1234, 1.15)
-    m = models(1234, 1.15, seed)
+    m = inject(models(1234, 1.15, seed))
     starts = PX.uniform_fill(8, (E, 10), 910, -1, 1)
     G, pi0, q0 = m.simulate_batch(starts, T, use_means=False, stage=st, row_offset=5)
     orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
@@ -482,7 +506,7 @@ def test_simulate_batch_vs_oracle_per_episode(models, weights_cache):
             oG, opi0, oq = orc.mcts_step_simulate(torch.from_numpy(starts[e]), T, False, st, episode=5 + e)
         assert np.array_equal(c(pi0[e]), opi0.numpy())
         np.testing.assert_allclose(c(q0[e]), oq.numpy(), rtol=1e-5, atol=1e-6)
-        assert abs(float(G[e]) - oG) < 0.05
+        assert abs(float(G[e]) - oG) < gtol(np.array([2800.0]))
 
 
 def test_mcts_habit_shortcut_and_prior_exploration(models):
@@ -571,9 +595,9 @@ def test_mcts_tree_kernels_vs_host_torch(models):
                     q = W[ep, cur] / N[ep, cur]
                     q = q - q.min()
                     q = q / q.sum()
-                    bonus = 1.5 / N[ep, cur]
+                    bonus = 1.5 * 1.0 / N[ep, cur]
                     if use_prior:
-                        bonus = Qpi[ep, cur] * bonus
+                        bonus = 1.5 * Qpi[ep, cur] * 1.0 / N[ep, cur]      # mcts.py:45, left to right
                     a = int(torch.argmax(q + bonus))
                     path.append((cur, a))
                     cur = int(child[ep, cur, a])
@@ -590,3 +614,109 @@ def test_mcts_tree_kernels_vs_host_torch(models):
     done = active.bool() & ((dist.max(dim=1).values - dist.mean(dim=1)) > 0.2)
     assert torch.equal(act2.cpu().bool(), active.bool() & ~done)
     assert torch.equal(stop_at.cpu() == 7, done) and int(n_act.item()) == int((active.bool() & ~done).sum())
+
+
+# ------------------------------------------------------------------------------------------------------
+# the benchmarked configuration itself, pinned at full size
+# ------------------------------------------------------------------------------------------------------
+def test_full_size_cfg2_vs_oracle(models, weights_cache):
+    """BASELINE configs[1] exactly as bench.py runs it -- 128 rows (32 roots x 4 actions), depth 5, 10 MC samples, one
+    efe_rollout call -- against the CPU oracle on the same seeded inputs (about 20 s of host time)."""
+    seed, st, M, D, S = 1, 0, 128, 5, 10
+    w = weights_cache(1234, 1.15)
+    m = models(1234, 1.15, seed)
+    orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
+    o = np.repeat(synth.make_frames(41, M // 4), 4, axis=0)
+    pi = np.tile(np.eye(4, dtype=np.float32), (M // 4, 1))
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    with torch.no_grad():
+        oG, oT, opo1 = orc.calculate_G_repeated(torch.from_numpy(o), torch.from_numpy(pi), D, False, S, st)
+    G, T, po1 = m.calculate_G_repeated(o, pi, steps=D, samples=S, stage=st, eps=eps_rollout(seed, M, D, S, st))
+    np.testing.assert_allclose(c(T[0]), oT[0].numpy(), atol=5e-3)
+    np.testing.assert_allclose(c(T[1]), oT[1].numpy(), atol=5e-3)
+    np.testing.assert_allclose(c(G), oG.numpy(), atol=D * gtol(np.array([2800.0])))
+    np.testing.assert_allclose(c(po1), opo1.numpy(), rtol=1e-5, atol=5e-5)
+    P, _ = m.action_posterior(G)
+    oP, _ = EO.softmax_multi_with_log(-oG.numpy(), 4)
+    np.testing.assert_allclose(c(P), oP, atol=2e-3)
+
+
+def test_reserve_no_growth(models):
+    """efe_reserve + efe_rollout_scratch_bytes: after reserving for a rollout size, calls at that size never grow the arena"""
+    import daimc_amd
+    m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=2)
+    need = m.reserve(24, 3, 4)
+    st0 = m.arena_stats()
+    assert st0['capacity_bytes'] >= need
+    o = synth.make_frames(35, 24)
+    pi = np.eye(4, dtype=np.float32)[np.arange(24) % 4]
+    for k in range(3):
+        m.calculate_G_repeated(o, pi, steps=3, samples=4, stage=10 * k)
+    torch.cuda.synchronize()
+    st1 = m.arena_stats()
+    assert st1['grow_count'] == st0['grow_count'] and st1['capacity_bytes'] == st0['capacity_bytes']
+    assert 0 < st1['high_water_bytes'] <= need
+
+
+def test_stream_switch_is_ordered(models):
+    """one context, calls alternating between two torch streams: the engine orders a call behind the previous call's
+    stream (the scratch arena is shared), so results equal the single-stream ones"""
+    m = models(1234, 1.15, 14)
+    o = synth.make_frames(36, 12)
+    pi = np.eye(4, dtype=np.float32)[np.arange(12) % 4]
+    ref = [m.calculate_G_repeated(o, pi, steps=2, samples=3, stage=4 * k)[0].clone() for k in range(4)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ot, pit = torch.from_numpy(o).cuda(), torch.from_numpy(pi).cuda()
+    torch.cuda.synchronize()
+    got = []
+    for k in range(4):
+        with torch.cuda.stream(s1 if k % 2 == 0 else s2):
+            got.append(m.calculate_G_repeated(ot, pit, steps=2, samples=3, stage=4 * k)[0])
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+
+
+def test_recommit_updates_one_tensor_without_leaking(models):
+    import ctypes as C
+    import daimc_amd
+    m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=4)
+    s = PX.uniform_fill(8, (4, 10), 930, -1, 1)
+    a = m.model_down.decoder(s, stage=0)
+    e = m._ready()
+    # C-ABI user: change ONE tensor and commit again (the host copies of the others are kept)
+    b4 = np.array([0.25], dtype=np.float32)
+    shape = (C.c_int64 * 1)(1)
+    e.check(e.lib.efe_set_weight(e.ctx, b'down.po_net.19.bias', b4.ctypes.data_as(C.c_void_p), shape, 1))
+    e.check(e.lib.efe_commit_weights(e.ctx))
+    b = m.model_down.decoder(s, stage=0)
+    assert not torch.equal(a, b)
+    sd = m.model_down.state_dict(); sd['po_net.19.bias'] = torch.tensor([0.25])
+    m.model_down.load_state_dict(sd)
+    assert torch.equal(m.model_down.decoder(s, stage=0), b)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):                                   # 6 x 21 MB of packed weights would show as 128 MB
+        m.model_down.load_state_dict(sd)
+        m.model_down.decoder(s, stage=0)
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 32 * 2 ** 20
+
+
+def test_torch_ops_are_the_dispatch_path(models):
+    """torch.ops.efe.* (csrc/torch_ops.cpp): registered schemas, called directly with device tensors, equal the mirror's results"""
+    m = models(1234, 1.15, 19)
+    e = m._ready()
+    ops = torch.ops.efe
+    for name in ('transition', 'decoder', 'encoder', 'habit', 'calculate_g', 'rollout', 'trajectory', 'simulate', 'action_posterior',
+                 'check_reward', 'reparameterize'):
+        assert hasattr(ops, name)
+    s0 = torch.from_numpy(PX.uniform_fill(8, (4, 10), 940, -1, 1)).cuda()
+    G, terms, ps1, ps1m, po1, parts = ops.calculate_g(e.h, s0, m.pi_one_hot, 3, False, 19, 7, 0, None)
+    G2, t2, ps12, _, po12 = m.calculate_G(s0, m.pi_one_hot, samples=3, stage=7)
+    assert torch.equal(G, G2) and torch.equal(po1, po12) and torch.equal(ps1, ps12)
+    with pytest.raises(NotImplementedError):
+        ops.habit(e.h, s0.cpu())                          # no CPU kernel is registered: no fallback
+    with pytest.raises(RuntimeError):
+        ops.calculate_g(e.h, s0, m.pi_one_hot, 0, False, 19, 7, 0, None)

@@ -132,3 +132,42 @@ def test_convtranspose_subpixel_restatement():
                     src = xp[:, da:da + n, db:db + n]                      # in[a+da, b+db]
                     out[0, :, ph::2, pw::2] += np.einsum('iab,io->oab', src, w[:, :, kh, kw])
     np.testing.assert_allclose(out, ref, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the oracle planner (oracle/mcts_oracle.py) against the fixtures captured from the reference planner
+# ------------------------------------------------------------------------------------------------------
+def _paths(arr):
+    return [[int(a) for a in row if a >= 0] for row in arr]
+
+
+@pytest.mark.parametrize('name', ['mcts_means', 'mcts_samples', 'mcts_prior'])
+def test_oracle_planner_vs_reference(golden, weights_cache, name):
+    from oracle import mcts_oracle as MO
+    g = golden(name)
+    m = _oracle(g, weights_cache)
+    p = MO.Params(repeats=int(g['repeats']), simulation_depth=int(g['simulation_depth']), use_means=bool(g['use_means']),
+                  threshold=float(g['threshold']), using_prior_for_exploration=(name == 'mcts_prior'))
+    path, reps, explored, all_paths, all_G, _ = MO.plan(m, torch.from_numpy(g['frame']), p, int(g['stage']))
+    assert reps == int(g['repeats_done']) and explored == int(g['states_explored'])
+    assert all_paths == _paths(g['all_paths'])
+    np.testing.assert_allclose(np.array(all_G), g['all_paths_G'], atol=1e-3)
+    assert path == [int(a) for a in g['final_path']]
+
+
+@pytest.mark.parametrize('e', [1, 6])
+def test_oracle_planner_ten_samples_vs_reference(golden, weights_cache, e):
+    """BASELINE configs[2] shape (Node.expand(samples=10), simulation depth 5), episode e of the 8-episode fixture
+    (episode 1 stops early, episode 6 runs all repeats)"""
+    from oracle import mcts_oracle as MO
+    g = golden('mcts_batch_s10')
+    m = _oracle(g, weights_cache)
+    p = MO.Params(repeats=int(g['repeats']), simulation_depth=int(g['simulation_depth']), use_means=False,
+                  threshold=float(g['threshold']), samples=int(g['samples']))
+    path, reps, explored, all_paths, all_G, root_N = MO.plan(m, torch.from_numpy(g['frames'][e]), p, int(g['stage']), episode=e)
+    n = int(g['n_paths'][e])
+    assert reps == int(g['repeats_done'][e]) and explored == int(g['states_explored'][e]) and len(all_paths) == n
+    assert all_paths == _paths(g['all_paths'][e][:n])
+    np.testing.assert_allclose(np.array(all_G), g['all_paths_G'][e][:n], atol=1e-3)
+    assert path == [int(a) for a in g['final_path'][e] if a >= 0]
+    assert np.array_equal(root_N.numpy(), g['root_N'][e])
