@@ -53,3 +53,16 @@ def eps_rollout(seed, M, D, S, stage0, row_offset=0):
     for t in range(D):
         parts.append(eps_calcG(seed, M, S, stage0 + t, row_offset).reshape(-1))
     return np.concatenate(parts)
+
+
+def usable_cores():
+    """cores this process may actually use: affinity mask capped by the cgroup CPU quota (oversubscribing torch's intra-op
+    pool on a quota-limited container stalls it)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, n)

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import eps_calcG, eps_rollout
+from conftest import eps_calcG, eps_rollout, usable_cores
 from oracle import philox as PX
 from oracle import synth
 from oracle import efe_oracle as EO
@@ -628,7 +628,7 @@ def test_full_size_cfg2_vs_oracle(models, weights_cache):
     orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
     o = np.repeat(synth.make_frames(41, M // 4), 4, axis=0)
     pi = np.tile(np.eye(4, dtype=np.float32), (M // 4, 1))
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(usable_cores())
     with torch.no_grad():
         oG, oT, opo1 = orc.calculate_G_repeated(torch.from_numpy(o), torch.from_numpy(pi), D, False, S, st)
     G, T, po1 = m.calculate_G_repeated(o, pi, steps=D, samples=S, stage=st, eps=eps_rollout(seed, M, D, S, st))

@@ -50,6 +50,7 @@ def _worker(rank, world, port, out_dir):
     os.environ['MASTER_PORT'] = str(port)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch.distributed as dist
+    torch.set_num_threads(2)
     multi = torch.cuda.device_count() >= world
     dev = torch.device('cuda', rank if multi else 0)
     torch.cuda.set_device(dev)
