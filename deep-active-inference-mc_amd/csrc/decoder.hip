@@ -226,11 +226,12 @@ __global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) 
 }
 
 constexpr size_t DA_LDS_BYTES = (257 * 16 + 33) * sizeof(float4);
+int init_dec_b_kernels();
 // kernels that need more than the default 64 KiB of dynamic LDS: set once per device (called from efe_create)
 int init_decoder_kernels() {
     if (hipFuncSetAttribute((const void*)(k_dec_a<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)(k_dec_a<1>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES) != hipSuccess) return 1;
-    return 0;
+    return init_dec_b_kernels();
 }
 
 void launch_dec_a(const DecAArgs& a, hipStream_t st) {
@@ -293,7 +294,10 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
     // wave -> (row group rp, parity group pg).  pg 0 contracts 5 tap-tiles per row, pg 1 only 4, and waves w and w+4 share a
     // SIMD: flip pg for the upper four waves so every SIMD gets one heavy and one light wave (otherwise two SIMDs of the CU
     // carry 25 % more MFMA work than the other two and everyone waits for them at the strip barrier).
-    const int rp = w >> 1, pg = (NW == 8 ? (w ^ (w >> 2)) : w) & 1;
+    const int rp = w >> 1;
+#ifndef EFE_X_FLIP
+    const int pg = (NW == 8 ? (w ^ (w >> 2)) : w) & 1;
+#endif
     const int img = blockIdx.x;
 
     const int mg = a.m0 + img;
@@ -311,7 +315,13 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
     float w4f[16];
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {                   // register e holds channel co = (e&3) + 8*(e>>2) + 4h: four contiguous floats per e>>2
+#ifdef EFE_X_TAP3             // experiment: tap t = 3*(i>>2) + (i&3) in A row i (rows 3, 7, 11, 12-15 are padding): three taps per 16-lane group
+        const int ti_ = lane & 15;
+        const bool tv_ = (ti_ & 3) < 3 && ti_ < 12;
+        const float4 q = tv_ ? reinterpret_cast<const float4*>(a.w4 + (3 * (ti_ >> 2) + (ti_ & 3)) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+#else
         const float4 q = ((lane & 15) < 9) ? reinterpret_cast<const float4*>(a.w4 + (lane & 15) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         w4f[4 * g4] = q.x; w4f[4 * g4 + 1] = q.y; w4f[4 * g4 + 2] = q.z; w4f[4 * g4 + 3] = q.w;   // A_b[i = tap = lane&15], b>>1 = h
     }
     if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -342,6 +352,7 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
         }
         __syncthreads();
         TLB(1);
+#ifndef EFE_X_PF_LATE
         {   // request strip s+1 now (it lands during the MFMA phase); rows >= 32 are clamped here and zeroed when staged
             const int sn = (s < NS - 1) ? s + 1 : NS - 1;
 #pragma unroll
@@ -351,8 +362,12 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
                 pf[it] = Xv[y2_at(grow, idx)];
             }
         }
+#endif
 
         // ---- MFMA phase: wave (rp, pg) owns local rows 2rp, 2rp+1 and two of the four output parities
+#ifdef EFE_X_FLIP             // experiment: heavy (5 tap-tiles) / light (4) roles alternate every strip
+        const int pg = ((NW == 8 ? (w ^ (w >> 2)) : w) ^ s) & 1;
+#endif
 #pragma unroll 1
         for (int pi = 0; pi < 2; ++pi) {
             const int par = pg ? (pi ? 2 : 1) : (pi ? 0 : 3);          // pg0: (1,1),(0,0)   pg1: (0,1),(1,0)
@@ -403,6 +418,17 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
 #endif
                 const int tq = lane >> 4, c = lane & 15;               // this lane holds taps 4*tq + r
                 const int orow = 2 * (SR * s + RW * rp + nt) + ph;
+#ifdef EFE_X_TAP3
+                float* tp3 = sT + ((orow % DB_YROWS) * 9 + 3 * tq) * TS + 1 + pw;
+                if (tq < 3) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 3; ++r4) {
+                        tp3[r4 * TS + 2 * c] = T[r4] + T[8 + r4];
+                        tp3[r4 * TS + 2 * (16 + c)] = T[4 + r4] + T[12 + r4];
+                    }
+                }
+                continue;
+#endif
                 float* tp = sT + ((orow % DB_YROWS) * 9 + 4 * tq) * TS + 1 + pw;
                 if (tq < 2) {
 #pragma unroll
@@ -419,6 +445,17 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
         }
         __syncthreads();
         TLB(4);
+#ifdef EFE_X_PF_LATE          // experiment: request strip s+1 after the MFMA phase (vmcnt retires in order: issued before the tap loops, the
+        {                     // HBM loads sit in front of every weight-fragment wait of the strip); the gather covers their latency
+            const int sn = (s < NS - 1) ? s + 1 : NS - 1;
+#pragma unroll
+            for (int it = 0; it < NPF; ++it) {
+                const int idx = it * NTHR + tid;
+                const int grow = min(SR * sn + (idx >> 9), 31);
+                pf[it] = Xv[y2_at(grow, idx)];
+            }
+        }
+#endif
 
         // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete now (row 63 after the last strip).  One output row
         // per wave and pass (row index wave-uniform: scalar branches only), 9 unconditional LDS reads per pixel -- the zero
@@ -470,10 +507,255 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_dec_b4: the same layer pair, INPUT-STATIONARY.  One wave owns one input row of the strip (32 positions) and ALL FOUR output
+// parities of it.  The nine (kh, kw) taps of the stride-2 transposed conv read only four shifted views of the input,
+//     shift (0,0): taps of parities (0,0) (0,1) (1,0) (1,1)      shift (0,+1): parities (0,1) (1,1)
+//     shift (+1,0): parities (1,0) (1,1)                          shift (+1,+1): parity (1,1)
+// so a B fragment (LDS) is read once per shift and chunk and feeds up to four INDEPENDENT accumulator chains (4 / 2 / 2 / 1
+// weight fragments): 9 tap-tiles per wave for every wave (the parity-pair split of k_dec_b gives 5 and 4), 4 LDS reads per chunk
+// instead of 9, and back-to-back MFMAs never wait on their own accumulator.  SR = 4 input rows per strip, 4 waves, two workgroups
+// per CU (65 KiB LDS, <= 256 VGPRs).
+// ---------------------------------------------------------------------------------------------------------
+#ifndef EFE_B4_WAVES
+#define EFE_B4_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) {
+    constexpr int SR = 4, NW = 4, NTHR = 256;
+    constexpr int DB_ZERO = (SR + 1) * 32;
+    constexpr int DB_IN_F4 = (DB_ZERO + 1) * 16;
+    constexpr int DB_YROWS = 2 * SR + 2;
+    constexpr int NPF = (SR + 1) * 512 / NTHR;        // 10 float4s of the input strip per thread
+    constexpr int NS = 32 / SR;
+    extern __shared__ __attribute__((aligned(16))) float4 sm[];
+    constexpr int TS = 66;
+    float* sT = reinterpret_cast<float*>(sm + DB_IN_F4);
+    __shared__ float sred[NW];
+    __shared__ float4 sb3[8];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int img = blockIdx.x;
+
+    const int mg = a.m0 + img;
+    const int g = mg / a.rows_per_group;
+    const int r = mg - g * a.rows_per_group;
+    int gt, gp, gs;
+    group_decode(a.gm, g, gt, gp, gs);
+    const int mode = (gp == 0 && a.reward0) ? 1 : 0;
+    const int slot = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
+    float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + r) * 4096 : nullptr;
+
+    if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];
+    float w4f[16];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 q = ((lane & 15) < 9) ? reinterpret_cast<const float4*>(a.w4 + (lane & 15) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+        w4f[4 * g4] = q.x; w4f[4 * g4 + 1] = q.y; w4f[4 * g4 + 2] = q.z; w4f[4 * g4 + 3] = q.w;
+    }
+    if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < DB_YROWS * 9 * 2; i += NTHR) sT[(i >> 1) * TS + (i & 1) * (TS - 1)] = 0.f;
+
+    const float4* X = reinterpret_cast<const float4*>(a.y2) + (size_t)img * (32 * 32 * 16);
+    const float4* W3 = reinterpret_cast<const float4*>(a.w3);
+    const __amdgpu_buffer_rsrc_t wr = wrsrc(W3);
+    const unsigned ln = (unsigned)lane * 16u;
+    const float D1 = 1.00001f, D0 = 0.00001f;
+    float part = 0.f;
+    f32x4 pf[NPF];
+    f32x4* smv = reinterpret_cast<f32x4*>(sm);
+    const f32x4* Xv = reinterpret_cast<const f32x4*>(X);
+    auto y2_at = [&](int iy, int idx) -> size_t { return (size_t)(((iy & 1) * 16 + ((idx & 511) >> 5)) * 512 + (iy >> 1) * 32 + (idx & 31)); };
+#pragma unroll
+    for (int it = 0; it < NPF; ++it) { const int idx = it * NTHR + tid; pf[it] = Xv[y2_at(min(idx >> 9, 31), idx)]; }
+
+    // the four shifted B views of this wave's row: LDS float4 base and swizzle key
+    const int spA = w * 32 + j;                                   // (row w,     col j)
+    const int spB = (j < 31) ? w * 32 + j + 1 : DB_ZERO;          // (row w,     col j + 1)   (column 32 does not exist)
+    const int spC = (w + 1) * 32 + j;                             // (row w + 1, col j)
+    const int spD = (j < 31) ? (w + 1) * 32 + j + 1 : DB_ZERO;    // (row w + 1, col j + 1)
+    // packed-weight tap indices kh * 3 + kw: parity p = 2 * ph + pw
+    //   shift A: p0 (1,1)=4  p1 (1,2)=5  p2 (2,1)=7  p3 (2,2)=8 | shift B: p1 (1,0)=3  p3 (2,0)=6 | shift C: p2 (0,1)=1  p3 (0,2)=2 | shift D: p3 (0,0)=0
+    auto wf = [&](int tap, int kc) -> float4 { return wfrag(wr, ln, (size_t)(tap * 8 + kc) * 64); };
+
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int idx = it * NTHR + tid;
+            const int rl = idx >> 9, seg = (idx & 511) >> 5, wi = idx & 31;
+            const int ix = 2 * (wi >> 1) + (seg >> 3), c4 = 2 * (seg & 7) + (wi & 1);
+            smv[swz(rl * 32 + ix, c4)] = (SR * s + rl < 32) ? pf[it] : (f32x4)(0.f);
+        }
+        float4 a0 = wf(4, 0), a1 = wf(5, 0), a2 = wf(7, 0), a3 = wf(8, 0);      // the strip's first weight fragments: in flight across the barrier
+        __syncthreads();
+#ifndef EFE_B4_PF_LATE
+        {   // request strip s+1 (rows >= 32 are clamped here and zeroed when staged)
+            const int sn = (s < NS - 1) ? s + 1 : NS - 1;
+#pragma unroll
+            for (int it = 0; it < NPF; ++it) {
+                const int idx = it * NTHR + tid;
+                const int grow = min(SR * sn + (idx >> 9), 31);
+                pf[it] = Xv[y2_at(grow, idx)];
+            }
+        }
+#endif
+
+        f32x16 acc[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 bb = sb3[2 * g4 + h];
+#pragma unroll
+            for (int p_ = 0; p_ < 4; ++p_) { acc[p_][4 * g4] = bb.x; acc[p_][4 * g4 + 1] = bb.y; acc[p_][4 * g4 + 2] = bb.z; acc[p_][4 * g4 + 3] = bb.w; }
+        }
+        // ---- contraction, software-pipelined one chunk ahead: shift A (4 chains), shift B (2), shifts C + D fused (2 + 1, so the
+        // single-chain shift never runs alone).  The first weight fragments were requested before the staging barrier.
+        {
+            float4 b = sm[spA * 16 + (h ^ (spA & 15))];
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const float4 c0 = a0, c1 = a1, c2 = a2, c3 = a3, cb = b;
+                if (kc < 7) {
+                    a0 = wf(4, kc + 1); a1 = wf(5, kc + 1); a2 = wf(7, kc + 1); a3 = wf(8, kc + 1);
+                    b = sm[spA * 16 + ((2 * (kc + 1) + h) ^ (spA & 15))];
+                } else {
+                    a0 = wf(3, 0); a1 = wf(6, 0);
+                    b = sm[spB * 16 + (h ^ (spB & 15))];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                MFMA4(acc[0], c0, cb) MFMA4(acc[1], c1, cb) MFMA4(acc[2], c2, cb) MFMA4(acc[3], c3, cb)
+            }
+            float4 bd;
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const float4 c0 = a0, c1 = a1, cb = b;
+                if (kc < 7) {
+                    a0 = wf(3, kc + 1); a1 = wf(6, kc + 1);
+                    b = sm[spB * 16 + ((2 * (kc + 1) + h) ^ (spB & 15))];
+                } else {
+                    a0 = wf(1, 0); a1 = wf(2, 0); a2 = wf(0, 0);
+                    b = sm[spC * 16 + (h ^ (spC & 15))];
+                    bd = sm[spD * 16 + (h ^ (spD & 15))];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                MFMA4(acc[1], c0, cb) MFMA4(acc[3], c1, cb)
+            }
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const float4 c0 = a0, c1 = a1, c2 = a2, cb = b, cd = bd;
+                if (kc < 7) {
+                    a0 = wf(1, kc + 1); a1 = wf(2, kc + 1); a2 = wf(0, kc + 1);
+                    b = sm[spC * 16 + ((2 * (kc + 1) + h) ^ (spC & 15))];
+                    bd = sm[spD * 16 + ((2 * (kc + 1) + h) ^ (spD & 15))];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                MFMA4(acc[3], c1, cb) MFMA4(acc[2], c0, cb) MFMA4(acc[3], c2, cd)
+            }
+        }
+        // ---- ReLU, then the 32 -> 1 conv as tap planes: 16 x v_mfma_f32_16x16x1_4b per parity, the four parities' chains interleaved
+        f32x16 T2[4];
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[p_][e] = relu_bits(acc[p_][e]); T2[p_][e] = 0.f; }
+        }
+#ifdef EFE_X_NO_TMFMA
+#pragma unroll
+        for (int p_ = 0; p_ < 4; ++p_) T2[p_] = acc[p_];
+#else
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+#pragma unroll
+            for (int p_ = 0; p_ < 4; ++p_) T2[p_] = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[p_][e], T2[p_], 0, 0, 0);
+        }
+#endif
+#ifdef EFE_X_NO_TWRITE
+        if (T2[0][0] == 12345.678f) sT[lane] = T2[1][1] + T2[2][2] + T2[3][3];
+#else
+        {
+            const int tq = lane >> 4, c = lane & 15;
+#pragma unroll
+            for (int p_ = 0; p_ < 4; ++p_) {
+                const int ph = p_ >> 1, pw = p_ & 1;
+                const f32x16 T = T2[p_];
+                const int orow = 2 * (SR * s + w) + ph;
+                float* tp = sT + ((orow % DB_YROWS) * 9 + 4 * tq) * TS + 1 + pw;
+                if (tq < 2) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        tp[r4 * TS + 2 * c] = T[r4] + T[8 + r4];
+                        tp[r4 * TS + 2 * (16 + c)] = T[4 + r4] + T[12 + r4];
+                    }
+                } else if (tq == 2) {
+                    tp[2 * c] = T[0] + T[8];
+                    tp[2 * (16 + c)] = T[4] + T[12];
+                }
+            }
+        }
+#endif
+        __syncthreads();
+#ifdef EFE_B4_PF_LATE
+        {   // request strip s+1 behind the MFMA phase (vmcnt retires in order: an HBM load in front of the weight-fragment loads stalls them)
+            const int sn = (s < NS - 1) ? s + 1 : NS - 1;
+#pragma unroll
+            for (int it = 0; it < NPF; ++it) {
+                const int idx = it * NTHR + tid;
+                const int grow = min(SR * sn + (idx >> 9), 31);
+                pf[it] = Xv[y2_at(grow, idx)];
+            }
+        }
+#endif
+
+        // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete (row 63 after the last strip)
+        constexpr int RWG = 2 * SR / NW;
+        const int nq = (a.dbg & 2) ? 0 : (s == NS - 1) ? RWG + 1 : RWG;
+        for (int q = 0; q < nq; ++q) {
+            if (q == RWG && w != 0) break;
+            const int oh = 2 * SR * s - 1 + q * NW + w, ow = lane;
+            if (oh < 0) continue;
+            float tv[9];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int tr = oh + 1 - kh;
+                const bool rv = tr >= 0 && tr <= 63;
+                const float* trow = sT + (((rv ? tr : 0) % DB_YROWS) * 9 + kh * 3) * TS + ow + 2;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) tv[kh * 3 + kw] = rv ? trow[kw * TS - kw] : 0.f;
+            }
+            float v = a.b4;
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) v += tv[t9];
+            const float pr = 1.0f / (1.0f + EFE_EXP(-v));
+            if (po) {
+                int owl = ow; asm volatile("" : "+v"(owl));
+                (po + oh * 64)[owl] = pr;
+            }
+            if (mode == 0) part += -(1.0f - pr) * EFE_LOG(D1 - pr) - pr * EFE_LOG(D0 + pr);
+            else
+                part += (oh < 32) ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f) : pr * logf(D0) + (1.0f - pr) * logf(D1);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) sred[w] = part;
+    __syncthreads();
+    if (tid == 0) a.val[mg] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+constexpr size_t DB_LDS4 = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 66 * sizeof(float);
+int init_dec_b_kernels() {
+    if (hipFuncSetAttribute((const void*)(k_dec_b4), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)(k_dec_b<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)(k_dec_b<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4) != hipSuccess) return 1;
+    return 0;
+}
+
 void launch_dec_b(const DecBArgs& a, hipStream_t st) {
     const size_t lds4 = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 66 * sizeof(float);
     const size_t lds2 = ((3 * 32 + 1) * 16) * sizeof(float4) + 6 * 9 * 66 * sizeof(float);
-    if (!(a.dbg & 24)) {        // default: 2-row strips, four one-row waves per workgroup, 38 KiB LDS: four workgroups (four independent
+    if (a.dbg & 32) {           // input-stationary form: one wave = one strip row x four parities (four accumulator chains per B fragment)
+        hipLaunchKernelGGL(k_dec_b4, dim3(a.rows), dim3(256), lds4, st, a);
+    } else if (!(a.dbg & 24)) {        // default: 2-row strips, four one-row waves per workgroup, 38 KiB LDS: four workgroups (four independent
                                 // barrier domains) and 16 waves per CU.  Measured 0.795 of the fp32 MFMA peak (k_dec_b alone, 19200 images)
         hipLaunchKernelGGL((k_dec_b<2, 1>), dim3(a.rows), dim3(256), lds2, st, a);
     } else if (a.dbg & 8) {     // 4-row strips, eight one-row waves, two workgroups per CU: 0.767

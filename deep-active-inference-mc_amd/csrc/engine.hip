@@ -48,6 +48,8 @@ struct efe_ctx {
     std::map<std::string, HostTensor> raw;
     bool committed = false;
     Layer top[3], mid[4], enc_conv[3], enc_fc[4], dec_fc[4], dec_ct[3];
+    MlpW mid16{}, top16{};         // the same transition / habit weights packed for the fused 16x16x4 kernels (fused.hip)
+    int64_t mid_unfused = 0;       // option: 1 = layer-by-layer k_dense transition (A/B experiments)
     float *enc_w1 = nullptr, *enc_b1 = nullptr, *dec_wf = nullptr;
     float dec_bf = 0.f;
     float* zeros = nullptr;
@@ -157,6 +159,30 @@ int pack_linear(efe_ctx* ctx, Layer& L, const std::string& key, int out, int in,
         b->data.data(), row_perm);
 }
 
+// packed for v_mfma_f32_16x16x4_f32 (fused.hip): [16-feature tile][16-channel chunk][lane = (m, q)][s] = W[16 mt + m][16 kc + 4 q + s]
+int pack_linear16(efe_ctx* ctx, const float4*& Wout, const float*& bout, const std::string& key, int out, int in) {
+    const HostTensor* w = need(ctx, key + ".weight", {out, in});
+    const HostTensor* b = need(ctx, key + ".bias", {out});
+    if (!w || !b) return 1;
+    const int mtiles = (out + 15) / 16, KC = (in + 15) / 16;
+    std::vector<float> p((size_t)mtiles * KC * 256, 0.f), bb((size_t)mtiles * 16, 0.f);
+    for (int mt = 0; mt < mtiles; ++mt)
+        for (int kc = 0; kc < KC; ++kc)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    const int co = 16 * mt + (lane & 15), ci = 16 * kc + 4 * (lane >> 4) + s_;
+                    if (co < out && ci < in) p[(((size_t)mt * KC + kc) * 64 + lane) * 4 + s_] = w->data[(size_t)co * in + ci];
+                }
+    for (int co = 0; co < out; ++co) bb[co] = b->data[co];
+    float *dW = nullptr, *dB = nullptr;
+    HIPCHK(hipMalloc((void**)&dW, p.size() * 4)); ctx->wbufs.push_back(dW);
+    HIPCHK(hipMalloc((void**)&dB, bb.size() * 4)); ctx->wbufs.push_back(dB);
+    HIPCHK(hipMemcpy(dW, p.data(), p.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB, bb.data(), bb.size() * 4, hipMemcpyHostToDevice));
+    Wout = reinterpret_cast<const float4*>(dW); bout = dB;
+    return 0;
+}
+
 // ---- launch helpers ----------------------------------------------------------------------------------
 struct NoiseCfg {
     uint32_t k0 = 0, k1 = 0;
@@ -188,6 +214,18 @@ void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float*
 
 // ModelMid.ps_net over M = groups*R rows; X is [R][16], every group reads the same rows (x_mod).
 int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*/, const NoiseCfg& nc, hipStream_t st) {
+    if (!ctx->mid_unfused) {           // one launch for the four layers, activations in LDS (fused.hip)
+        TransFusedArgs a{};
+        a.W = ctx->mid16; a.X = X; a.tr = tr; a.M = M; a.x_mod = x_mod; a.k0 = nc.k0; a.k1 = nc.k1; a.gm = nc.gm;
+        a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = 0;
+        ctx->cls = PROF_MID;
+        hipEvent_t e0 = ctx->prof_begin(st);
+        launch_trans_fused(a, st);
+        ctx->prof_end(e0, st);
+        ctx->cls = PROF_OTHER;
+        ctx->last_macs += (int64_t)M * MAC_TRANS;
+        return 0;
+    }
     float* h1 = ctx->allocT<float>((size_t)M * 512);
     float* h2 = ctx->allocT<float>((size_t)M * 512);
     if (!h1 || !h2) return 1;
@@ -407,7 +445,7 @@ int efe_create(efe_ctx** out, int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return 2;
     if (hipSetDevice(device) != hipSuccess) return 3;
-    if (init_small_kernels() || init_decoder_kernels()) return 5;       // per device: a second context on another GPU needs them too
+    if (init_small_kernels() || init_decoder_kernels() || init_fused_kernels()) return 5;       // per device: a second context on another GPU needs them too
     efe_ctx* ctx = new efe_ctx();
     ctx->device = device;
     if (hipMalloc((void**)&ctx->zeros, 8192) != hipSuccess || hipMemset(ctx->zeros, 0, 8192) != hipSuccess) { delete ctx; return 4; }
@@ -451,6 +489,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "dbg_a")) { ctx->dbg_a = value; return 0; }
     if (!strcmp(name, "dbg_b")) { ctx->dbg_b = value; return 0; }
     if (!strcmp(name, "arena_align")) { if (value < 256 || (value & (value - 1))) return ctx->fail("arena_align must be a power of two >= 256"); ctx->arena_align = value; return 0; }
+    if (!strcmp(name, "mid_unfused")) { ctx->mid_unfused = value; return 0; }
     if (!strcmp(name, "enc_chunk")) { if (value < 1) return ctx->fail("enc_chunk < 1"); ctx->enc_chunk = value; return 0; }
     return ctx->fail(std::string("unknown option ") + name);
 }
@@ -475,6 +514,14 @@ int efe_commit_weights(efe_ctx* ctx) {
     if (pack_linear(ctx, ctx->mid[1], "mid.ps_net.3", 512, 512, nullptr, nullptr)) return 1;
     if (pack_linear(ctx, ctx->mid[2], "mid.ps_net.6", 512, 512, nullptr, nullptr)) return 1;
     if (pack_linear(ctx, ctx->mid[3], "mid.ps_net.9", 20, 512, nullptr, nullptr)) return 1;
+    {   // the same two nets packed for the fused kernels
+        const char* mk[4] = {"mid.ps_net.0", "mid.ps_net.3", "mid.ps_net.6", "mid.ps_net.9"};
+        const int mo[4] = {512, 512, 512, 20}, mi[4] = {14, 512, 512, 512};
+        for (int i = 0; i < 4; ++i) if (pack_linear16(ctx, ctx->mid16.w[i], ctx->mid16.b[i], mk[i], mo[i], mi[i])) return 1;
+        const char* tk[3] = {"top.qpi_net.0", "top.qpi_net.2", "top.qpi_net.4"};
+        const int to[3] = {128, 128, 4}, ti[3] = {10, 128, 128};
+        for (int i = 0; i < 3; ++i) if (pack_linear16(ctx, ctx->top16.w[i], ctx->top16.b[i], tk[i], to[i], ti[i])) return 1;
+    }
     // encoder (torchmodel.py:84-104).  conv1 (Cin = 1) runs on the VALU: w1[tap][co]
     {
         const HostTensor* w = need(ctx, "down.qs_net.0.weight", {32, 1, 3, 3});
@@ -837,36 +884,24 @@ int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int us
     if (!starting_s || !nz || !G_mean || !pi0 || E < 1 || depth < 1 || depth > 65535) return ctx->fail("efe_simulate: bad arguments");
     const uint32_t k0 = (uint32_t)nz->seed, k1 = (uint32_t)(nz->seed >> 32);
     const int T = depth;
-    float* s_cur = ctx->allocT<float>((size_t)2 * E * 10);
     float* s0t = ctx->allocT<float>((size_t)E * T * 10);
     float* ps1t = ctx->allocT<float>((size_t)E * T * 10);
     float* mt = ctx->allocT<float>((size_t)E * T * 10);
     float* lvt = ctx->allocT<float>((size_t)E * T * 10);
-    float* x16 = ctx->allocT<float>((size_t)E * 16);
-    float* l32 = ctx->allocT<float>((size_t)E * 32);
-    float* q = ctx->allocT<float>((size_t)E * 4);
-    float* pit = ctx->allocT<float>((size_t)E * 4);
-    float* tr = ctx->allocT<float>((size_t)E * 32);
     float* Gt = ctx->allocT<float>((size_t)E * T);
-    if (!s_cur || !s0t || !ps1t || !mt || !lvt || !x16 || !l32 || !q || !pit || !tr || !Gt) return 1;
-    HIPCHK(hipMemcpyAsync(s_cur, starting_s, (size_t)E * 10 * 4, hipMemcpyDeviceToDevice, st));
-    float* cur = s_cur; float* nxt = s_cur + (size_t)E * 10;
-    for (int t = 0; t < T; ++t) {
-        const size_t mark_cur = ctx->arena.cur, mark_off = ctx->arena.off, mark_used = ctx->arena.used_total;   // per-step scratch is recycled
-        launch_pad16(cur, x16, E, S_DIM, st);
-        if (run_habit(ctx, x16, E, l32, st)) return 1;
-        launch_softmax4(l32, nullptr, q, nullptr, E, PI_DIM, st);
-        launch_sample_action(q, pit, (t == 0) ? Qpi0 : nullptr, E, PI_DIM, k0, k1, (uint32_t)t, nz->stage, nz->row_offset,
-                             u ? u + (size_t)t * E : nullptr, st);
-        launch_scatter_pi(pit, pi0, E, T, t, PI_DIM, st);
-        launch_pack_x(pit, cur, x16, E, PI_DIM, S_DIM, st);
-        NoiseCfg nc; nc.k0 = k0; nc.k1 = k1; nc.rows_per_group = E; nc.row_offset = nz->row_offset;
-        nc.gm = GroupMap{1, 1, {PASS_SIM, 0, 0}, nz->stage, (uint32_t)t};
-        if (run_mid(ctx, x16, 0, E, tr, nc, st)) return 1;
-        launch_sim_post(tr, eps ? eps + (size_t)t * E * 10 : nullptr, s0t, ps1t, mt, lvt, nxt, cur, E, T, t, use_means, k0, k1, nz->stage,
-                        nz->row_offset, st);
-        std::swap(cur, nxt);
-        ctx->arena.cur = mark_cur; ctx->arena.off = mark_off; ctx->arena.used_total = mark_used;
+    if (!s0t || !ps1t || !mt || !lvt || !Gt) return 1;
+    {   // the whole habit-policy rollout (depth x (encode_s, sample, transition, reparameterise)) is one launch (fused.hip)
+        SimChainArgs sa{};
+        sa.W = ctx->mid16; sa.H = ctx->top16; sa.s0 = starting_s; sa.E = E; sa.T = T; sa.use_means = use_means;
+        sa.k0 = k0; sa.k1 = k1; sa.stage = nz->stage; sa.row_offset = nz->row_offset;
+        sa.eps_inj = eps; sa.u_inj = u;
+        sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0;
+        ctx->cls = PROF_MID;
+        hipEvent_t e0 = ctx->prof_begin(st);
+        launch_sim_chain(sa, st);
+        ctx->prof_end(e0, st);
+        ctx->cls = PROF_OTHER;
+        ctx->last_macs += (int64_t)E * T * (MAC_TRANS + MAC_HABIT);
     }
     if (trajectory_impl(ctx, s0t, ps1t, mt, lvt, pi0, E * T, k0, k1, nz->stage, nz->row_offset * (uint32_t)T,
                         eps ? eps + (size_t)T * E * 10 : nullptr, Gt, st)) return 1;

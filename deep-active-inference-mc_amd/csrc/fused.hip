@@ -1,0 +1,285 @@
+// Fused small-MLP kernels for gfx950: the transition net ModelMid.ps_net (/root/reference/src/torchmodel.py:41-52, 58-61) as ONE
+// launch per stage, and the whole habit-policy rollout of mcts_step_simulate (torchmodel.py:360-390: encode_s -> sample an action
+// -> transition -> reparameterise, `depth` times) as ONE launch.
+//
+// A workgroup (4 waves) owns 16 batch rows and walks them through every layer; activations never leave LDS.  The contraction
+// uses v_mfma_f32_16x16x4_f32 (exact fp32, same FLOP rate as the 32x32x2 form): N = 16 batch rows, so a 2560-row stage is 160
+// workgroups (a 32-row tile would leave 2/3 of the CUs idle), M = 16 features per tile, eight tiles (128 features = one Philox
+// block of the MC-dropout mask) per wave.
+//
+//   weights : packed [16-feature tile][16-channel chunk][64 lanes][4]; lane l = (m = l & 15, q = l >> 4) holds
+//             W[16 mt + m][16 kc + 4 q + s], s = 0..3  -- one coalesced 1 KiB buffer load per (tile, chunk), read from L2
+//   B       : activations in LDS, [row n][512 floats], 16-byte quads XOR-swizzled by the row; lane (n = l & 15, q) reads the quad
+//             16 kc + 4 q .. + 3 with one ds_read_b128; MFMA step s of a chunk contracts channels {16 kc + 4 q + s : q = 0..3}
+//   D       : lane (n, q) holds features 16 mt + 4 q + 0..3 of row n: bias, ReLU, dropout and ONE ds_write_b128 back to LDS
+//
+// The summation order over K is fixed by the layer (never by the batch), so a row's result does not depend on which rows share
+// its launch -- the property the multi-GPU / chunking invariance tests pin.
+#include "kernels.h"
+
+namespace efe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int FR = 16;               // batch rows per workgroup
+constexpr int ACT_F4 = FR * 128;     // one activation buffer: 16 rows x 128 quads (512 floats)
+
+__device__ __forceinline__ int aswz(int n, int c4) { return n * 128 + ((c4 & ~15) | ((c4 ^ n) & 15)); }
+
+__device__ __forceinline__ float4 wfrag16(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned f4_index) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, lane_bytes, f4_index * 16u, 0);
+    return __builtin_bit_cast(float4, v);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc16(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+
+#define MFMA16(ACC, AV, BV)                                                     \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).x, (BV).x, ACC, 0, 0, 0);   \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).y, (BV).y, ACC, 0, 0, 0);   \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).z, (BV).z, ACC, 0, 0, 0);   \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((AV).w, (BV).w, ACC, 0, 0, 0);
+
+// acc[mt] += W[tiles mt0 .. mt0 + NMT) x act over KC 16-channel chunks.  Weight fragments (L2, ~1 us under load) are requested two
+// chunks ahead, the LDS activation fragment one chunk ahead, through THREE statically indexed register buffers (a two-buffer
+// rotation makes hipcc copy every fragment, and the copy waits for the load it was meant to hide); consecutive MFMAs go to
+// DIFFERENT accumulators (the 16x16x4 form has a 40-cycle dependent latency against a 32-cycle issue).
+#define G16_STEP(AU, AL, BU, BL, K)                                                                                          \
+    {                                                                                                                        \
+        const int ka_ = (K) + 2 < KC ? (K) + 2 : KC - 1, kb_ = (K) + 1 < KC ? (K) + 1 : KC - 1;                              \
+        _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) AL[mt] = wfrag16(wr, ln, (unsigned)((mt0 + mt) * KC + ka_) * 64u); \
+        BL = act[aswz(n, 4 * kb_ + q)];                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AU[mt].x, BU.x, acc[mt], 0, 0, 0); \
+        _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AU[mt].y, BU.y, acc[mt], 0, 0, 0); \
+        _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AU[mt].z, BU.z, acc[mt], 0, 0, 0); \
+        _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AU[mt].w, BU.w, acc[mt], 0, 0, 0); \
+    }
+template <int NMT>
+__device__ __forceinline__ void gemm16(f32x4 (&acc)[NMT], const float4* __restrict__ Wp, int mt0, int KC, const float4* act, int n, int q,
+                                       unsigned ln) {
+    const __amdgpu_buffer_rsrc_t wr = rsrc16(Wp);
+    float4 a0[NMT], a1[NMT], a2[NMT], b0, b1, b2;
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) a0[mt] = wfrag16(wr, ln, (unsigned)((mt0 + mt) * KC) * 64u);
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) a1[mt] = wfrag16(wr, ln, (unsigned)((mt0 + mt) * KC + (KC > 1 ? 1 : 0)) * 64u);
+    b0 = act[aswz(n, q)];
+    int kc = 0;
+    for (; kc + 3 <= KC; kc += 3) {
+        G16_STEP(a0, a2, b0, b1, kc)
+        G16_STEP(a1, a0, b1, b2, kc + 1)
+        G16_STEP(a2, a1, b2, b0, kc + 2)
+    }
+    if (kc < KC) G16_STEP(a0, a2, b0, b1, kc)              // KC % 3 tail (uniform branches)
+    if (kc + 1 < KC) G16_STEP(a1, a0, b1, b2, kc + 1)
+}
+#undef G16_STEP
+
+struct RowKey { uint32_t row, stream, stage; };
+
+// hidden layer of one wave: features 16 * mt0 .. + 16 * NMT, bias (+ ReLU) (+ MC-dropout from one Philox block) -> LDS
+template <int NMT, bool RELU, bool DROP>
+__device__ __forceinline__ void hidden16(const float4* __restrict__ Wp, const float* __restrict__ bias, int mt0, int KC, const float4* act_in,
+                                         float4* act_out, int n, int q, unsigned ln, uint32_t k0, uint32_t k1, uint32_t tag, const RowKey& rk) {
+    f32x4 acc[NMT];
+    float4 bq[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+        acc[mt] = (f32x4)(0.f);
+        bq[mt] = *reinterpret_cast<const float4*>(bias + 16 * (mt0 + mt) + 4 * q);
+    }
+    gemm16<NMT>(acc, Wp, mt0, KC, act_in, n, q, ln);
+    uint4 rnd = make_uint4(0u, 0u, 0u, 0u);
+    if (DROP) rnd = noise_words(k0, k1, tag, (uint32_t)((16 * mt0) >> 7), rk.row, rk.stream, rk.stage);     // NMT = 8: one 128-feature block per wave
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+        const int f = 16 * (mt0 + mt) + 4 * q;
+        float v[4] = {acc[mt][0] + bq[mt].x, acc[mt][1] + bq[mt].y, acc[mt][2] + bq[mt].z, acc[mt][3] + bq[mt].w};
+        if (RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        }
+        if (DROP) {
+            const int wsel = (f >> 5) & 3;
+            const uint32_t word = wsel == 0 ? rnd.x : wsel == 1 ? rnd.y : wsel == 2 ? rnd.z : rnd.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((word >> ((f + e) & 31)) & 1u) ? v[e] * 2.0f : 0.0f;
+        }
+        act_out[aswz(n, 4 * (mt0 + mt) + q)] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// the four layers of ps_net for the workgroup's 16 rows: x (in bufA[n][0..15]) -> out [n][0..31] in bufA (features 0..19 real)
+__device__ __forceinline__ void trans_chain(const MlpW& W, float4* bufA, float4* bufB, int w, int n, int q, unsigned ln, uint32_t k0,
+                                            uint32_t k1, const RowKey& rk) {
+    hidden16<8, true, true>(W.w[0], W.b[0], 8 * w, 1, bufA, bufB, n, q, ln, k0, k1, TAG_MID + 0, rk);
+    __syncthreads();
+    hidden16<8, true, true>(W.w[1], W.b[1], 8 * w, 32, bufB, bufA, n, q, ln, k0, k1, TAG_MID + 1, rk);
+    __syncthreads();
+    hidden16<8, true, true>(W.w[2], W.b[2], 8 * w, 32, bufA, bufB, n, q, ln, k0, k1, TAG_MID + 2, rk);
+    __syncthreads();
+    if (w < 2) hidden16<1, false, false>(W.w[3], W.b[3], w, 32, bufB, bufA, n, q, ln, k0, k1, 0u, rk);
+    __syncthreads();
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// k_trans_fused: ModelMid.ps_net over M rows ([group][row] batch; every group may read the same x rows, x_mod).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) k_trans_fused(const TransFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 sm[];
+    float4* bufA = sm;
+    float4* bufB = sm + ACT_F4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const unsigned ln = (unsigned)lane * 16u;
+    const int row0 = blockIdx.x * FR;
+    {   // x rows -> bufA[n][quads 0..3]
+        if (tid < 64) {
+            const int m = row0 + n;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < a.M) {
+                const int r = a.x_mod > 0 ? m % a.x_mod : m;
+                v = reinterpret_cast<const float4*>(a.X + (size_t)r * 16)[q];
+            }
+            bufA[aswz(n, q)] = v;
+        }
+    }
+    RowKey rk;
+    {
+        const int m = min(row0 + n, a.M - 1);
+        const int mg = a.m0 + m;
+        const int g = mg / a.rows_per_group;
+        rk.row = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
+        const uint2 key = group_key(a.gm, g);
+        rk.stream = key.x; rk.stage = key.y;
+    }
+    __syncthreads();
+    trans_chain(a.W, bufA, bufB, w, n, q, ln, a.k0, a.k1, rk);
+    if (tid < 64) {                       // tr[m][32]: mean 0..9, logvar 10..19 (20..31 are the zero-padded features)
+        const int m = row0 + n;
+        if (m < a.M) {
+            reinterpret_cast<float4*>(a.tr + (size_t)m * 32)[q] = bufA[aswz(n, q)];
+            reinterpret_cast<float4*>(a.tr + (size_t)m * 32)[4 + q] = bufA[aswz(n, 4 + q)];
+        }
+    }
+}
+
+void launch_trans_fused(const TransFusedArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_trans_fused, dim3((a.M + FR - 1) / FR), dim3(256), 2 * ACT_F4 * sizeof(float4), st, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_sim_chain: the habit-policy rollout of mcts_step_simulate for 16 episodes per workgroup, all `T` steps in one launch:
+//   q = softmax(qpi_net(s_t));  a_t ~ q (inverse CDF on a Philox / injected uniform; invalid q -> action 0, the reference's bare
+//   except);  (mean, logvar) = ps_net([onehot(a_t) | s_t]) with MC-dropout;  ps1 = eps * exp(logvar / 2) + mean;
+//   s_{t+1} = use_means ? mean : ps1.   Trajectory arrays are [E][T][...] (rows of the trajectory batch that follows).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float4 sm[];
+    float4* bufA = sm;
+    float4* bufB = sm + ACT_F4;
+    float* srow = reinterpret_cast<float*>(sm + 2 * ACT_F4);        // [16 rows][16]: current state s_t (10 used)
+    float* sact = srow + FR * 16;                                   // [16 rows][4]: one-hot action of the step
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const unsigned ln = (unsigned)lane * 16u;
+    const int e0 = blockIdx.x * FR;
+    const int E = a.E, T = a.T;
+    if (tid < FR * 16) {
+        const int rr = tid >> 4, k = tid & 15, e = e0 + rr;
+        srow[tid] = (k < 10 && e < E) ? a.s0[(size_t)e * 10 + k] : 0.f;
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        // ---- habit net (no dropout): x = [s | 0] -> 128 -> 128 -> 4
+        if (tid < 64) bufA[aswz(n, q)] = reinterpret_cast<const float4*>(srow + n * 16)[q];
+        __syncthreads();
+        RowKey none{0u, 0u, 0u};
+        hidden16<2, true, false>(a.H.w[0], a.H.b[0], 2 * w, 1, bufA, bufB, n, q, ln, 0u, 0u, 0u, none);
+        __syncthreads();
+        hidden16<2, true, false>(a.H.w[1], a.H.b[1], 2 * w, 8, bufB, bufA, n, q, ln, 0u, 0u, 0u, none);
+        __syncthreads();
+        if (w == 0) hidden16<1, false, false>(a.H.w[2], a.H.b[2], 0, 8, bufA, bufB, n, q, ln, 0u, 0u, 0u, none);
+        __syncthreads();
+        // ---- softmax (torchmodel.py:28-29), categorical sample (torchmodel.py:364,379), one thread per episode row
+        if (tid < FR) {
+            const int e = e0 + tid;
+            const float4 lg = bufB[aswz(tid, 0)];
+            const float l[4] = {lg.x, lg.y, lg.z, lg.w};
+            float mx = -INFINITY;
+            for (int k = 0; k < 4; ++k) mx = fmaxf(mx, l[k]);
+            float ex[4], sum = 0.f;
+            for (int k = 0; k < 4; ++k) { ex[k] = expf(l[k] - mx); sum += ex[k]; }
+            float qq[4], tot = 0.f; bool bad = false;
+            for (int k = 0; k < 4; ++k) { qq[k] = ex[k] / sum; if (!(qq[k] >= 0.f) || isinf(qq[k])) bad = true; tot += qq[k]; }
+            int act = 0;
+            if (!bad && tot > 0.f) {
+                const float u = a.u_inj ? a.u_inj[(size_t)t * E + min(e, E - 1)]
+                                        : u01(noise_words(a.k0, a.k1, TAG_ACT, 0u, a.row_offset + e, stream_id(PASS_HABIT, (uint32_t)t), a.stage).x);
+                const float thr = u * tot;
+                float accq = 0.f; act = 3;
+                for (int k = 0; k < 4; ++k) { accq += qq[k]; if (thr < accq) { act = k; break; } }
+            } else bad = true;
+            for (int k = 0; k < 4; ++k) {
+                const float oh = (k == act) ? 1.f : 0.f;
+                sact[tid * 4 + k] = oh;
+                if (e < E) {
+                    a.pi0[((size_t)e * T + t) * 4 + k] = oh;
+                    if (t == 0 && a.Qpi0) a.Qpi0[(size_t)e * 4 + k] = bad ? oh : qq[k];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- transition: x = [pi | s | 0 0] (torchmodel.py:59)
+        if (tid < 64) {
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 4 * q + i;
+                v[i] = k < 4 ? sact[n * 4 + k] : k < 14 ? srow[n * 16 + (k - 4)] : 0.f;
+            }
+            bufA[aswz(n, q)] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        RowKey rk{a.row_offset + (uint32_t)(e0 + n), stream_id(PASS_SIM, (uint32_t)t), a.stage};
+        __syncthreads();
+        trans_chain(a.W, bufA, bufB, w, n, q, ln, a.k0, a.k1, rk);
+        // ---- reparameterise and scatter into the trajectory arrays (torchmodel.py:368-376, 382-390)
+        if (tid < FR * 10) {
+            const int rr = tid / 10, k = tid - rr * 10, e = e0 + rr;
+            if (e < E) {
+                const float* o = reinterpret_cast<const float*>(bufA);
+                const float mean = o[4 * aswz(rr, k >> 2) + (k & 3)], lv = o[4 * aswz(rr, (10 + k) >> 2) + ((10 + k) & 3)];
+                const float eps = a.eps_inj ? a.eps_inj[((size_t)t * E + e) * 10 + k]
+                                            : normal_elem(a.k0, a.k1, a.row_offset + e, stream_id(PASS_SIM, (uint32_t)t), a.stage, k);
+                const float samp = eps * expf(lv * 0.5f) + mean;
+                const size_t oo = ((size_t)e * T + t) * 10 + k;
+                a.s0_traj[oo] = srow[rr * 16 + k];
+                a.ps1_traj[oo] = samp; a.mean_traj[oo] = mean; a.lv_traj[oo] = lv;
+                srow[rr * 16 + k] = a.use_means ? mean : samp;          // each (row, k) is read and rewritten by this thread only
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_sim_chain(const SimChainArgs& a, hipStream_t st) {
+    const size_t lds = 2 * ACT_F4 * sizeof(float4) + (FR * 16 + FR * 4) * sizeof(float);
+    hipLaunchKernelGGL(k_sim_chain, dim3((a.E + FR - 1) / FR), dim3(256), lds, st, a);
+}
+
+int init_fused_kernels() {
+    const size_t lds = 2 * ACT_F4 * sizeof(float4) + (FR * 16 + FR * 4) * sizeof(float);
+    if (hipFuncSetAttribute((const void*)k_trans_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ACT_F4 * sizeof(float4)) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_sim_chain, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
+    return 0;
+}
+
+}  // namespace efe

@@ -149,6 +149,32 @@ void launch_mcts_backprop(const MctsTree& t, const int32_t* path_nodes, const in
 void launch_mcts_stop(const MctsTree& t, uint8_t* active, int32_t* stop_at, int repeat, float threshold, int32_t* n_active,
                       hipStream_t st);
 
+// ---- fused small-MLP kernels (fused.hip) ---------------------------------------------------------------------
+// weights packed for v_mfma_f32_16x16x4_f32: [16-feature tile][16-channel chunk][64 lanes][4], biases padded to the tile count
+struct MlpW { const float4* w[4]; const float* b[4]; };
+struct TransFusedArgs {
+    MlpW W;                // ps_net.0 / .3 / .6 / .9
+    const float* X;        // [rows][16] = [pi | s0 | 0 0]
+    float* tr;             // [M][32]: mean 0..9, logvar 10..19
+    int M, x_mod;          // x_mod > 0: input row = m % x_mod (every MC group reads the same rows)
+    uint32_t k0, k1;
+    GroupMap gm; int rows_per_group; uint32_t row_offset; int m0;
+};
+void launch_trans_fused(const TransFusedArgs& a, hipStream_t st);
+struct SimChainArgs {
+    MlpW W, H;             // transition net, habit net (qpi_net.0 / .2 / .4)
+    const float* s0;       // [E][10] starting states
+    int E, T, use_means;
+    uint32_t k0, k1, stage, row_offset;
+    const float* eps_inj;  // nullable [T][E][10]
+    const float* u_inj;    // nullable [T][E]
+    float *s0_traj, *ps1_traj, *mean_traj, *lv_traj;   // [E][T][10]
+    float* pi0;            // [E][T][4] one-hot
+    float* Qpi0;           // nullable [E][4]
+};
+void launch_sim_chain(const SimChainArgs& a, hipStream_t st);
+int init_fused_kernels();
+
 void launch_pack_x(const float* pi, const float* s, float* x, int R, int pi_dim, int s_dim, hipStream_t st);
 void launch_pad16(const float* s, float* x, int R, int s_dim, hipStream_t st);
 void launch_root_post(const float* enc, const float* pi, const float* eps_inj, float* x, float* s_out, int R, int use_mean,
