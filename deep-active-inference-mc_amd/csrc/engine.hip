@@ -20,7 +20,7 @@ using namespace efe;
 
 namespace {
 
-constexpr int S_DIM = 10, PI_DIM = 4;
+constexpr int S_DIM = 10;
 constexpr int64_t MAC_TRANS = 541696, MAC_DEC = 43256320, MAC_ENC = 3868960, MAC_HABIT = 18176;
 
 enum ProfClass { PROF_MID = 0, PROF_DEC_FC = 1, PROF_DEC_FC4 = 2, PROF_CT1 = 3, PROF_CT2 = 4, PROF_CT3 = 5, PROF_FINAL = 6,
@@ -48,6 +48,15 @@ struct efe_ctx {
     std::map<std::string, HostTensor> raw;
     bool committed = false;
     Layer top[3], mid[4], enc_conv[3], enc_fc[4], dec_fc[4], dec_ct[3];
+    // geometry: the reference's Dynamic-dSprites configuration (pi 4, 1 x 64 x 64) runs on the fused kernels; any other
+    // (pi_dim, channels, resolution) runs the generic layer-by-layer convolution path (generic.hip; SURVEY 8a-13, parity unpinned)
+    int pi_dim = 4, chan = 1, res = 64;
+    bool generic = false;
+    int base = 16, enc_hw[5] = {64, 31, 15, 7, 3};
+    size_t img_store = 4096;        // floats per stored D1 image: C*H*W NCHW (dSprites, C = 1) or H*W*8 NHWC8 (generic)
+    Layer g_fc4, g_ct[3], g_enc[4];
+    float* g_wf = nullptr; float g_bf[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t mac_dec = 43256320, mac_enc = 3868960, mac_trans = 541696, mac_habit = 18176;
     MlpW mid16{}, top16{};         // the same transition / habit weights packed for the fused 16x16x4 kernels (fused.hip)
     int64_t mid_unfused = 0;       // option: 1 = layer-by-layer k_dense transition (A/B experiments)
     float *enc_w1 = nullptr, *enc_b1 = nullptr, *dec_wf = nullptr;
@@ -223,7 +232,7 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
         launch_trans_fused(a, st);
         ctx->prof_end(e0, st);
         ctx->cls = PROF_OTHER;
-        ctx->last_macs += (int64_t)M * MAC_TRANS;
+        ctx->last_macs += (int64_t)M * ctx->mac_trans;
         return 0;
     }
     float* h1 = ctx->allocT<float>((size_t)M * 512);
@@ -235,7 +244,90 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
     fc(ctx, ctx->mid[2], h2, 512, 0, h1, 512, M, true, true, TAG_MID + 2, nc, 0, st);
     fc(ctx, ctx->mid[3], h1, 512, 0, tr, 32, M, false, false, 0, nc, 0, st);
     ctx->cls = PROF_OTHER;
-    ctx->last_macs += (int64_t)M * MAC_TRANS;
+    ctx->last_macs += (int64_t)M * ctx->mac_trans;
+    return 0;
+}
+
+// generic geometry (generic.hip): dense head -> Linear(256, 64*B*B) -> ConvT(64,64,s1) -> ConvT(64,64,s2) -> ConvT(64,32,s2) -> final conv
+int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, int reward0, int store0, float* val, float* po_store,
+                  hipStream_t st) {
+    const int B = ctx->base, H2 = 2 * B, H3 = 4 * B;
+    const int C = (int)std::min<int64_t>(std::min<int64_t>(ctx->dec_chunk, 4096), N);
+    float* hA = ctx->allocT<float>((size_t)N * 256);
+    float* hB = ctx->allocT<float>((size_t)N * 256);
+    float* x4 = ctx->allocT<float>((size_t)C * B * B * 64);
+    float* y1 = ctx->allocT<float>((size_t)C * B * B * 64);
+    float* y2 = ctx->allocT<float>((size_t)C * H2 * H2 * 64);
+    float* y3 = ctx->allocT<float>((size_t)C * H3 * H3 * 32);
+    if (!hA || !hB || !x4 || !y1 || !y2 || !y3) return 1;
+    ctx->cls = PROF_DEC_FC;
+    fc(ctx, ctx->dec_fc[0], dec_in, 16, 0, hA, 256, N, true, true, TAG_DEC + 0, nc, 0, st);
+    fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, N, true, true, TAG_DEC + 1, nc, 0, st);
+    fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, N, true, true, TAG_DEC + 2, nc, 0, st);
+    auto conv = [&](const Layer& L, const float* in, float* out, int n, int hin, int cin, int hout, int cout, int mode) {
+        ConvGArgs a{};
+        a.in = in; a.out = out; a.Wp = L.Wp; a.bias = L.bias; a.zeros = ctx->zeros; a.n_img = n; a.Hin = hin; a.Win = hin; a.Cin = cin;
+        a.Hout = hout; a.Wout = hout; a.Cout = cout; a.mtiles = L.mtiles; a.mode = mode; a.relu = 1; a.ldo = cout;
+        hipEvent_t e0 = ctx->prof_begin(st);
+        launch_conv_g(a, st);
+        ctx->prof_end(e0, st);
+    };
+    for (int m0 = 0; m0 < N; m0 += C) {
+        const int c = std::min(C, N - m0);
+        ctx->cls = PROF_DEC_FC4;
+        fc(ctx, ctx->g_fc4, hA + (size_t)m0 * 256, 256, 0, x4, B * B * 64, c, true, true, TAG_DEC + 3, nc, m0, st);
+        ctx->cls = PROF_CT2;
+        conv(ctx->g_ct[0], x4, y1, c, B, 64, B, 64, 1);
+        conv(ctx->g_ct[1], y1, y2, c, B, 64, H2, 64, 2);
+        ctx->cls = PROF_CT3;
+        conv(ctx->g_ct[2], y2, y3, c, H2, 64, H3, 32, 2);
+        FinalGArgs f{};
+        f.y3 = y3; f.w = ctx->g_wf; for (int i = 0; i < 4; ++i) f.b[i] = ctx->g_bf[i];
+        f.rows = c; f.m0 = m0; f.rows_per_group = nc.rows_per_group; f.H = H3; f.W = H3; f.C = ctx->chan; f.gm = nc.gm;
+        f.reward0 = reward0; f.store0 = store0; f.val = val; f.po = po_store;
+        hipEvent_t e0 = ctx->prof_begin(st);
+        launch_final_g(f, st);
+        ctx->prof_end(e0, st);
+    }
+    ctx->cls = PROF_OTHER;
+    ctx->last_macs += (int64_t)N * ctx->mac_dec;
+    return 0;
+}
+
+// generic geometry: o is NHWC8 [N][res*res][8]; four Conv2d(k3,s2,p0)+ReLU, then the dense head
+int run_encoder_g(efe_ctx* ctx, const float* o8, int N, const NoiseCfg& nc, float* enc, hipStream_t st) {
+    const int* hw = ctx->enc_hw;
+    const int C = (int)std::min<int64_t>(std::min<int64_t>(ctx->enc_chunk, 8192), N);
+    float* c1 = ctx->allocT<float>((size_t)C * hw[1] * hw[1] * 32);
+    float* c2 = ctx->allocT<float>((size_t)C * hw[2] * hw[2] * 32);
+    float* c3 = ctx->allocT<float>((size_t)C * hw[3] * hw[3] * 64);
+    float* c4 = ctx->allocT<float>((size_t)C * hw[4] * hw[4] * 64);
+    float* hA = ctx->allocT<float>((size_t)C * 256);
+    float* hB = ctx->allocT<float>((size_t)C * 256);
+    if (!c1 || !c2 || !c3 || !c4 || !hA || !hB) return 1;
+    const int flat = hw[4] * hw[4] * 64;
+    auto conv = [&](const Layer& L, const float* in, float* out, int n, int hin, int cin, int hout, int cout) {
+        ConvGArgs a{};
+        a.in = in; a.out = out; a.Wp = L.Wp; a.bias = L.bias; a.zeros = ctx->zeros; a.n_img = n; a.Hin = hin; a.Win = hin; a.Cin = cin;
+        a.Hout = hout; a.Wout = hout; a.Cout = cout; a.mtiles = L.mtiles; a.mode = 0; a.relu = 1; a.ldo = cout;
+        hipEvent_t e0 = ctx->prof_begin(st);
+        launch_conv_g(a, st);
+        ctx->prof_end(e0, st);
+    };
+    for (int m0 = 0; m0 < N; m0 += C) {
+        const int c = std::min(C, N - m0);
+        ctx->cls = PROF_ENC;
+        conv(ctx->g_enc[0], o8 + (size_t)m0 * hw[0] * hw[0] * 8, c1, c, hw[0], 8, hw[1], 32);
+        conv(ctx->g_enc[1], c1, c2, c, hw[1], 32, hw[2], 32);
+        conv(ctx->g_enc[2], c2, c3, c, hw[2], 32, hw[3], 64);
+        conv(ctx->g_enc[3], c3, c4, c, hw[3], 64, hw[4], 64);
+        fc(ctx, ctx->enc_fc[0], c4, flat, 0, hA, 256, c, true, true, TAG_ENC + 0, nc, m0, st);
+        fc(ctx, ctx->enc_fc[1], hA, 256, 0, hB, 256, c, true, true, TAG_ENC + 1, nc, m0, st);
+        fc(ctx, ctx->enc_fc[2], hB, 256, 0, hA, 256, c, true, true, TAG_ENC + 2, nc, m0, st);
+        fc(ctx, ctx->enc_fc[3], hA, 256, 0, enc + (size_t)m0 * 32, 32, c, false, false, 0, nc, m0, st);
+    }
+    ctx->cls = PROF_OTHER;
+    ctx->last_macs += (int64_t)N * ctx->mac_enc;
     return 0;
 }
 
@@ -244,6 +336,7 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
 // final conv, sigmoid and the per-image reduction, all on chip).
 int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const NoiseCfg& nc, int reward0, int store0,
                 float* val /*[N]*/, float* po_store, hipStream_t st) {
+    if (ctx->generic) return run_decoder_g(ctx, dec_in, N, nc, reward0, store0, val, po_store, st);
     const int C = (int)std::min<int64_t>(ctx->dec_chunk, N);
     float* hA = ctx->allocT<float>((size_t)N * 256);
     float* hB = ctx->allocT<float>((size_t)N * 256);
@@ -279,12 +372,13 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         ctx->prof_end(e0, st);
     }
     ctx->cls = PROF_OTHER;
-    ctx->last_macs += (int64_t)N * MAC_DEC;
+    ctx->last_macs += (int64_t)N * ctx->mac_dec;
     return 0;
 }
 
 // ModelDown.qs_net over N rows; o is [N][4096]; out enc [N][32] (mean 0..9, logvar 10..19).
 int run_encoder(efe_ctx* ctx, const float* o, int N, const NoiseCfg& nc, float* enc, hipStream_t st) {
+    if (ctx->generic) return run_encoder_g(ctx, o, N, nc, enc, st);
     const int C = (int)std::min<int64_t>(ctx->enc_chunk, N);
     float* c4 = ctx->allocT<float>((size_t)C * 9 * 64);
     float* hA = ctx->allocT<float>((size_t)C * 256);
@@ -306,7 +400,7 @@ int run_encoder(efe_ctx* ctx, const float* o, int N, const NoiseCfg& nc, float* 
         fc(ctx, ctx->enc_fc[3], hA, 256, 0, enc + (size_t)m0 * 32, 32, c, false, false, 0, nc, m0, st);
     }
     ctx->cls = PROF_OTHER;
-    ctx->last_macs += (int64_t)N * MAC_ENC;
+    ctx->last_macs += (int64_t)N * ctx->mac_enc;
     return 0;
 }
 
@@ -319,7 +413,7 @@ int run_habit(efe_ctx* ctx, const float* s16 /*[M][16]*/, int M, float* l32 /*[M
     fc(ctx, ctx->top[0], s16, 16, 0, h1, 128, M, true, false, 0, nc, 0, st);
     fc(ctx, ctx->top[1], h1, 128, 0, h2, 128, M, true, false, 0, nc, 0, st);
     fc(ctx, ctx->top[2], h2, 128, 0, l32, 32, M, false, false, 0, nc, 0, st);
-    ctx->last_macs += (int64_t)M * MAC_HABIT;
+    ctx->last_macs += (int64_t)M * ctx->mac_habit;
     return 0;
 }
 
@@ -340,7 +434,7 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
     float* dec_in = ctx->allocT<float>((size_t)D * 3 * S * R * 16);
     float* xbuf = ctx->allocT<float>((size_t)2 * R * 16);
     float* val = ctx->allocT<float>((size_t)D * 3 * S * R);
-    float* po_store = ctx->allocT<float>((size_t)D * S * R * 4096);
+    float* po_store = ctx->allocT<float>((size_t)D * S * R * ctx->img_store);
     float* enc = ctx->allocT<float>((size_t)D * S * R * 32);
     float* terms_tmp = io.terms ? nullptr : ctx->allocT<float>((size_t)3 * R);
     if (!tr_all || !dec_in || !xbuf || !val || !po_store || !enc) return 1;
@@ -367,7 +461,7 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
         p.ps1_last = (t + 1 == D) ? io.ps1 : nullptr;
         p.ps1_mean_last = (t + 1 == D) ? io.ps1_mean : nullptr;
         p.S = S; p.R = R; p.mean_mode = io.mean_mode; p.carry_mean = io.carry_mean;
-        p.k0 = io.k0; p.k1 = io.k1; p.stage = io.stage0 + t; p.row_offset = io.row_offset;
+        p.k0 = io.k0; p.k1 = io.k1; p.stage = io.stage0 + t; p.row_offset = io.row_offset; p.pi_dim = ctx->pi_dim;
         launch_trans_post(p, st);
         x = nx;
     }
@@ -383,11 +477,13 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
     }
     TermsArgs ta{};
     ta.val = val; ta.tr = tr_all; ta.enc = enc; ta.D = D; ta.S = S; ta.R = R;
+    ta.reward_scale = ctx->generic ? 1.0f : 10.0f / 4096.0f;
     ta.G = io.G; ta.terms = io.terms ? io.terms : terms_tmp; ta.t2parts = io.t2parts;
     launch_terms(ta, st);
     if (io.po1) {
-        if (hipMemcpyAsync(io.po1, po_store + ((size_t)(D - 1) * S + (S - 1)) * R * 4096, (size_t)R * 4096 * 4,
-                           hipMemcpyDeviceToDevice, st) != hipSuccess) return ctx->fail("po1 copy failed");
+        const float* last = po_store + ((size_t)(D - 1) * S + (S - 1)) * R * ctx->img_store;
+        if (ctx->generic) launch_to_nchw(last, io.po1, R, ctx->res * ctx->res, ctx->chan, st);
+        else if (hipMemcpyAsync(io.po1, last, (size_t)R * 4096 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return ctx->fail("po1 copy failed");
     }
     return 0;
 }
@@ -439,15 +535,35 @@ const char* efe_build_id(void) {
     return stamp + 13;
 }
 
-int efe_create(efe_ctx** out, int device) {
+int efe_create(efe_ctx** out, int device) { return efe_create_cfg(out, device, 10, 4, 1, 64); }
+
+int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channels, int resolution) {
     if (!out) return 1;
     *out = nullptr;
+    // s_dim is 10 everywhere in the reference (train.py / test_demo.py); x rows are 16 floats = [pi | s | pad]
+    if (s_dim != 10 || pi_dim < 2 || pi_dim > 6 || channels < 1 || channels > 4 || resolution < 32 || resolution > 256 || resolution % 4) return 7;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return 2;
     if (hipSetDevice(device) != hipSuccess) return 3;
     if (init_small_kernels() || init_decoder_kernels() || init_fused_kernels()) return 5;       // per device: a second context on another GPU needs them too
     efe_ctx* ctx = new efe_ctx();
     ctx->device = device;
+    ctx->pi_dim = pi_dim; ctx->chan = channels; ctx->res = resolution;
+    ctx->generic = !(channels == 1 && resolution == 64);
+    ctx->base = resolution / 4;
+    ctx->enc_hw[0] = resolution;
+    for (int i = 1; i < 5; ++i) ctx->enc_hw[i] = (ctx->enc_hw[i - 1] - 3) / 2 + 1;      // Conv2d(k3, s2, p0), SURVEY appendix A.3
+    if (ctx->enc_hw[4] < 1) { delete ctx; return 7; }
+    if (ctx->generic) {
+        const int64_t B = ctx->base, r = resolution;
+        ctx->img_store = (size_t)r * r * 8;
+        ctx->mac_dec = 10 * 256 + 2 * 256 * 256 + 256 * 64 * B * B + B * B * 9 * 64 * 64 * 2 + 4 * B * B * 9 * 64 * 32 + r * r * 9 * 32 * channels;
+        const int* hw = ctx->enc_hw;
+        ctx->mac_enc = (int64_t)hw[1] * hw[1] * 9 * channels * 32 + (int64_t)hw[2] * hw[2] * 9 * 32 * 32 + (int64_t)hw[3] * hw[3] * 9 * 32 * 64
+                     + (int64_t)hw[4] * hw[4] * 9 * 64 * 64 + (int64_t)hw[4] * hw[4] * 64 * 256 + 2 * 256 * 256 + 256 * 20;
+    }
+    ctx->mac_trans = (int64_t)(pi_dim + 10) * 512 + 2 * 512 * 512 + 512 * 20;
+    ctx->mac_habit = 10 * 128 + 128 * 128 + 128 * pi_dim;
     if (hipMalloc((void**)&ctx->zeros, 8192) != hipSuccess || hipMemset(ctx->zeros, 0, 8192) != hipSuccess) { delete ctx; return 4; }
     ctx->owned.push_back(ctx->zeros);
     if (hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(ctx->zeros); delete ctx; return 6; }
@@ -465,6 +581,15 @@ void efe_destroy(efe_ctx* ctx) {
     for (void* p : ctx->wbufs) (void)hipFree(p);
     for (auto& b : ctx->arena.blocks) (void)hipFree(b.first);
     delete ctx;
+}
+
+int efe_get_config(efe_ctx* ctx, int* s_dim, int* pi_dim, int* channels, int* resolution) {
+    if (!ctx) return 1;
+    if (s_dim) *s_dim = S_DIM;
+    if (pi_dim) *pi_dim = ctx->pi_dim;
+    if (channels) *channels = ctx->chan;
+    if (resolution) *resolution = ctx->res;
+    return 0;
 }
 
 const char* efe_last_error(efe_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -505,24 +630,76 @@ int efe_commit_weights(efe_ctx* ctx) {
         ctx->wbufs.clear();
     }
     ctx->committed = false;
+    const int A = ctx->pi_dim;
     // habit net (torchmodel.py:19-25)
     if (pack_linear(ctx, ctx->top[0], "top.qpi_net.0", 128, 10, nullptr, nullptr)) return 1;
     if (pack_linear(ctx, ctx->top[1], "top.qpi_net.2", 128, 128, nullptr, nullptr)) return 1;
-    if (pack_linear(ctx, ctx->top[2], "top.qpi_net.4", 4, 128, nullptr, nullptr)) return 1;
-    // transition net (torchmodel.py:41-52)
-    if (pack_linear(ctx, ctx->mid[0], "mid.ps_net.0", 512, 14, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->top[2], "top.qpi_net.4", A, 128, nullptr, nullptr)) return 1;
+    // transition net (torchmodel.py:41-52); input = cat[pi, s0] (torchmodel.py:59)
+    if (pack_linear(ctx, ctx->mid[0], "mid.ps_net.0", 512, A + 10, nullptr, nullptr)) return 1;
     if (pack_linear(ctx, ctx->mid[1], "mid.ps_net.3", 512, 512, nullptr, nullptr)) return 1;
     if (pack_linear(ctx, ctx->mid[2], "mid.ps_net.6", 512, 512, nullptr, nullptr)) return 1;
     if (pack_linear(ctx, ctx->mid[3], "mid.ps_net.9", 20, 512, nullptr, nullptr)) return 1;
     {   // the same two nets packed for the fused kernels
         const char* mk[4] = {"mid.ps_net.0", "mid.ps_net.3", "mid.ps_net.6", "mid.ps_net.9"};
-        const int mo[4] = {512, 512, 512, 20}, mi[4] = {14, 512, 512, 512};
+        const int mo[4] = {512, 512, 512, 20}, mi[4] = {A + 10, 512, 512, 512};
         for (int i = 0; i < 4; ++i) if (pack_linear16(ctx, ctx->mid16.w[i], ctx->mid16.b[i], mk[i], mo[i], mi[i])) return 1;
         const char* tk[3] = {"top.qpi_net.0", "top.qpi_net.2", "top.qpi_net.4"};
-        const int to[3] = {128, 128, 4}, ti[3] = {10, 128, 128};
+        const int to[3] = {128, 128, A}, ti[3] = {10, 128, 128};
         for (int i = 0; i < 3; ++i) if (pack_linear16(ctx, ctx->top16.w[i], ctx->top16.b[i], tk[i], to[i], ti[i])) return 1;
     }
-    // encoder (torchmodel.py:84-104).  conv1 (Cin = 1) runs on the VALU: w1[tap][co]
+    // shared dense layers of the encoder / decoder heads
+    if (pack_linear(ctx, ctx->enc_fc[1], "down.qs_net.12", 256, 256, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->enc_fc[2], "down.qs_net.15", 256, 256, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->enc_fc[3], "down.qs_net.18", 20, 256, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->dec_fc[0], "down.po_net.0", 256, 10, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->dec_fc[1], "down.po_net.3", 256, 256, nullptr, nullptr)) return 1;
+    if (pack_linear(ctx, ctx->dec_fc[2], "down.po_net.6", 256, 256, nullptr, nullptr)) return 1;
+    const char* tk[3] = {"down.po_net.13", "down.po_net.15", "down.po_net.17"};
+    const int tci[3] = {64, 64, 64}, tco[3] = {64, 64, 32};
+    if (ctx->generic) {
+        // ---- build-defined geometry: same layer list as torchmodel.py:84-128 with the sizes the resolution implies
+        const int C = ctx->chan, B = ctx->base, F = ctx->enc_hw[4] * ctx->enc_hw[4];
+        const char* ck[4] = {"down.qs_net.0", "down.qs_net.2", "down.qs_net.4", "down.qs_net.6"};
+        const int cci[4] = {C, 32, 32, 64}, cco[4] = {32, 32, 64, 64};
+        for (int i = 0; i < 4; ++i) {
+            const HostTensor* w = need(ctx, std::string(ck[i]) + ".weight", {cco[i], cci[i], 3, 3});
+            const HostTensor* b = need(ctx, std::string(ck[i]) + ".bias", {cco[i]});
+            if (!w || !b) return 1;
+            const float* W = w->data.data(); const int Cin = cci[i];
+            if (upload_packed(ctx, ctx->g_enc[i], 9, cco[i], Cin,
+                              [&](int t, int co, int ci) { return W[((size_t)co * Cin + ci) * 9 + t]; }, b->data.data(), nullptr)) return 1;
+        }
+        {   // Flatten is channel-major c*F + p; conv4's output is NHWC p*64 + c
+            std::vector<int> colp((size_t)F * 64);
+            for (int p_ = 0; p_ < F; ++p_) for (int c = 0; c < 64; ++c) colp[(size_t)p_ * 64 + c] = c * F + p_;
+            if (pack_linear(ctx, ctx->enc_fc[0], "down.qs_net.9", 256, F * 64, nullptr, colp.data())) return 1;
+        }
+        {   // Unflatten(1,(64,B,B)) is channel-major c*B*B + p; emitted NHWC p*64 + c
+            std::vector<int> rowp((size_t)B * B * 64);
+            for (int p_ = 0; p_ < B * B; ++p_) for (int c = 0; c < 64; ++c) rowp[(size_t)p_ * 64 + c] = c * B * B + p_;
+            if (pack_linear(ctx, ctx->g_fc4, "down.po_net.9", B * B * 64, 256, rowp.data(), nullptr)) return 1;
+        }
+        for (int i = 0; i < 3; ++i) {
+            const HostTensor* w = need(ctx, std::string(tk[i]) + ".weight", {tci[i], tco[i], 3, 3});
+            const HostTensor* b = need(ctx, std::string(tk[i]) + ".bias", {tco[i]});
+            if (!w || !b) return 1;
+            const float* W = w->data.data(); const int Cout = tco[i];
+            if (upload_packed(ctx, ctx->g_ct[i], 9, Cout, tci[i],
+                              [&](int t, int co, int ci) { return W[((size_t)ci * Cout + co) * 9 + t]; }, b->data.data(), nullptr)) return 1;
+        }
+        const HostTensor* w = need(ctx, "down.po_net.19.weight", {32, C, 3, 3});
+        const HostTensor* b = need(ctx, "down.po_net.19.bias", {C});
+        if (!w || !b) return 1;
+        std::vector<float> wf(9 * 32 * 4, 0.f);         // [tap][ci][c padded to 4]
+        for (int t = 0; t < 9; ++t) for (int ci = 0; ci < 32; ++ci) for (int c = 0; c < C; ++c) wf[(t * 32 + ci) * 4 + c] = w->data[((size_t)ci * C + c) * 9 + t];
+        HIPCHK(hipMalloc((void**)&ctx->g_wf, wf.size() * 4)); ctx->wbufs.push_back(ctx->g_wf);
+        HIPCHK(hipMemcpy(ctx->g_wf, wf.data(), wf.size() * 4, hipMemcpyHostToDevice));
+        for (int c = 0; c < 4; ++c) ctx->g_bf[c] = c < C ? b->data[c] : 0.f;
+        ctx->committed = true;
+        return 0;
+    }
+    // ---- Dynamic-dSprites geometry (1 x 64 x 64): fused kernels.  encoder (torchmodel.py:84-104): conv1 (Cin = 1) runs on the VALU: w1[tap][co]
     {
         const HostTensor* w = need(ctx, "down.qs_net.0.weight", {32, 1, 3, 3});
         const HostTensor* b = need(ctx, "down.qs_net.0.bias", {32});
@@ -549,20 +726,11 @@ int efe_commit_weights(efe_ctx* ctx) {
         for (int p = 0; p < 9; ++p) for (int c = 0; c < 64; ++c) colp[p * 64 + c] = c * 9 + p;
         if (pack_linear(ctx, ctx->enc_fc[0], "down.qs_net.9", 256, 576, nullptr, colp.data())) return 1;
     }
-    if (pack_linear(ctx, ctx->enc_fc[1], "down.qs_net.12", 256, 256, nullptr, nullptr)) return 1;
-    if (pack_linear(ctx, ctx->enc_fc[2], "down.qs_net.15", 256, 256, nullptr, nullptr)) return 1;
-    if (pack_linear(ctx, ctx->enc_fc[3], "down.qs_net.18", 20, 256, nullptr, nullptr)) return 1;
-    // decoder (torchmodel.py:106-128)
-    if (pack_linear(ctx, ctx->dec_fc[0], "down.po_net.0", 256, 10, nullptr, nullptr)) return 1;
-    if (pack_linear(ctx, ctx->dec_fc[1], "down.po_net.3", 256, 256, nullptr, nullptr)) return 1;
-    if (pack_linear(ctx, ctx->dec_fc[2], "down.po_net.6", 256, 256, nullptr, nullptr)) return 1;
     {   // Unflatten(1,(64,16,16)) is channel-major c*256 + p (torchmodel.py:119); we emit NHWC p*64 + c directly
         std::vector<int> rowp(16384);
         for (int p = 0; p < 256; ++p) for (int c = 0; c < 64; ++c) rowp[p * 64 + c] = c * 256 + p;
         if (pack_linear(ctx, ctx->dec_fc[3], "down.po_net.9", 16384, 256, rowp.data(), nullptr)) return 1;
     }
-    const char* tk[3] = {"down.po_net.13", "down.po_net.15", "down.po_net.17"};
-    const int tci[3] = {64, 64, 64}, tco[3] = {64, 64, 32};
     for (int i = 0; i < 3; ++i) {   // ConvTranspose2d weights are [Cin][Cout][kh][kw]
         const HostTensor* w = need(ctx, std::string(tk[i]) + ".weight", {tci[i], tco[i], 3, 3});
         const HostTensor* b = need(ctx, std::string(tk[i]) + ".bias", {tco[i]});
@@ -726,12 +894,12 @@ int efe_transition(efe_ctx* ctx, const float* pi, const float* s0, int M, const 
     float* x = ctx->allocT<float>((size_t)M * 16);
     float* tr = ctx->allocT<float>((size_t)M * 32);
     if (!x || !tr) return 1;
-    launch_pack_x(pi, s0, x, M, PI_DIM, S_DIM, st);
+    launch_pack_x(pi, s0, x, M, ctx->pi_dim, S_DIM, st);
     NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;
     nc.gm = GroupMap{1, 1, {nz->pass, 0, 0}, nz->stage, nz->sample};
     if (run_mid(ctx, x, 0, M, tr, nc, st)) return 1;
     launch_split_enc(tr, mean, logvar, M, st);
-    if (ps1) launch_root_post(tr, nullptr, eps, nullptr, ps1, M, 0, nc.k0, nc.k1, nz->pass, nz->sample, nz->stage, nz->row_offset, st);
+    if (ps1) launch_root_post(tr, nullptr, eps, nullptr, ps1, M, 0, nc.k0, nc.k1, nz->pass, nz->sample, nz->stage, nz->row_offset, ctx->pi_dim, st);
     return finish(ctx, st);
 }
 
@@ -747,7 +915,12 @@ int efe_decoder(efe_ctx* ctx, const float* s, int M, const efe_noise* nz, float*
     launch_pad16(s, x, M, S_DIM, st);
     NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;
     nc.gm = GroupMap{1, 1, {nz->pass, 0, 0}, nz->stage, nz->sample};
-    if (run_decoder(ctx, x, M, nc, 0, 1, val, po, st)) return 1;
+    if (ctx->generic) {            // the generic path stores NHWC8 images: convert to the NCHW the API returns
+        float* tmp = ctx->allocT<float>((size_t)M * ctx->img_store);
+        if (!tmp) return 1;
+        if (run_decoder(ctx, x, M, nc, 0, 1, val, tmp, st)) return 1;
+        launch_to_nchw(tmp, po, M, ctx->res * ctx->res, ctx->chan, st);
+    } else if (run_decoder(ctx, x, M, nc, 0, 1, val, po, st)) return 1;
     return finish(ctx, st);
 }
 
@@ -761,9 +934,15 @@ int efe_encoder(efe_ctx* ctx, const float* o, int M, const efe_noise* nz, const 
     if (!enc) return 1;
     NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;
     nc.gm = GroupMap{1, 1, {nz->pass, 0, 0}, nz->stage, nz->sample};
+    if (ctx->generic) {
+        float* o8 = ctx->allocT<float>((size_t)M * ctx->img_store);
+        if (!o8) return 1;
+        launch_to_nhwc8(o, o8, M, ctx->res * ctx->res, ctx->chan, st);
+        o = o8;
+    }
     if (run_encoder(ctx, o, M, nc, enc, st)) return 1;
     launch_split_enc(enc, mean, logvar, M, st);
-    if (s) launch_root_post(enc, nullptr, eps, nullptr, s, M, 0, nc.k0, nc.k1, nz->pass, nz->sample, nz->stage, nz->row_offset, st);
+    if (s) launch_root_post(enc, nullptr, eps, nullptr, s, M, 0, nc.k0, nc.k1, nz->pass, nz->sample, nz->stage, nz->row_offset, ctx->pi_dim, st);
     return finish(ctx, st);
 }
 
@@ -778,7 +957,7 @@ int efe_habit(efe_ctx* ctx, const float* s, int M, float* logits, float* q, floa
     if (!x || !l32) return 1;
     launch_pad16(s, x, M, S_DIM, st);
     if (run_habit(ctx, x, M, l32, st)) return 1;
-    launch_softmax4(l32, logits, q, logq, M, PI_DIM, st);
+    launch_softmax4(l32, logits, q, logq, M, ctx->pi_dim, st);
     return finish(ctx, st);
 }
 
@@ -787,7 +966,8 @@ int efe_check_reward(efe_ctx* ctx, const float* o, int M, float* out, void* stre
     EFE_LOCK(ctx);
     if (!o || !out || M < 1) return ctx->fail("efe_check_reward: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
-    launch_check_reward(o, out, M, (hipStream_t)stream);
+    if (ctx->generic) launch_check_reward_g(o, out, M, ctx->chan, ctx->res, ctx->res, (hipStream_t)stream);
+    else launch_check_reward(o, out, M, (hipStream_t)stream);
     return finish(ctx);
 }
 
@@ -812,7 +992,7 @@ int efe_calculate_g(efe_ctx* ctx, const float* s0, const float* pi0, int M, int 
     if (!s0 || !pi0 || !nz || !G || M < 1 || samples < 1 || samples > 65535) return ctx->fail("efe_calculate_g: bad arguments");
     float* x = ctx->allocT<float>((size_t)M * 16);
     if (!x) return 1;
-    launch_pack_x(pi0, s0, x, M, PI_DIM, S_DIM, st);
+    launch_pack_x(pi0, s0, x, M, ctx->pi_dim, S_DIM, st);
     CoreIO io{};
     io.x0 = x; io.R = M; io.D = 1; io.S = mean_mode ? 1 : samples; io.mean_mode = mean_mode; io.carry_mean = 0;
     io.k0 = (uint32_t)nz->seed; io.k1 = (uint32_t)(nz->seed >> 32); io.stage0 = nz->stage; io.row_offset = nz->row_offset;
@@ -835,8 +1015,14 @@ int efe_rollout(efe_ctx* ctx, const float* o, const float* pi, int M, int steps,
     {   // root encode + reparameterize (torchmodel.py:228-234)
         NoiseCfg nc; nc.k0 = k0; nc.k1 = k1; nc.rows_per_group = M; nc.row_offset = nz->row_offset;
         nc.gm = GroupMap{1, 1, {PASS_ROOT, 0, 0}, nz->stage, 0};
+        if (ctx->generic) {
+            float* o8 = ctx->allocT<float>((size_t)M * ctx->img_store);
+            if (!o8) return 1;
+            launch_to_nhwc8(o, o8, M, ctx->res * ctx->res, ctx->chan, st);
+            o = o8;
+        }
         if (run_encoder(ctx, o, M, nc, enc0, st)) return 1;
-        launch_root_post(enc0, pi, eps, x, nullptr, M, calc_mean ? 1 : 0, k0, k1, PASS_ROOT, 0, nz->stage, nz->row_offset, st);
+        launch_root_post(enc0, pi, eps, x, nullptr, M, calc_mean ? 1 : 0, k0, k1, PASS_ROOT, 0, nz->stage, nz->row_offset, ctx->pi_dim, st);
     }
     const int mean_mode = (per_stage_mean && calc_mean) ? 1 : 0;
     CoreIO io{};
@@ -853,7 +1039,7 @@ static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_
                            const float* eps, float* G, hipStream_t st) {
     float* x = ctx->allocT<float>((size_t)T * 16);
     if (!x) return 1;
-    launch_pack_x(pi0_traj, s0_traj, x, T, PI_DIM, S_DIM, st);
+    launch_pack_x(pi0_traj, s0_traj, x, T, ctx->pi_dim, S_DIM, st);
     CoreIO io{};
     io.x0 = x; io.R = T; io.D = 1; io.S = 1; io.mean_mode = 0; io.carry_mean = 0;
     io.k0 = k0; io.k1 = k1; io.stage0 = stage; io.row_offset = row_offset; io.eps = eps;
@@ -895,13 +1081,13 @@ int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int us
         sa.W = ctx->mid16; sa.H = ctx->top16; sa.s0 = starting_s; sa.E = E; sa.T = T; sa.use_means = use_means;
         sa.k0 = k0; sa.k1 = k1; sa.stage = nz->stage; sa.row_offset = nz->row_offset;
         sa.eps_inj = eps; sa.u_inj = u;
-        sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0;
+        sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0; sa.pi_dim = ctx->pi_dim;
         ctx->cls = PROF_MID;
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_sim_chain(sa, st);
         ctx->prof_end(e0, st);
         ctx->cls = PROF_OTHER;
-        ctx->last_macs += (int64_t)E * T * (MAC_TRANS + MAC_HABIT);
+        ctx->last_macs += (int64_t)E * T * (ctx->mac_trans + ctx->mac_habit);
     }
     if (trajectory_impl(ctx, s0t, ps1t, mt, lvt, pi0, E * T, k0, k1, nz->stage, nz->row_offset * (uint32_t)T,
                         eps ? eps + (size_t)T * E * 10 : nullptr, Gt, st)) return 1;
@@ -946,6 +1132,23 @@ int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples) {
     const size_t A = (size_t)ctx->arena_align;
     const int64_t dec_chunk = ctx->dec_chunk, enc_chunk = ctx->enc_chunk;
     auto al = [A](size_t b) { return (b + A - 1) / A * A; };
+    if (ctx->generic) {
+        const size_t R = (size_t)M, D = (size_t)steps, S = (size_t)samples, B = (size_t)ctx->base, IS = ctx->img_store;
+        const int* hw = ctx->enc_hw;
+        size_t t = 0;
+        auto enc = [&](size_t N) {
+            const size_t C = std::min<size_t>(std::min<size_t>((size_t)enc_chunk, 8192), N);
+            t += al(C * hw[1] * hw[1] * 32 * 4) + al(C * hw[2] * hw[2] * 32 * 4) + al(C * hw[3] * hw[3] * 64 * 4) + al(C * hw[4] * hw[4] * 64 * 4) + 2 * al(C * 256 * 4);
+        };
+        t += al(R * 32 * 4) + al(R * 16 * 4) + al(R * IS * 4);
+        enc(R);
+        t += al(D * 2 * S * R * 32 * 4) + al(D * 3 * S * R * 16 * 4) + al(2 * R * 16 * 4) + al(D * 3 * S * R * 4) + al(D * S * R * IS * 4)
+           + al(D * S * R * 32 * 4) + al(3 * R * 4);
+        {   const size_t N = D * 3 * S * R, C = std::min<size_t>(std::min<size_t>((size_t)dec_chunk, 4096), N);
+            t += 2 * al(N * 256 * 4) + 2 * al(C * B * B * 64 * 4) + al(C * 4 * B * B * 64 * 4) + al(C * 16 * B * B * 32 * 4); }
+        enc(D * S * R);
+        return (int64_t)(t + ((size_t)1 << 20));
+    }
     const size_t R = (size_t)M, D = (size_t)steps, S = (size_t)samples;
     size_t t = 0;
     auto enc = [&](size_t N) { const size_t C = std::min<size_t>((size_t)enc_chunk, N); t += al(C * 576 * 4) + 2 * al(C * 256 * 4); };

@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
     float4* bufA = sm;
     float4* bufB = sm + ACT_F4;
     float* srow = reinterpret_cast<float*>(sm + 2 * ACT_F4);        // [16 rows][16]: current state s_t (10 used)
-    float* sact = srow + FR * 16;                                   // [16 rows][4]: one-hot action of the step
+    float* sact = srow + FR * 16;                                   // [16 rows][8]: one-hot action of the step
+    const int A = a.pi_dim;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
@@ -212,28 +213,28 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
         // ---- softmax (torchmodel.py:28-29), categorical sample (torchmodel.py:364,379), one thread per episode row
         if (tid < FR) {
             const int e = e0 + tid;
-            const float4 lg = bufB[aswz(tid, 0)];
-            const float l[4] = {lg.x, lg.y, lg.z, lg.w};
+            const float4 lg = bufB[aswz(tid, 0)], lg2 = bufB[aswz(tid, 1)];
+            const float l[8] = {lg.x, lg.y, lg.z, lg.w, lg2.x, lg2.y, lg2.z, lg2.w};
             float mx = -INFINITY;
-            for (int k = 0; k < 4; ++k) mx = fmaxf(mx, l[k]);
-            float ex[4], sum = 0.f;
-            for (int k = 0; k < 4; ++k) { ex[k] = expf(l[k] - mx); sum += ex[k]; }
-            float qq[4], tot = 0.f; bool bad = false;
-            for (int k = 0; k < 4; ++k) { qq[k] = ex[k] / sum; if (!(qq[k] >= 0.f) || isinf(qq[k])) bad = true; tot += qq[k]; }
+            for (int k = 0; k < A; ++k) mx = fmaxf(mx, l[k]);
+            float ex[8], sum = 0.f;
+            for (int k = 0; k < A; ++k) { ex[k] = expf(l[k] - mx); sum += ex[k]; }
+            float qq[8], tot = 0.f; bool bad = false;
+            for (int k = 0; k < A; ++k) { qq[k] = ex[k] / sum; if (!(qq[k] >= 0.f) || isinf(qq[k])) bad = true; tot += qq[k]; }
             int act = 0;
             if (!bad && tot > 0.f) {
                 const float u = a.u_inj ? a.u_inj[(size_t)t * E + min(e, E - 1)]
                                         : u01(noise_words(a.k0, a.k1, TAG_ACT, 0u, a.row_offset + e, stream_id(PASS_HABIT, (uint32_t)t), a.stage).x);
                 const float thr = u * tot;
-                float accq = 0.f; act = 3;
-                for (int k = 0; k < 4; ++k) { accq += qq[k]; if (thr < accq) { act = k; break; } }
+                float accq = 0.f; act = A - 1;
+                for (int k = 0; k < A; ++k) { accq += qq[k]; if (thr < accq) { act = k; break; } }
             } else bad = true;
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < A; ++k) {
                 const float oh = (k == act) ? 1.f : 0.f;
-                sact[tid * 4 + k] = oh;
+                sact[tid * 8 + k] = oh;
                 if (e < E) {
-                    a.pi0[((size_t)e * T + t) * 4 + k] = oh;
-                    if (t == 0 && a.Qpi0) a.Qpi0[(size_t)e * 4 + k] = bad ? oh : qq[k];
+                    a.pi0[((size_t)e * T + t) * A + k] = oh;
+                    if (t == 0 && a.Qpi0) a.Qpi0[(size_t)e * A + k] = bad ? oh : qq[k];
                 }
             }
         }
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = 4 * q + i;
-                v[i] = k < 4 ? sact[n * 4 + k] : k < 14 ? srow[n * 16 + (k - 4)] : 0.f;
+                v[i] = k < A ? sact[n * 8 + k] : k < A + 10 ? srow[n * 16 + (k - A)] : 0.f;
             }
             bufA[aswz(n, q)] = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -271,12 +272,12 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
 }
 
 void launch_sim_chain(const SimChainArgs& a, hipStream_t st) {
-    const size_t lds = 2 * ACT_F4 * sizeof(float4) + (FR * 16 + FR * 4) * sizeof(float);
+    const size_t lds = 2 * ACT_F4 * sizeof(float4) + (FR * 16 + FR * 8) * sizeof(float);
     hipLaunchKernelGGL(k_sim_chain, dim3((a.E + FR - 1) / FR), dim3(256), lds, st, a);
 }
 
 int init_fused_kernels() {
-    const size_t lds = 2 * ACT_F4 * sizeof(float4) + (FR * 16 + FR * 4) * sizeof(float);
+    const size_t lds = 2 * ACT_F4 * sizeof(float4) + (FR * 16 + FR * 8) * sizeof(float);
     if (hipFuncSetAttribute((const void*)k_trans_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ACT_F4 * sizeof(float4)) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_sim_chain, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
     return 0;

@@ -116,6 +116,7 @@ struct TransPostArgs {
     float* ps1_mean_last;  // nullable [R][10]
     int S, R, mean_mode, carry_mean;
     uint32_t k0, k1, stage, row_offset;
+    int pi_dim;            // x rows are [pi (pi_dim) | s (10) | zeros]
 };
 void launch_trans_post(const TransPostArgs& a, hipStream_t st);
 
@@ -124,6 +125,7 @@ struct TermsArgs {
     const float* tr;       // [D][2S][R][32]
     const float* enc;      // [D][S][R][32]
     int D, S, R;
+    float reward_scale;    // term0 per image = pixel sum * reward_scale: 10 / 4096 (mean over pixels * 10, torchmodel.py:212) for dSprites, 1 for the sum form
     float* G;              // [R] summed over stages
     float* terms;          // [3][R] summed over stages
     float* t2parts;        // nullable [2][R]: term2_1, term2_2 (last stage; diagnostics)
@@ -169,16 +171,42 @@ struct SimChainArgs {
     const float* eps_inj;  // nullable [T][E][10]
     const float* u_inj;    // nullable [T][E]
     float *s0_traj, *ps1_traj, *mean_traj, *lv_traj;   // [E][T][10]
-    float* pi0;            // [E][T][4] one-hot
-    float* Qpi0;           // nullable [E][4]
+    float* pi0;            // [E][T][pi_dim] one-hot
+    float* Qpi0;           // nullable [E][pi_dim]
+    int pi_dim;
 };
 void launch_sim_chain(const SimChainArgs& a, hipStream_t st);
 int init_fused_kernels();
 
+// ---- geometry-generic convolution path (generic.hip) ---------------------------------------------
+struct ConvGArgs {
+    const float* in; float* out;      // NHWC activations
+    const float* Wp; const float* bias; const float* zeros;     // packed [tap][32-feature tile][8-channel chunk][64 lanes][4]
+    int n_img, Hin, Win, Cin;         // Cin padded to a multiple of 8
+    int Hout, Wout, Cout, mtiles;
+    int mode;                         // 0 Conv2d(k3,s2,p0)   1 ConvTranspose2d(k3,s1,p1)   2 ConvTranspose2d(k3,s2,p1,op1), sub-pixel form
+    int relu;
+    int ldo;                          // floats per output pixel
+};
+void launch_conv_g(const ConvGArgs& a, hipStream_t st);
+struct FinalGArgs {
+    const float* y3;                  // [rows][H*W][32]
+    const float* w; float b[4];       // [9 taps][32 ci][4 c], bias
+    int rows, m0, rows_per_group, H, W, C;
+    GroupMap gm;
+    int reward0, store0;
+    float* val;                       // [batch] per-image sums
+    float* po;                        // [slots][rows_per_group][H*W][8] stored images (NHWC, channels padded to 8)
+};
+void launch_final_g(const FinalGArgs& a, hipStream_t st);
+void launch_to_nhwc8(const float* in, float* out, long M, int HW, int C, hipStream_t st);
+void launch_to_nchw(const float* in, float* out, long M, int HW, int C, hipStream_t st);
+void launch_check_reward_g(const float* o, float* out, int M, int C, int H, int W, hipStream_t st);
+
 void launch_pack_x(const float* pi, const float* s, float* x, int R, int pi_dim, int s_dim, hipStream_t st);
 void launch_pad16(const float* s, float* x, int R, int s_dim, hipStream_t st);
 void launch_root_post(const float* enc, const float* pi, const float* eps_inj, float* x, float* s_out, int R, int use_mean,
-                      uint32_t k0, uint32_t k1, uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, hipStream_t st);
+                      uint32_t k0, uint32_t k1, uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, int pi_dim, hipStream_t st);
 void launch_split_enc(const float* enc, float* mean, float* logvar, int R, hipStream_t st);
 void launch_softmax4(const float* logits32, float* logits, float* q, float* logq, int R, int n, hipStream_t st);
 void launch_sample_action(const float* q, float* pi_onehot, float* q_ret, int R, int n, uint32_t k0, uint32_t k1,

@@ -217,14 +217,14 @@ __global__ void k_trans_post(const TransPostArgs a) {
         if (q == S - 1) {
             if (a.ps1_last) a.ps1_last[(size_t)r * 10 + k] = samp;
             if (a.ps1_mean_last) a.ps1_mean_last[(size_t)r * 10 + k] = mean;
-            if (a.next_x) a.next_x[(size_t)r * 16 + 4 + k] = (a.carry_mean || a.mean_mode) ? mean : samp;
+            if (a.next_x) a.next_x[(size_t)r * 16 + a.pi_dim + k] = (a.carry_mean || a.mean_mode) ? mean : samp;
             if (a.given_ps1) out = a.given_ps1[(size_t)r * 10 + k];
         }
     }
     a.dec_in[qr * 16 + k] = out;
     if (q == S - 1 && a.next_x) {
-        if (k < 4) a.next_x[(size_t)r * 16 + k] = a.x[(size_t)r * 16 + k];
-        if (k >= 14) a.next_x[(size_t)r * 16 + k] = 0.0f;
+        if (k < a.pi_dim) a.next_x[(size_t)r * 16 + k] = a.x[(size_t)r * 16 + k];
+        if (k >= a.pi_dim + 10) a.next_x[(size_t)r * 16 + k] = 0.0f;
     }
 }
 
@@ -260,7 +260,8 @@ __global__ void __launch_bounds__(256) k_terms(const TermsArgs a) {
         const float* en = a.enc + (((size_t)t * S + i) * R + r) * 32 + 10;
         float h = 0.f;
         for (int k = 0; k < 10; ++k) h += 0.5f * (C + tr[k]) + 0.5f * (C + en[k]);
-        p1s[idx * 4 + 0] = val[(size_t)i * R + r] * (1.0f / 4096.0f) * 10.0f;   // mean over pixels * 10 (torchmodel.py:212)
+        p1s[idx * 4 + 0] = a.reward_scale == 1.0f ? val[(size_t)i * R + r]
+                                                  : val[(size_t)i * R + r] * (1.0f / 4096.0f) * 10.0f;   // mean over pixels * 10 (torchmodel.py:212)
         p1s[idx * 4 + 1] = -h;
         p1s[idx * 4 + 2] = val[(size_t)(S + i) * R + r];
         p1s[idx * 4 + 3] = val[(size_t)(2 * S + i) * R + r];
@@ -338,14 +339,14 @@ void launch_pad16(const float* s, float* x, int R, int s_dim, hipStream_t st) {
 
 // root encode -> s0 (torchmodel.py:228-234): x[r] = [pi | (use_mean ? mean : eps*exp(lv/2)+mean) | 0 0]
 __global__ void k_root_post(const float* enc, const float* pi, const float* eps_inj, float* x, float* s_out, int R, int use_mean,
-                            uint32_t k0, uint32_t k1, uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset) {
+                            uint32_t k0, uint32_t k1, uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, int pi_dim) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = gid >> 4, k = gid & 15;
     if (r >= R) return;
     float v = 0.f;
-    if (k < 4) v = pi ? pi[(size_t)r * 4 + k] : 0.f;
-    else if (k < 14) {
-        const int kk = k - 4;
+    if (k < pi_dim) v = pi ? pi[(size_t)r * pi_dim + k] : 0.f;
+    else if (k < pi_dim + 10) {
+        const int kk = k - pi_dim;
         const float mean = enc[(size_t)r * 32 + kk], lv = enc[(size_t)r * 32 + 10 + kk];
         if (use_mean) v = mean;
         else {
@@ -358,9 +359,9 @@ __global__ void k_root_post(const float* enc, const float* pi, const float* eps_
     if (x) x[gid] = v;
 }
 void launch_root_post(const float* enc, const float* pi, const float* eps_inj, float* x, float* s_out, int R, int use_mean,
-                      uint32_t k0, uint32_t k1, uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, hipStream_t st) {
+                      uint32_t k0, uint32_t k1, uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, int pi_dim, hipStream_t st) {
     hipLaunchKernelGGL(k_root_post, dim3((R * 16 + 255) / 256), dim3(256), 0, st, enc, pi, eps_inj, x, s_out, R, use_mean,
-                       k0, k1, pass, sample, stage, row_offset);
+                       k0, k1, pass, sample, stage, row_offset, pi_dim);
 }
 
 __global__ void k_split_enc(const float* enc, float* mean, float* logvar, int R) {

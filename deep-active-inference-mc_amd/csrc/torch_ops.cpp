@@ -51,6 +51,8 @@ efe_noise noise(int64_t seed, int64_t stage, int64_t pass, int64_t sample, int64
     nz.row_offset = (uint32_t)row_offset;
     return nz;
 }
+struct Geo { int s = 10, A = 4, C = 1, R = 64; int64_t img() const { return (int64_t)C * R * R; } };
+Geo geo(efe_ctx* c) { Geo g; efe_get_config(c, &g.s, &g.A, &g.C, &g.R); return g; }
 int rows(const Tensor& t, int64_t width, const char* name) {
     TORCH_CHECK(t.numel() % width == 0 && t.numel() > 0, "efe: ", name, " must be [M, ", width, "]");
     return (int)(t.numel() / width);
@@ -61,8 +63,9 @@ std::tuple<Tensor, Tensor, Tensor> transition(int64_t h, const Tensor& pi_, cons
                                               int64_t sample, int64_t row_offset, const OptT& eps) {
     efe_ctx* c = CTX(h);
     Tensor pi = in(pi_, "pi"), s0 = in(s0_, "s0"), ek;
+    const Geo gq = geo(c);
     const int M = rows(s0, 10, "s0");
-    TORCH_CHECK(pi.numel() == (int64_t)M * 4, "efe: pi must be [M, 4]");
+    TORCH_CHECK(pi.numel() == (int64_t)M * gq.A, "efe: pi must be [M, pi_dim]");
     Tensor ps1 = at::empty({M, 10}, s0.options()), mean = at::empty({M, 10}, s0.options()), lv = at::empty({M, 10}, s0.options());
     efe_noise nz = noise(seed, stage, pass, sample, row_offset);
     ok(c, efe_transition(c, pi.data_ptr<float>(), s0.data_ptr<float>(), M, &nz, optp(eps, ek, "eps", (int64_t)M * 10), ps1.data_ptr<float>(),
@@ -74,8 +77,9 @@ std::tuple<Tensor, Tensor, Tensor> transition(int64_t h, const Tensor& pi_, cons
 Tensor decoder(int64_t h, const Tensor& s_, int64_t seed, int64_t stage, int64_t pass, int64_t sample, int64_t row_offset) {
     efe_ctx* c = CTX(h);
     Tensor s = in(s_, "s");
+    const Geo gq = geo(c);
     const int M = rows(s, 10, "s");
-    Tensor po = at::empty({M, 1, 64, 64}, s.options());
+    Tensor po = at::empty({M, gq.C, gq.R, gq.R}, s.options());
     efe_noise nz = noise(seed, stage, pass, sample, row_offset);
     ok(c, efe_decoder(c, s.data_ptr<float>(), M, &nz, po.data_ptr<float>(), stream_of(s)));
     return po;
@@ -86,7 +90,7 @@ std::tuple<Tensor, Tensor, Tensor> encoder(int64_t h, const Tensor& o_, int64_t 
                                            int64_t row_offset, const OptT& eps, bool want_s) {
     efe_ctx* c = CTX(h);
     Tensor o = in(o_, "o"), ek;
-    const int M = rows(o, 4096, "o");
+    const int M = rows(o, geo(c).img(), "o");
     Tensor s = want_s ? at::empty({M, 10}, o.options()) : at::empty({0}, o.options());
     Tensor mean = at::empty({M, 10}, o.options()), lv = at::empty({M, 10}, o.options());
     efe_noise nz = noise(seed, stage, pass, sample, row_offset);
@@ -100,7 +104,8 @@ std::tuple<Tensor, Tensor, Tensor> habit(int64_t h, const Tensor& s_) {
     efe_ctx* c = CTX(h);
     Tensor s = in(s_, "s");
     const int M = rows(s, 10, "s");
-    Tensor logits = at::empty({M, 4}, s.options()), q = at::empty({M, 4}, s.options()), logq = at::empty({M, 4}, s.options());
+    const int A = geo(c).A;
+    Tensor logits = at::empty({M, A}, s.options()), q = at::empty({M, A}, s.options()), logq = at::empty({M, A}, s.options());
     ok(c, efe_habit(c, s.data_ptr<float>(), M, logits.data_ptr<float>(), q.data_ptr<float>(), logq.data_ptr<float>(), stream_of(s)));
     return {logits, q, logq};
 }
@@ -111,13 +116,14 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> calculate_g(int64_t h
                                                                        const OptT& eps) {
     efe_ctx* c = CTX(h);
     Tensor s0 = in(s0_, "s0"), pi0 = in(pi0_, "pi0"), ek;
+    const Geo gq = geo(c);
     const int M = rows(s0, 10, "s0");
-    TORCH_CHECK(pi0.numel() == (int64_t)M * 4, "efe: pi0 must be [M, 4]");
+    TORCH_CHECK(pi0.numel() == (int64_t)M * gq.A, "efe: pi0 must be [M, pi_dim]");
     TORCH_CHECK(samples >= 1 && samples <= 65535, "efe engine: samples must be in [1, 65535]");
     const int S = mean_mode ? 1 : (int)samples;
     auto op = s0.options();
     Tensor G = at::empty({M}, op), terms = at::empty({3, M}, op), ps1 = at::empty({M, 10}, op), ps1m = at::empty({M, 10}, op),
-           po1 = at::empty({M, 1, 64, 64}, op), parts = at::empty({2, M}, op);
+           po1 = at::empty({M, gq.C, gq.R, gq.R}, op), parts = at::empty({2, M}, op);
     efe_noise nz = noise(seed, stage, 0, 0, row_offset);
     ok(c, efe_calculate_g(c, s0.data_ptr<float>(), pi0.data_ptr<float>(), M, S, mean_mode ? 1 : 0, &nz, optp(eps, ek, "eps", (int64_t)3 * S * M * 10),
                           G.data_ptr<float>(), terms.data_ptr<float>(), ps1.data_ptr<float>(), ps1m.data_ptr<float>(), po1.data_ptr<float>(),
@@ -130,12 +136,13 @@ std::tuple<Tensor, Tensor, Tensor> rollout(int64_t h, const Tensor& o_, const Te
                                            bool per_stage_mean, int64_t seed, int64_t stage, int64_t row_offset, const OptT& eps) {
     efe_ctx* c = CTX(h);
     Tensor o = in(o_, "o"), pi = in(pi_, "pi"), ek;
-    const int M = rows(o, 4096, "o");
-    TORCH_CHECK(pi.numel() == (int64_t)M * 4, "efe: o and pi must have the same number of rows");
+    const Geo gq = geo(c);
+    const int M = rows(o, gq.img(), "o");
+    TORCH_CHECK(pi.numel() == (int64_t)M * gq.A, "efe: o and pi must have the same number of rows");
     TORCH_CHECK(steps >= 1 && samples >= 1 && samples <= 65535, "efe engine: steps and samples must be >= 1");
     const int64_t S = (per_stage_mean && calc_mean) ? 1 : samples;
     auto op = o.options();
-    Tensor G = at::empty({M}, op), terms = at::empty({3, M}, op), po1 = at::empty({M, 1, 64, 64}, op);
+    Tensor G = at::empty({M}, op), terms = at::empty({3, M}, op), po1 = at::empty({M, gq.C, gq.R, gq.R}, op);
     efe_noise nz = noise(seed, stage, 0, 0, row_offset);
     ok(c, efe_rollout(c, o.data_ptr<float>(), pi.data_ptr<float>(), M, (int)steps, (int)samples, calc_mean ? 1 : 0, per_stage_mean ? 1 : 0, &nz,
                       optp(eps, ek, "eps", (int64_t)M * 10 + steps * 3 * S * M * 10), G.data_ptr<float>(), terms.data_ptr<float>(),
@@ -150,7 +157,7 @@ Tensor trajectory(int64_t h, const Tensor& s0_, const Tensor& ps1_, const Tensor
     Tensor s0 = in(s0_, "s0_traj"), ps1 = in(ps1_, "ps1_traj"), mean = in(mean_, "ps1_mean_traj"), lv = in(lv_, "ps1_logvar_traj"),
            pi0 = in(pi0_, "pi0_traj"), ek;
     const int T = rows(s0, 10, "s0_traj");
-    TORCH_CHECK(ps1.numel() == (int64_t)T * 10 && mean.numel() == (int64_t)T * 10 && lv.numel() == (int64_t)T * 10 && pi0.numel() == (int64_t)T * 4,
+    TORCH_CHECK(ps1.numel() == (int64_t)T * 10 && mean.numel() == (int64_t)T * 10 && lv.numel() == (int64_t)T * 10 && pi0.numel() == (int64_t)T * geo(c).A,
                 "efe: trajectory tensors must all have T rows");
     Tensor G = at::empty({T}, s0.options());
     efe_noise nz = noise(seed, stage, 0, 0, row_offset);
@@ -167,7 +174,8 @@ std::tuple<Tensor, Tensor, Tensor> simulate(int64_t h, const Tensor& s_, int64_t
     const int E = rows(s, 10, "starting_s");
     TORCH_CHECK(depth >= 1 && depth <= 65535, "efe engine: depth must be in [1, 65535]");
     auto op = s.options();
-    Tensor G = at::empty({E}, op), pi0 = at::empty({E, depth, 4}, op), q0 = at::empty({E, 4}, op);
+    const int A = geo(c).A;
+    Tensor G = at::empty({E}, op), pi0 = at::empty({E, depth, A}, op), q0 = at::empty({E, A}, op);
     efe_noise nz = noise(seed, stage, 0, 0, row_offset);
     ok(c, efe_simulate(c, s.data_ptr<float>(), E, (int)depth, use_means ? 1 : 0, &nz, optp(eps, ek, "eps", (int64_t)4 * depth * E * 10),
                        optp(u, uk, "u", depth * E), G.data_ptr<float>(), pi0.data_ptr<float>(), q0.data_ptr<float>(), stream_of(s)));
@@ -190,7 +198,7 @@ std::tuple<Tensor, Tensor> action_posterior(int64_t h, const Tensor& g_, int64_t
 Tensor check_reward(int64_t h, const Tensor& o_) {
     efe_ctx* c = CTX(h);
     Tensor o = in(o_, "o");
-    const int M = rows(o, 4096, "o");
+    const int M = rows(o, geo(c).img(), "o");
     Tensor out = at::empty({M}, o.options());
     ok(c, efe_check_reward(c, o.data_ptr<float>(), M, out.data_ptr<float>(), stream_of(o)));
     return out;

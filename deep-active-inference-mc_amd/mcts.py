@@ -292,9 +292,15 @@ class BatchedMCTS:
         active = active_h.to(torch.uint8).to(m.device)
         self._expand(torch.zeros(E, dtype=torch.int32, device=m.device), active, self.S[:, 0].repeat_interleave(A, dim=0).contiguous())
         n_iter = 0
+        # The per-episode early stop (mcts.py:176) is applied on the device every iteration (stopped episodes are masked out of
+        # every tree update); the host only needs to know when ALL episodes have stopped, to end the loop early.  It looks at
+        # the active count every CHECK iterations instead of synchronising with the GPU in each one -- and never when the
+        # threshold cannot be exceeded (max - mean of a distribution over A actions is below 1 - 1/A).
+        CHECK = 8
+        can_stop = float(p.threshold) < 1.0 - 1.0 / A
         for repeat in range(p.repeats):
             self._call(lib.efe_mcts_stop, p_(active), p_(self.stop_at), repeat, float(p.threshold), p_(self.n_active))
-            if int(self.n_active.item()) == 0:          # the only host read of the iteration
+            if can_stop and (repeat % CHECK == 0 or E == 1) and int(self.n_active.item()) == 0:
                 break
             self._call(lib.efe_mcts_select, p_(active), float(p.C), 1 if p.using_prior_for_exploration else 0, self.max_depth,
                        p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))

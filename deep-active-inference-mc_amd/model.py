@@ -24,14 +24,25 @@ from . import _lib
 
 PASS_T1, PASS_D1, PASS_E1, PASS_T2, PASS_D2A, PASS_D2B, PASS_ROOT, PASS_HABIT, PASS_SIM = range(9)
 
-_SHAPES = {
-    'top': {'qpi_net.0': (128, 10), 'qpi_net.2': (128, 128), 'qpi_net.4': (4, 128)},
-    'mid': {'ps_net.0': (512, 14), 'ps_net.3': (512, 512), 'ps_net.6': (512, 512), 'ps_net.9': (20, 512)},
-    'down': {'qs_net.0': (32, 1, 3, 3), 'qs_net.2': (32, 32, 3, 3), 'qs_net.4': (64, 32, 3, 3), 'qs_net.6': (64, 64, 3, 3),
-             'qs_net.9': (256, 576), 'qs_net.12': (256, 256), 'qs_net.15': (256, 256), 'qs_net.18': (20, 256),
-             'po_net.0': (256, 10), 'po_net.3': (256, 256), 'po_net.6': (256, 256), 'po_net.9': (16384, 256),
-             'po_net.13': (64, 64, 3, 3), 'po_net.15': (64, 64, 3, 3), 'po_net.17': (64, 32, 3, 3), 'po_net.19': (32, 1, 3, 3)},
-}
+def layer_shapes(pi_dim=4, channels=1, resolution=64):
+    """state_dict tensor shapes per sub-model (reference key names, torchmodel.py:13-128).  (pi 4, 1 x 64 x 64) is the reference's
+    Dynamic-dSprites model (with the 576-input repair of the first encoder Linear); other geometries are
+    build-defined: four Conv2d(k3, s2) leave h4 x h4 x 64 features, the decoder starts from 64 x res/4 x res/4."""
+    h = resolution
+    for _ in range(4):
+        h = (h - 3) // 2 + 1
+    base = resolution // 4
+    return {
+        'top': {'qpi_net.0': (128, 10), 'qpi_net.2': (128, 128), 'qpi_net.4': (pi_dim, 128)},
+        'mid': {'ps_net.0': (512, pi_dim + 10), 'ps_net.3': (512, 512), 'ps_net.6': (512, 512), 'ps_net.9': (20, 512)},
+        'down': {'qs_net.0': (32, channels, 3, 3), 'qs_net.2': (32, 32, 3, 3), 'qs_net.4': (64, 32, 3, 3), 'qs_net.6': (64, 64, 3, 3),
+                 'qs_net.9': (256, 64 * h * h), 'qs_net.12': (256, 256), 'qs_net.15': (256, 256), 'qs_net.18': (20, 256),
+                 'po_net.0': (256, 10), 'po_net.3': (256, 256), 'po_net.6': (256, 256), 'po_net.9': (64 * base * base, 256),
+                 'po_net.13': (64, 64, 3, 3), 'po_net.15': (64, 64, 3, 3), 'po_net.17': (64, 32, 3, 3), 'po_net.19': (32, channels, 3, 3)},
+    }
+
+
+_SHAPES = layer_shapes()
 _CONVT = ('po_net.13', 'po_net.15', 'po_net.17', 'po_net.19')
 
 
@@ -42,14 +53,17 @@ def _ptr(t):
 class _Engine:
     """Owns one efe_ctx on one device."""
 
-    def __init__(self, device_index):
+    def __init__(self, device_index, cfg=(10, 4, 1, 64)):
         self.lib = _lib.load()
         self.ops = _lib.load_ops()
         if not torch.cuda.is_available():
             raise RuntimeError('deep-active-inference-mc_amd needs a HIP device (MI355X); there is no CPU fallback')
         self.device = torch.device('cuda', device_index)
         self.ctx = C.c_void_p()
-        rc = self.lib.efe_create(C.byref(self.ctx), device_index)
+        rc = self.lib.efe_create_cfg(C.byref(self.ctx), device_index, *[int(v) for v in cfg])
+        if rc == 7:
+            raise ValueError(f'unsupported model geometry (s_dim, pi_dim, colour_channels, resolution) = {tuple(cfg)}: the engine takes '
+                             's_dim 10, pi_dim 2..6, 1..4 channels, resolution a multiple of 4 in [32, 256]')
         if rc != 0:
             raise RuntimeError(f'efe_create failed with code {rc}')
         self.h = int(self.ctx.value)              # context handle as the torch.ops.efe ops take it
@@ -96,7 +110,7 @@ class _Module:
         return {k: v.clone() for k, v in self._sd.items()}
 
     def load_state_dict(self, sd):
-        want = _SHAPES[self._part]
+        want = self._owner._shapes[self._part]
         new = {}
         for name, shape in want.items():
             for suffix in ('weight', 'bias'):
@@ -110,7 +124,7 @@ class _Module:
                     exp = (shape[1],) if name in _CONVT else (shape[0],)
                 if tuple(t.shape) != tuple(exp):
                     hint = ''
-                    if key == 'qs_net.9.weight' and tuple(t.shape) == (256, 256):
+                    if key == 'qs_net.9.weight' and tuple(t.shape) in ((256, 256), (256, 64)):
                         hint = (' (this is the shipped port defect torchmodel.py:94: the encoder emits 576 features; '
                                 'such a checkpoint cannot run the reference either)')
                     raise ValueError(f'{self._part}.{key}: shape {tuple(t.shape)} != {tuple(exp)}{hint}')
@@ -173,7 +187,7 @@ class ModelDown(_Module):
     def __init__(self, owner):
         super().__init__(owner, 'down')
         self.s_dim, self.pi_dim = owner.s_dim, owner.pi_dim
-        self.colour_channels, self.resolution = 1, 64
+        self.colour_channels, self.resolution = owner.colour_channels, owner.resolution
 
     def reparameterize(self, mean, logvar, **kw):
         """torchmodel.py:130-132; the normals come from the model's Philox stream (one stage per call)"""
@@ -182,7 +196,7 @@ class ModelDown(_Module):
     def encoder_with_sample(self, o, stage=None, pass_=PASS_E1, sample=0, eps=None, row_offset=None, _want_s=True):
         m = self._owner
         e = m._ready()
-        o = e.tensor(o, (-1, 1, 64, 64))
+        o = e.tensor(o, (-1, m.colour_channels, m.resolution, m.resolution))
         M = o.shape[0]
         nz = m._noise(stage, pass_, sample, row_offset)
         if eps is None and _want_s and m.eps_source is not None:
@@ -211,17 +225,19 @@ class ActiveInferenceModel:
 
     def __init__(self, s_dim, pi_dim, gamma, beta_s, beta_o, colour_channels=1, resolution=64, *, device=None, seed=0,
                  row_offset=0, init_weights=True):
-        if s_dim != 10 or pi_dim != 4 or colour_channels != 1 or resolution != 64:
-            raise ValueError('the engine implements the Dynamic-dSprites configuration of the reference '
-                             '(s_dim=10, pi_dim=4, 1x64x64); the Animal-AI branch of the reference is not runnable '
-                             '(calc_reward_animalai undefined, torchmodel.py:214)')
+        # (10, 4, 1, 64) is the reference's Dynamic-dSprites model (fused kernels, parity pinned).  Other geometries -- BASELINE
+        # configs[4]: pi 3, 3 x 84 x 84 -- are build-defined and parity-unpinned: the reference rejects the resolution
+        # (torchmodel.py:77-82) and its Animal-AI reward is undefined (torchmodel.py:214); see layer_shapes() / efe_create_cfg.
         if device is None:
             idx = torch.cuda.current_device() if torch.cuda.is_available() else 0
         else:
             idx = torch.device(device).index or 0
-        self._engine = _Engine(idx)
+        self.colour_channels, self.resolution = int(colour_channels), int(resolution)
+        self._engine = _Engine(idx, (s_dim, pi_dim, colour_channels, resolution))
         self.device = self._engine.device
         self.s_dim, self.pi_dim = s_dim, pi_dim
+        self._shapes = layer_shapes(pi_dim, self.colour_channels, self.resolution)
+        self.parity_pinned = (pi_dim, self.colour_channels, self.resolution) == (4, 1, 64)
         self.seed = int(seed)
         self.row_offset = int(row_offset)
         self._stage = 0
@@ -251,7 +267,7 @@ class ActiveInferenceModel:
         g = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFF)
         for part, mod in (('top', self.model_top), ('mid', self.model_mid), ('down', self.model_down)):
             sd = {}
-            for name, shape in _SHAPES[part].items():
+            for name, shape in self._shapes[part].items():
                 if len(shape) == 2:
                     fan = shape[1]
                 elif name in _CONVT:
@@ -379,7 +395,7 @@ class ActiveInferenceModel:
         """torchmodel.py:210-212 on an arbitrary image batch [M,1,64,64] -> [M] (the rollout path computes the same
         expression inside the fused decoder epilogue)"""
         e = self._ready()
-        return e.ops.check_reward(e.h, e.tensor(o, (-1, 1, 64, 64)))
+        return e.ops.check_reward(e.h, e.tensor(o, (-1, self.colour_channels, self.resolution, self.resolution)))
 
     def _reparameterize(self, mean, logvar, stage=None, pass_=PASS_ROOT, sample=0, eps=None, row_offset=None):
         e = self._ready()
@@ -429,7 +445,7 @@ class ActiveInferenceModel:
 
     def _rollout(self, o, pi, steps, calc_mean, samples, per_stage_mean, stage, eps, row_offset):
         e = self._ready()
-        o = e.tensor(o, (-1, 1, 64, 64)); pi = e.tensor(pi, (-1, self.pi_dim))
+        o = e.tensor(o, (-1, self.colour_channels, self.resolution, self.resolution)); pi = e.tensor(pi, (-1, self.pi_dim))
         M = o.shape[0]
         if pi.shape[0] != M:
             raise ValueError('o and pi must have the same number of rows')
@@ -456,7 +472,9 @@ class ActiveInferenceModel:
 
     def calculate_G_4_repeated(self, o, steps=1, calc_mean=False, samples=10, *, stage=None, eps=None, row_offset=None):
         """torchmodel.py:247-268 (4 rows, pi = eye(4); calc_mean switches every stage to calculate_G_mean)"""
-        o = self._engine.tensor(o, (-1, 1, 64, 64))
+        if self.pi_dim != 4:
+            raise ValueError('calculate_G_4_repeated is hard-wired to 4 actions (pi_one_hot, torchmodel.py:251-252)')
+        o = self._engine.tensor(o, (-1, self.colour_channels, self.resolution, self.resolution))
         if o.shape[0] != 4:
             raise ValueError('calculate_G_4_repeated expects 4 rows (torchmodel.py:251-252)')
         return self._rollout(o, self.pi_one_hot, steps, calc_mean, samples, True, stage, eps, row_offset)
@@ -466,7 +484,7 @@ class ActiveInferenceModel:
         """torchmodel.py:329-352 -> G[T]"""
         e = self._ready()
         s0 = e.tensor(s0_traj, (-1, 10)); ps1 = e.tensor(ps1_traj, (-1, 10)); mean = e.tensor(ps1_mean_traj, (-1, 10))
-        lv = e.tensor(ps1_logvar_traj, (-1, 10)); pi0 = e.tensor(pi0_traj, (-1, 4))
+        lv = e.tensor(ps1_logvar_traj, (-1, 10)); pi0 = e.tensor(pi0_traj, (-1, self.pi_dim))
         T = s0.shape[0]
         nz = self._noise(stage, 0, 0, row_offset)
         if eps is None and self.eps_source is not None:

@@ -22,16 +22,17 @@ def plan_actions_batch(model, frames, deepness=10, samples=5, calc_mean=False, t
     import torch
     f = torch.as_tensor(frames)
     n = f.shape[0]
-    f = f.reshape(n, 1, 64, 64)
-    o0_repeated = f.repeat_interleave(4, dim=0)                       # util.py:56-57 (intended row order 4i + a)
-    pi_repeated = torch.eye(4, device=model.device).repeat(n, 1)     # util.py:59-60
+    A = model.pi_dim
+    f = f.reshape(n, model.colour_channels, model.resolution, model.resolution)
+    o0_repeated = f.repeat_interleave(A, dim=0)                       # util.py:56-57 (intended row order A*i + a)
+    pi_repeated = torch.eye(A, device=model.device).repeat(n, 1)     # util.py:59-60
     sum_G, sum_terms, _ = model.calculate_G_repeated(o0_repeated, pi_repeated, steps=deepness, samples=samples,
                                                      calc_mean=calc_mean, **kw)
-    Ppi, log_Ppi = model.action_posterior(sum_G, 4, temperature)     # util.py:68
+    Ppi, log_Ppi = model.action_posterior(sum_G, A, temperature)     # util.py:68
     choices = torch.multinomial(Ppi, 1, generator=generator).squeeze(1)   # util.py:70 (np.random.choice per game)
-    pi0 = torch.zeros(n, 4, device=Ppi.device)
+    pi0 = torch.zeros(n, A, device=Ppi.device)
     pi0[torch.arange(n, device=Ppi.device), choices] = 1.0            # util.py:73-74
-    return pi0, log_Ppi, Ppi, sum_G.reshape(n, 4)
+    return pi0, log_Ppi, Ppi, sum_G.reshape(n, A)
 
 
 def make_batch_dsprites_active_inference(games, model, deepness=10, samples=5, calc_mean=False, repeats=1, generator=None):

@@ -57,6 +57,16 @@ def check_reward(o):
     return torch.mean(calc_reward(o), dim=[1, 2, 3]) * 10.0
 
 
+def check_reward_generic(o):
+    """BUILD-DEFINED reward of the non-dSprites geometries (the reference's `calc_reward_animalai`,
+    torchmodel.py:213-214, does not exist): the NCHW-broadcast target of torchutils.py:34-37 -- 1 for image rows
+    h < H/2, 0 below -- applied to every channel, summed over [1,2,3] like the reference's resolution-32 branch."""
+    H = o.shape[2]
+    target = torch.zeros((1, 1, H, 1), dtype=torch.float32)
+    target[:, :, :H // 2] = 1.0
+    return torch.sum(log_bernoulli(o, target), dim=[1, 2, 3])
+
+
 def softmax_multi_with_log(x, single_values=4, eps=1e-20, temperature=10.0):
     """util.py:46-53 (numpy; note logSM is NOT log(SM) -- replicated as is)."""
     x = x.reshape(-1, single_values)
@@ -81,9 +91,9 @@ class PhiloxNoise:
         ro = self.row_offset if row_offset is None else row_offset
         m = PX.dropout_mask(self.seed, tag, rows, n_feat, pas, sample, stage, ro)
         if fc4_perm:
-            # the engine keys the 16384-wide mask in its NHWC order f' = p*64 + c;
-            # the reference feature index is c*256 + p (Unflatten(1,(64,16,16)), torchmodel.py:119)
-            m = m.reshape(rows, 256, 64).transpose(0, 2, 1).reshape(rows, 16384)
+            # the engine keys the last dense layer's mask in its NHWC order f' = p*64 + c;
+            # the reference feature index is c*P + p (Unflatten(1,(64,B,B)), torchmodel.py:119), P = B*B = n_feat / 64
+            m = m.reshape(rows, n_feat // 64, 64).transpose(0, 2, 1).reshape(rows, n_feat)
         return torch.from_numpy(np.ascontiguousarray(m))
 
     def eps(self, rows, n, pas, sample, stage, row_offset=None):
@@ -136,14 +146,23 @@ def categorical_from_uniform(probs, u):
 class OracleModel:
     """Functional restatement of ActiveInferenceModel (torchmodel.py:149-393) for
     s_dim=10, pi_dim=4, 1x64x64 observations.  `weights` maps the reference's
-    state_dict keys prefixed by 'top.', 'mid.', 'down.' to float32 arrays."""
+    state_dict keys prefixed by 'top.', 'mid.', 'down.' to float32 arrays.
 
-    def __init__(self, weights, noise, s_dim=10, pi_dim=4):
+    `channels` / `resolution` other than (1, 64) select the BUILD-DEFINED geometry of SURVEY 8a-13 (BASELINE configs[4]):
+    the same layer list with the sizes the resolution implies and check_reward_generic -- the reference cannot run it
+    (torchmodel.py:77-82, 213-214), so for that geometry this restatement is the only oracle: PARITY UNPINNED."""
+
+    def __init__(self, weights, noise, s_dim=10, pi_dim=4, channels=1, resolution=64):
         self.w = {k: torch.as_tensor(np.asarray(v, dtype=np.float32)) for k, v in weights.items()}
         self.noise = noise
         self.s_dim = s_dim
         self.pi_dim = pi_dim
-        self.pi_one_hot = torch.eye(4)          # torchmodel.py:164
+        self.channels, self.resolution, self.base = channels, resolution, resolution // 4
+        self.generic = (channels, resolution) != (1, 64)
+        self.pi_one_hot = torch.eye(pi_dim)      # torchmodel.py:164-165
+
+    def check_reward(self, o):
+        return check_reward_generic(o) if self.generic else check_reward(o)
 
     # ---- ModelTop.encode_s (torchmodel.py:27-31); no dropout --------------
     def encode_s(self, s0):
@@ -185,8 +204,8 @@ class OracleModel:
         for li, idx in enumerate((0, 3, 6, 9)):
             h = F.relu(F.linear(h, w[f'down.po_net.{idx}.weight'], w[f'down.po_net.{idx}.bias']))
             nf = h.shape[1]
-            h = h * self.noise.mask(PX.TAG_DEC + li, M, nf, pas, sample, stage, ro, fc4_perm=(nf == 16384))
-        h = h.reshape(M, 64, 16, 16)
+            h = h * self.noise.mask(PX.TAG_DEC + li, M, nf, pas, sample, stage, ro, fc4_perm=(li == 3))
+        h = h.reshape(M, 64, self.base, self.base)
         h = F.relu(F.conv_transpose2d(h, w['down.po_net.13.weight'], w['down.po_net.13.bias'], stride=1, padding=1))
         h = F.relu(F.conv_transpose2d(h, w['down.po_net.15.weight'], w['down.po_net.15.bias'], stride=2, padding=1, output_padding=1))
         h = F.relu(F.conv_transpose2d(h, w['down.po_net.17.weight'], w['down.po_net.17.bias'], stride=2, padding=1, output_padding=1))
@@ -222,7 +241,7 @@ class OracleModel:
             ps1, ps1_mean, ps1_logvar = self.transition_with_sample(pi0, s0, PX.PASS_T1, i, stage, ro)
             po1 = self.decoder(ps1, PX.PASS_D1, i, stage, ro)
             qs1, _, qs1_logvar = self.encoder_with_sample(po1, PX.PASS_E1, i, stage, ro)
-            logpo1 = check_reward(po1)
+            logpo1 = self.check_reward(po1)
             term0 += logpo1
             term1 += -torch.sum(entropy_normal_from_logvar(ps1_logvar) + entropy_normal_from_logvar(qs1_logvar), dim=1)
         term0 /= float(samples)
@@ -248,7 +267,7 @@ class OracleModel:
         _, ps1_mean, ps1_logvar = self.transition_with_sample(pi0, s0, PX.PASS_T1, 0, stage, ro)
         po1 = self.decoder(ps1_mean, PX.PASS_D1, 0, stage, ro)
         _, qs1_mean, qs1_logvar = self.encoder_with_sample(po1, PX.PASS_E1, 0, stage, ro)
-        term0 = check_reward(po1)
+        term0 = self.check_reward(po1)
         term1 = -torch.sum(entropy_normal_from_logvar(ps1_logvar) + entropy_normal_from_logvar(qs1_logvar), dim=1)
         po1_temp1 = self.decoder(self.transition_with_sample(pi0, s0, PX.PASS_T2, 0, stage, ro)[1], PX.PASS_D2A, 0, stage, ro)
         term2_1 = torch.sum(entropy_bernoulli(po1_temp1), dim=[1, 2, 3])
@@ -299,7 +318,7 @@ class OracleModel:
     def calculate_G_given_trajectory(self, s0_traj, ps1_traj, ps1_mean_traj, ps1_logvar_traj, pi0_traj, stage, ro=None):
         po1 = self.decoder(ps1_traj, PX.PASS_D1, 0, stage, ro)
         qs1, _, qs1_logvar = self.encoder_with_sample(po1, PX.PASS_E1, 0, stage, ro)
-        term0 = check_reward(po1)
+        term0 = self.check_reward(po1)
         term1 = -torch.sum(entropy_normal_from_logvar(ps1_logvar_traj) + entropy_normal_from_logvar(qs1_logvar), dim=1)
         po1_temp1 = self.decoder(self.transition_with_sample(pi0_traj, s0_traj, PX.PASS_T2, 0, stage, ro)[0], PX.PASS_D2A, 0, stage, ro)
         term2_1 = torch.sum(entropy_bernoulli(po1_temp1), dim=[1, 2, 3])

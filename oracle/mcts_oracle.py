@@ -90,7 +90,7 @@ def calc_threshold(P):
 
 
 def plan(orc, frame, params, stage0, episode=0):
-    """active_inference_mcts (mcts.py:150-195) for one episode.  frame: [1,64,64] (or anything reshapeable to [1,1,64,64]).
+    """active_inference_mcts (mcts.py:150-195) for one episode.  frame: anything reshapeable to [1, C, R, R] of the oracle's geometry.
     -> (final_path, repeats_done, states_explored, all_paths, all_paths_G, root_N)"""
     A = orc.pi_dim
     stage = [int(stage0)]
@@ -112,7 +112,7 @@ def plan(orc, frame, params, stage0, episode=0):
             node.children[a] = Node(ps_next[a], params.C, A, params.using_prior_for_exploration)
 
     with torch.no_grad():
-        qs0_mean, _ = orc.encoder(torch.as_tensor(frame).reshape(1, 1, 64, 64), PX.PASS_ROOT, 0, take(), episode)
+        qs0_mean, _ = orc.encoder(torch.as_tensor(frame).reshape(1, orc.channels, orc.resolution, orc.resolution), PX.PASS_ROOT, 0, take(), episode)
         root = Node(qs0_mean[0], params.C, A, params.using_prior_for_exploration)
         root.Qpi = orc.encode_s(qs0_mean)[1][0]
         all_paths, all_G, explored = [], [], 0

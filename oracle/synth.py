@@ -34,10 +34,23 @@ def _fan_in(name, shape):
     return shape[1] * 9
 
 
-def make_weights(seed=1234, gain=1.0):
+def specs_for(pi_dim=4, channels=1, resolution=64):
+    """(key, shape) list for a geometry: SPECS for the reference's dSprites model; build-defined sizes otherwise"""
+    if (pi_dim, channels, resolution) == (4, 1, 64):
+        return SPECS
+    h = resolution
+    for _ in range(4):
+        h = (h - 3) // 2 + 1
+    base = resolution // 4
+    repl = {'top.qpi_net.4': (pi_dim, 128), 'mid.ps_net.0': (512, pi_dim + 10), 'down.qs_net.0': (32, channels, 3, 3),
+            'down.qs_net.9': (256, 64 * h * h), 'down.po_net.9': (64 * base * base, 256), 'down.po_net.19': (32, channels, 3, 3)}
+    return [(k, repl.get(k, shp)) for k, shp in SPECS]
+
+
+def make_weights(seed=1234, gain=1.0, pi_dim=4, channels=1, resolution=64):
     """dict key -> float32 array; keys are '<top|mid|down>.<state_dict key>'."""
     w = {}
-    for i, (name, shape) in enumerate(SPECS):
+    for i, (name, shape) in enumerate(specs_for(pi_dim, channels, resolution)):
         fan = _fan_in(name, shape)
         # dropout(0.5) doubles the second moment of kept activations, so use sqrt(3/fan) for the
         # layers that follow a dropout and sqrt(6/fan) elsewhere; overall scale via `gain`.
@@ -51,6 +64,19 @@ def make_weights(seed=1234, gain=1.0):
     for k in ('mid.ps_net.9', 'down.qs_net.18'):
         w[k + '.bias'][10:] -= 2.0
     return w
+
+
+def make_frames_rgb(seed, n, channels=3, resolution=84):
+    """[n, C, R, R] float32 synthetic colour frames (a filled box per channel on a dim background), values in [0, 1]"""
+    u = PX.uniform_fill(seed, (n, channels, 5), 2000, 0.0, 1.0)
+    frames = np.zeros((n, channels, resolution, resolution), dtype=np.float32)
+    for i in range(n):
+        for c in range(channels):
+            side = 8 + int(u[i, c, 0] * (resolution // 3))
+            y = int(u[i, c, 1] * (resolution - side)); x = int(u[i, c, 2] * (resolution - side))
+            frames[i, c] = 0.1 * u[i, c, 3]
+            frames[i, c, y:y + side, x:x + side] = 0.5 + 0.5 * u[i, c, 4]
+    return frames
 
 
 def make_frames(seed, n):

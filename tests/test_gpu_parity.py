@@ -457,7 +457,7 @@ def test_api_errors_are_loud(models):
         m.calculate_G_4_repeated(np.zeros((3, 1, 64, 64), np.float32))
     with pytest.raises(ValueError):
         import daimc_amd
-        daimc_amd.ActiveInferenceModel(10, 3, 0.0, 1.0, 1.0)
+        daimc_amd.ActiveInferenceModel(10, 9, 0.0, 1.0, 1.0)          # pi_dim outside 2..6
     import daimc_amd
     p = daimc_amd.MCTS_Params()
     assert daimc_amd.active_inference_mcts(m, [], p) == ([0], 0, 0, [], [])
