@@ -135,7 +135,7 @@ def mcts_flops_per_decision(samples, repeats=50, depth=5):
     return 2.0 * ((repeats + 1) * 4 * g_row + repeats * sim)
 
 
-def cpu_baseline_mcts(samples, depth=5, repeats_sample=3):
+def cpu_baseline_mcts(samples, depth=5, repeats_sample=12):
     """BASELINE configs[2] on the CPU as the reference would run it: ONE episode at a time through the oracle planner
     (oracle/mcts_oracle.py), torch RNG.  Bounded sample: `repeats_sample` planner iterations (+ the root expansion) instead
     of 50; decisions/s is extrapolated by algorithmic FLOPs (every iteration costs the same)."""
@@ -246,6 +246,80 @@ def bench_mcts(a, model, device, world, rank, dist, steps, warmup, with_cpu):
     return out
 
 
+def cpu_baseline_generic(A, C, R, depth, samples):
+    """configs[4] on the CPU: the build-defined oracle restatement (parity unpinned), one bounded pass; rollouts/s extrapolated
+    by (depth x samples) -- every (stage, sample) costs the same"""
+    from oracle import synth
+    from oracle.efe_oracle import OracleModel, TorchNoise
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    m = OracleModel(synth.make_weights(1234, 1.15, A, C, R), TorchNoise(), pi_dim=A, channels=C, resolution=R)
+    o = torch.from_numpy(np.repeat(synth.make_frames_rgb(5, 4, C, R), A, axis=0))
+    pi = torch.eye(A).repeat(4, 1)
+    d, sm = 1, 3
+    with torch.no_grad():
+        m.calculate_G_repeated(o[:A], pi[:A], 1, False, 1, 0)
+        t = time.perf_counter()
+        m.calculate_G_repeated(o, pi, d, False, sm, 0)
+        dt = time.perf_counter() - t
+    rows = o.shape[0]
+    frac = (d * sm) / (depth * samples)
+    return {'value': rows * frac / dt, 'unit': 'rollouts/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
+            'sample': f'{rows} rows x depth {d} x {sm} MC samples in {dt:.1f} s, extrapolated to depth {depth} x {samples} samples (x{1 / frac:.0f}); '
+                      f'build-defined oracle restatement (oracle/efe_oracle.py, channels={C}, resolution={R}), torch RNG; parity unpinned'}
+
+
+def bench_generic(a, device, world, rank, dist, steps, warmup, with_cpu):
+    """BASELINE configs[4]: Animal-AI-sized observations (3 x 84 x 84, 3 actions), 30 MC samples, depth 7, 32 episodes per GPU
+    (256 over 8 GPUs).  Build-defined network, PARITY UNPINNED: no reference semantics exist for this geometry."""
+    import daimc_amd
+    A, C, R, S, D, E = 3, 3, 84, 30, 7, 32
+    rows = E * A
+    model = daimc_amd.ActiveInferenceModel(10, A, 0.0, 1.0, 1.0, colour_channels=C, resolution=R, device=device, seed=1, row_offset=rank * rows)
+    g = torch.Generator().manual_seed(300 + rank)
+    frames = torch.rand(E, C, R, R, generator=g).to(device)
+    o = frames.repeat_interleave(A, dim=0).contiguous()
+    pi = torch.eye(A, device=device).repeat(E, 1).contiguous()
+    model.reserve(rows, D, S)
+
+    def step(k):
+        G, _, _ = model.calculate_G_repeated(o, pi, steps=D, samples=S, stage=k * D)
+        P, _ = model.action_posterior(G, A)
+        if world > 1:
+            daimc_amd.gather_action_posteriors(P, world * E)
+        return G
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    for k in range(warmup):
+        step(k)
+    sync()
+    macs_row = model.last_call_macs() / rows
+    regions, _ = timed_regions(step, steps, warmup, sync, min_total_s=1.0, max_regions=4)
+    if world > 1:
+        t = torch.tensor(regions, device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        regions = [float(x) for x in t]
+    dt = statistics.median(regions)
+    value = world * rows * steps / dt
+    tf = value * 2 * macs_row / 1e12
+    out = {'metric': 'EFE rollouts/sec (84x84 RGB, 30 MC-samples, depth 7)', 'value': value, 'unit': 'rollouts/s', 'n_gpus': world,
+           'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * dt / steps, 'timed_regions': len(regions),
+           'region_ms': [round(1e3 * x, 3) for x in regions], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32', 'data': 'synthetic', 'parity': 'unpinned: build-defined network, no reference semantics (SURVEY 8a-13)',
+           'config': {'workload': f'calculate_G_repeated: {rows} rows ({E} episodes x {A} actions) x depth {D} x {S} MC samples per GPU, '
+                                  f'{C} x {R} x {R} observations (BASELINE configs[4]) + action posterior', 'rows_per_gpu': rows},
+           'gflop_per_rollout': 2 * macs_row / 1e9, 'achieved_tflops_total': tf,
+           'roofline': {'bound': 'mfma', 'kernel': 'whole step (generic layer-by-layer convolution path)', 'achieved': tf / world,
+                        'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s', 'frac': tf / world / PEAK_FP32_MFMA_TF, 'traffic': None}}
+    if with_cpu:
+        out['cpu_baseline'] = cpu_baseline_generic(A, C, R, D, S)
+        out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -256,8 +330,9 @@ def main():
     ap.add_argument('--depth', type=int, default=5)
     ap.add_argument('--dec-chunk', type=int, default=0)
     ap.add_argument('--opt', action='append', default=[], help='engine option name=value')
-    ap.add_argument('--workload', default='rollout', choices=['rollout', 'mcts'],
-                    help="'mcts' = only BASELINE configs[2]: full lock-step MCTS (50 expansions, 10 samples, sim depth 5) over 64 episodes/GPU")
+    ap.add_argument('--workload', default='rollout', choices=['rollout', 'mcts', 'animalai'],
+                    help="'mcts' = only BASELINE configs[2]: full lock-step MCTS (50 expansions, 10 samples, sim depth 5) over 64 episodes/GPU; "
+                         "'animalai' = only BASELINE configs[4]: 3 x 84 x 84 observations, 30 samples, depth 7, 32 episodes/GPU (parity unpinned)")
     ap.add_argument('--episodes', type=int, default=64)
     ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path on a 1-GPU box')
     ap.add_argument('--no-cpu', action='store_true')
@@ -283,6 +358,13 @@ def main():
     torch.cuda.set_device(device)
 
     import daimc_amd
+    if a.workload == 'animalai':
+        out = bench_generic(a, device, world, rank, dist, max(1, min(a.steps, 3)), max(1, min(a.warmup, 1)), world == 1 and not a.no_cpu)
+        if rank == 0:
+            print(json.dumps(out))
+        if use_dist:
+            dist.destroy_process_group()
+        return
     R = a.rows or (128 if world == 1 else 256)
     S, D = a.samples, a.depth
     model = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device=device, seed=1, row_offset=rank * R)
@@ -397,6 +479,9 @@ def main():
     if world == 1 and not a.no_extras and not a.force_dist:
         mc = bench_mcts(a, model, device, 1, 0, None, 3, 1, not a.no_cpu)
         out['extras'] = {'mcts_cfg3': mc}
+        del model
+        torch.cuda.empty_cache()
+        out['extras']['animalai_cfg5'] = bench_generic(a, device, 1, 0, None, 2, 1, not a.no_cpu)
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

@@ -507,6 +507,15 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
 #endif
 }
 
+// DPP row shifts of one fp32 register inside 16-lane rows (measured semantics, tools/ubench/dpp_probe.hip): shr1: lane i <- lane i - 1,
+// shl1: lane i <- lane i + 1; lanes without a source are zero (_zero) or keep `old` (_keep); ror1: lane i <- lane (i - 1) & 15, ror15: <- (i + 1) & 15
+__device__ __forceinline__ float dpp_shr1_zero(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true)); }
+__device__ __forceinline__ float dpp_shl1_zero(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, true)); }
+__device__ __forceinline__ float dpp_shr1_keep(float old, float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_shl1_keep(float old, float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_ror1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_ror15(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x12f, 0xf, 0xf, false)); }
+
 // ---------------------------------------------------------------------------------------------------------
 // k_dec_b4: the same layer pair, INPUT-STATIONARY.  One wave owns one input row of the strip (32 positions) and ALL FOUR output
 // parities of it.  The nine (kh, kw) taps of the stride-2 transposed conv read only four shifted views of the input,
@@ -514,8 +523,14 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
 //     shift (+1,0): parities (1,0) (1,1)                          shift (+1,+1): parity (1,1)
 // so a B fragment (LDS) is read once per shift and chunk and feeds up to four INDEPENDENT accumulator chains (4 / 2 / 2 / 1
 // weight fragments): 9 tap-tiles per wave for every wave (the parity-pair split of k_dec_b gives 5 and 4), 4 LDS reads per chunk
-// instead of 9, and back-to-back MFMAs never wait on their own accumulator.  SR = 4 input rows per strip, 4 waves, two workgroups
-// per CU (65 KiB LDS, <= 256 VGPRs).
+// instead of 9, and back-to-back MFMAs never wait on their own accumulator.  SR = 4 input rows per strip, 4 waves.
+//
+// The 32 -> 1 conv: tap planes by v_mfma_f32_16x16x1_4b on the accumulators (as in k_dec_b), with the taps placed in A rows
+// {0-2, 4-6, 8-10} so that the 16-lane group kh of a wave holds the three kw taps of every pixel.  The horizontal part of the 3 x 3
+// sum is then formed IN REGISTERS (the two column parities of a pixel are the same lane of two accumulators, its left / right
+// neighbours one DPP row shift away):   H[kh][r][ow] = sum_kw T[kh,kw][r][ow + 1 - kw],
+// and only the three H planes of a source row go through LDS (two ds_write_b64 per parity row instead of twenty ds_write_b32; the
+// gather reads 3 values per pixel instead of 9).  The plane ring shrinks from 23.7 to 7.7 KiB: 49 KiB of LDS per workgroup.
 // ---------------------------------------------------------------------------------------------------------
 #ifndef EFE_B4_WAVES
 #define EFE_B4_WAVES 2
@@ -528,8 +543,7 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
     constexpr int NPF = (SR + 1) * 512 / NTHR;        // 10 float4s of the input strip per thread
     constexpr int NS = 32 / SR;
     extern __shared__ __attribute__((aligned(16))) float4 sm[];
-    constexpr int TS = 66;
-    float* sT = reinterpret_cast<float*>(sm + DB_IN_F4);
+    float* sH = reinterpret_cast<float*>(sm + DB_IN_F4);       // [ring row][kh][64 output columns]
     __shared__ float sred[NW];
     __shared__ float4 sb3[8];
     const int tid = threadIdx.x;
@@ -550,12 +564,13 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
     if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];
     float w4f[16];
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-        const float4 q = ((lane & 15) < 9) ? reinterpret_cast<const float4*>(a.w4 + (lane & 15) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g4 = 0; g4 < 4; ++g4) {                   // A row i = lane & 15 holds tap (kh, kw) = (i >> 2, i & 3); rows with (i & 3) == 3 and rows 12..15 are padding
+        const int ti_ = lane & 15;
+        const bool tv_ = (ti_ & 3) < 3 && ti_ < 12;
+        const float4 q = tv_ ? reinterpret_cast<const float4*>(a.w4 + (3 * (ti_ >> 2) + (ti_ & 3)) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
         w4f[4 * g4] = q.x; w4f[4 * g4 + 1] = q.y; w4f[4 * g4 + 2] = q.z; w4f[4 * g4 + 3] = q.w;
     }
     if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = tid; i < DB_YROWS * 9 * 2; i += NTHR) sT[(i >> 1) * TS + (i & 1) * (TS - 1)] = 0.f;
 
     const float4* X = reinterpret_cast<const float4*>(a.y2) + (size_t)img * (32 * 32 * 16);
     const float4* W3 = reinterpret_cast<const float4*>(a.w3);
@@ -580,26 +595,16 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
     auto wf = [&](int tap, int kc) -> float4 { return wfrag(wr, ln, (size_t)(tap * 8 + kc) * 64); };
 
     for (int s = 0; s < NS; ++s) {
+        const int tl = tid;        // (laundering the index per strip frees ~20 VGPRs -- 168, three waves per SIMD, 4 spills -- for no gain: 0.814 vs 0.812)
 #pragma unroll
         for (int it = 0; it < NPF; ++it) {
-            const int idx = it * NTHR + tid;
+            const int idx = it * NTHR + tl;
             const int rl = idx >> 9, seg = (idx & 511) >> 5, wi = idx & 31;
             const int ix = 2 * (wi >> 1) + (seg >> 3), c4 = 2 * (seg & 7) + (wi & 1);
             smv[swz(rl * 32 + ix, c4)] = (SR * s + rl < 32) ? pf[it] : (f32x4)(0.f);
         }
         float4 a0 = wf(4, 0), a1 = wf(5, 0), a2 = wf(7, 0), a3 = wf(8, 0);      // the strip's first weight fragments: in flight across the barrier
         __syncthreads();
-#ifndef EFE_B4_PF_LATE
-        {   // request strip s+1 (rows >= 32 are clamped here and zeroed when staged)
-            const int sn = (s < NS - 1) ? s + 1 : NS - 1;
-#pragma unroll
-            for (int it = 0; it < NPF; ++it) {
-                const int idx = it * NTHR + tid;
-                const int grow = min(SR * sn + (idx >> 9), 31);
-                pf[it] = Xv[y2_at(grow, idx)];
-            }
-        }
-#endif
 
         f32x16 acc[4];
 #pragma unroll
@@ -653,58 +658,68 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
             }
         }
         // ---- ReLU, then the 32 -> 1 conv as tap planes: 16 x v_mfma_f32_16x16x1_4b per parity, the four parities' chains interleaved
-        f32x16 T2[4];
+        // one output-row parity ph (two column parities) at a time: 2 x 16 tap-plane registers live instead of 4 x 16
 #pragma unroll
-        for (int p_ = 0; p_ < 4; ++p_) {
+        for (int ph = 0; ph < 2; ++ph) {
+            f32x16 T0, T1;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[p_][e] = relu_bits(acc[p_][e]); T2[p_][e] = 0.f; }
-        }
+            for (int e = 0; e < 16; ++e) {
+                acc[2 * ph][e] = relu_bits(acc[2 * ph][e]); acc[2 * ph + 1][e] = relu_bits(acc[2 * ph + 1][e]);
+                T0[e] = 0.f; T1[e] = 0.f;
+            }
 #ifdef EFE_X_NO_TMFMA
-#pragma unroll
-        for (int p_ = 0; p_ < 4; ++p_) T2[p_] = acc[p_];
+            T0 = acc[2 * ph]; T1 = acc[2 * ph + 1];
 #else
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-#pragma unroll
-            for (int p_ = 0; p_ < 4; ++p_) T2[p_] = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[p_][e], T2[p_], 0, 0, 0);
-        }
+            for (int e = 0; e < 16; ++e) {
+                T0 = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[2 * ph][e], T0, 0, 0, 0);
+                T1 = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[2 * ph + 1][e], T1, 0, 0, 0);
+            }
 #endif
 #ifdef EFE_X_NO_TWRITE
-        if (T2[0][0] == 12345.678f) sT[lane] = T2[1][1] + T2[2][2] + T2[3][3];
+            if (T0[0] == 12345.678f) sH[lane] = T0[1] + T1[2];
 #else
-        {
-            const int tq = lane >> 4, c = lane & 15;
+            {
+                // D layout of the 4-block MFMA: T[4 b + r] = D_b[row 4 (lane >> 4) + r][col lane & 15], block b = (channel half) * 2 + (pixel half):
+                // lane (kh = lane >> 4, c = lane & 15) holds taps (kh, kw = r) of input columns c (regs 0-2, 8-10) and 16 + c (regs 4-6, 12-14);
+                // T0 / T1 = column parity 0 (x = 2 c') / 1 (x = 2 c' + 1)
+                const int kh = lane >> 4, c = lane & 15;
+                float X0[2][3], X1[2][3];                                   // [column half][kw], channel halves added
 #pragma unroll
-            for (int p_ = 0; p_ < 4; ++p_) {
-                const int ph = p_ >> 1, pw = p_ & 1;
-                const f32x16 T = T2[p_];
-                const int orow = 2 * (SR * s + w) + ph;
-                float* tp = sT + ((orow % DB_YROWS) * 9 + 4 * tq) * TS + 1 + pw;
-                if (tq < 2) {
+                for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        tp[r4 * TS + 2 * c] = T[r4] + T[8 + r4];
-                        tp[r4 * TS + 2 * (16 + c)] = T[4 + r4] + T[12 + r4];
+                    for (int kw = 0; kw < 3; ++kw) {
+                        X0[hb][kw] = T0[4 * hb + kw] + T0[8 + 4 * hb + kw];
+                        X1[hb][kw] = T1[4 * hb + kw] + T1[8 + 4 * hb + kw];
                     }
-                } else if (tq == 2) {
-                    tp[2 * c] = T[0] + T[8];
-                    tp[2 * (16 + c)] = T[4] + T[12];
+                // out column 2c'   takes kw = 0 from x = 2c' + 1, kw = 1 from x = 2c', kw = 2 from x = 2c' - 1 (odd column of c' - 1)
+                // out column 2c'+1 takes kw = 0 from x = 2c' + 2 (even column of c' + 1), kw = 1 from x = 2c' + 1, kw = 2 from x = 2c'
+                const float l0 = dpp_shr1_zero(X1[0][2]);                                  // c' - 1 for c' = 0..15 (c' = 0: image edge)
+                const float l1 = dpp_shr1_keep(dpp_ror1(X1[0][2]), X1[1][2]);              // c' = 16: column 15 lives in lane 15 of the first half
+                const float r0 = dpp_shl1_keep(dpp_ror15(X0[1][0]), X0[0][0]);             // c' = 15: column 16 lives in lane 0 of the second half
+                const float r1 = dpp_shl1_zero(X0[1][0]);                                  // c' = 31: image edge
+                float2 e0, e1;
+                e0.x = (X1[0][0] + X0[0][1]) + l0;  e0.y = (r0 + X1[0][1]) + X0[0][2];
+                e1.x = (X1[1][0] + X0[1][1]) + l1;  e1.y = (r1 + X1[1][1]) + X0[1][2];
+                if (kh < 3) {
+                    const int orow = 2 * (SR * s + w) + ph;
+                    float* hp = sH + ((orow % DB_YROWS) * 3 + kh) * 64 + 2 * c;
+                    *reinterpret_cast<float2*>(hp) = e0;
+                    *reinterpret_cast<float2*>(hp + 32) = e1;
                 }
             }
-        }
 #endif
+        }
         __syncthreads();
-#ifdef EFE_B4_PF_LATE
         {   // request strip s+1 behind the MFMA phase (vmcnt retires in order: an HBM load in front of the weight-fragment loads stalls them)
             const int sn = (s < NS - 1) ? s + 1 : NS - 1;
 #pragma unroll
             for (int it = 0; it < NPF; ++it) {
-                const int idx = it * NTHR + tid;
+                const int idx = it * NTHR + tl;
                 const int grow = min(SR * sn + (idx >> 9), 31);
                 pf[it] = Xv[y2_at(grow, idx)];
             }
         }
-#endif
 
         // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete (row 63 after the last strip)
         constexpr int RWG = 2 * SR / NW;
@@ -713,18 +728,14 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
             if (q == RWG && w != 0) break;
             const int oh = 2 * SR * s - 1 + q * NW + w, ow = lane;
             if (oh < 0) continue;
-            float tv[9];
+            // out[oh][ow] = b4 + H[0][oh + 1][ow] + H[1][oh][ow] + H[2][oh - 1][ow]   (source row r contributes to oh = r - 1 + kh)
+            float v = a.b4;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const int tr = oh + 1 - kh;
                 const bool rv = tr >= 0 && tr <= 63;
-                const float* trow = sT + (((rv ? tr : 0) % DB_YROWS) * 9 + kh * 3) * TS + ow + 2;
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) tv[kh * 3 + kw] = rv ? trow[kw * TS - kw] : 0.f;
+                v += rv ? sH[(((rv ? tr : 0) % DB_YROWS) * 3 + kh) * 64 + ow] : 0.f;
             }
-            float v = a.b4;
-#pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9) v += tv[t9];
             const float pr = 1.0f / (1.0f + EFE_EXP(-v));
             if (po) {
                 int owl = ow; asm volatile("" : "+v"(owl));
@@ -743,8 +754,9 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
 }
 
 constexpr size_t DB_LDS4 = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 66 * sizeof(float);
+constexpr size_t DB_LDS4H = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 3 * 64 * sizeof(float);      // k_dec_b4: H planes instead of tap planes
 int init_dec_b_kernels() {
-    if (hipFuncSetAttribute((const void*)(k_dec_b4), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)(k_dec_b4), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4H) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)(k_dec_b<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)(k_dec_b<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4) != hipSuccess) return 1;
     return 0;
@@ -753,9 +765,9 @@ int init_dec_b_kernels() {
 void launch_dec_b(const DecBArgs& a, hipStream_t st) {
     const size_t lds4 = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 66 * sizeof(float);
     const size_t lds2 = ((3 * 32 + 1) * 16) * sizeof(float4) + 6 * 9 * 66 * sizeof(float);
-    if (a.dbg & 32) {           // input-stationary form: one wave = one strip row x four parities (four accumulator chains per B fragment)
-        hipLaunchKernelGGL(k_dec_b4, dim3(a.rows), dim3(256), lds4, st, a);
-    } else if (!(a.dbg & 24)) {        // default: 2-row strips, four one-row waves per workgroup, 38 KiB LDS: four workgroups (four independent
+    if (!(a.dbg & (8 | 16 | 64))) {     // default: input-stationary form, one wave = one strip row x four parities, H planes (0.81 of the fp32 MFMA peak alone)
+        hipLaunchKernelGGL(k_dec_b4, dim3(a.rows), dim3(256), DB_LDS4H, st, a);
+    } else if (a.dbg & 64) {           // round-1 default: 2-row strips, four one-row waves per workgroup, 38 KiB LDS: four workgroups (four independent
                                 // barrier domains) and 16 waves per CU.  Measured 0.795 of the fp32 MFMA peak (k_dec_b alone, 19200 images)
         hipLaunchKernelGGL((k_dec_b<2, 1>), dim3(a.rows), dim3(256), lds2, st, a);
     } else if (a.dbg & 8) {     // 4-row strips, eight one-row waves, two workgroups per CU: 0.767

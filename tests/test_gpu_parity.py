@@ -235,7 +235,7 @@ def test_chunking_invariance(models):
     assert torch.equal(G1, G2) and torch.equal(po1, po2)
 
 
-@pytest.mark.parametrize('opt,val', [('dbg_b', 8), ('dbg_b', 16), ('dbg_a', 4)])
+@pytest.mark.parametrize('opt,val', [('dbg_b', 8), ('dbg_b', 16), ('dbg_b', 64), ('dbg_a', 4)])
 def test_kernel_variants_agree(models, opt, val):
     """the alternative workgroup shapes of the decoder kernels (4-row strips / 8 waves, 4-row strips / 4 waves for
     k_dec_b; 8-wave k_dec_a) compute the same images bit for bit and the same pixel sums up to the order in which
@@ -249,7 +249,10 @@ def test_kernel_variants_agree(models, opt, val):
         G2, t2, po2 = m.calculate_G_repeated(o, pi, steps=2, samples=3, stage=5)
     finally:
         m.set_option(opt, 0)
-    assert torch.equal(po1, po2)
+    if opt == 'dbg_b':       # the default k_dec_b4 adds the nine taps of the final conv in a different order (kw inside kh) than the k_dec_b forms: a few ulp per pixel
+        np.testing.assert_allclose(c(po2), c(po1), rtol=0, atol=2e-6)
+    else:
+        assert torch.equal(po1, po2)
     np.testing.assert_allclose(c(G2), c(G1), rtol=0, atol=2e-2)
     np.testing.assert_allclose(c(t2[0]), c(t1[0]), rtol=1e-5, atol=1e-4)
 
