@@ -513,6 +513,8 @@ __device__ __forceinline__ float dpp_shr1_zero(float x) { return __builtin_bit_c
 __device__ __forceinline__ float dpp_shl1_zero(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, true)); }
 __device__ __forceinline__ float dpp_shr1_keep(float old, float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, false)); }
 __device__ __forceinline__ float dpp_shl1_keep(float old, float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, false)); }
+__device__ __forceinline__ float wave_shr1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true)); }   // lane i <- i - 1 over the wave
+__device__ __forceinline__ float wave_shl1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true)); }   // lane i <- i + 1
 __device__ __forceinline__ float dpp_ror1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false)); }
 __device__ __forceinline__ float dpp_ror15(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x12f, 0xf, 0xf, false)); }
 
@@ -534,6 +536,9 @@ __device__ __forceinline__ float dpp_ror15(float x) { return __builtin_bit_cast(
 // ---------------------------------------------------------------------------------------------------------
 #ifndef EFE_B4_WAVES
 #define EFE_B4_WAVES 2
+#endif
+#if !defined(EFE_B4_T16) && !defined(EFE_B4_T4X4)
+#define EFE_B4_T4X4 1        // tap contraction of the 32 -> 1 conv: 16-block 4x4x1 MFMA (default, 0.826 alone) or 4-block 16x16x1 (EFE_B4_T16, 0.812)
 #endif
 __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) {
     constexpr int SR = 4, NW = 4, NTHR = 256;
@@ -570,6 +575,18 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
         const float4 q = tv_ ? reinterpret_cast<const float4*>(a.w4 + (3 * (ti_ >> 2) + (ti_ & 3)) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
         w4f[4 * g4] = q.x; w4f[4 * g4 + 1] = q.y; w4f[4 * g4 + 2] = q.z; w4f[4 * g4 + 3] = q.w;
     }
+#ifdef EFE_B4_T4X4
+    // 16-block 4x4x1 form of the tap contraction: block = 4 consecutive lanes = 4 pixels of one channel half, A row i = lane & 3 = kw,
+    // one instruction per (kh, accumulator register): 3 x 16 A registers, 12 tap rows (9 used) instead of 16
+    float w4g[3][16];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 q = ((lane & 3) < 3) ? reinterpret_cast<const float4*>(a.w4 + (3 * kh + (lane & 3)) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+            w4g[kh][4 * g4] = q.x; w4g[kh][4 * g4 + 1] = q.y; w4g[kh][4 * g4 + 2] = q.z; w4g[kh][4 * g4 + 3] = q.w;
+        }
+#endif
     if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const float4* X = reinterpret_cast<const float4*>(a.y2) + (size_t)img * (32 * 32 * 16);
@@ -658,6 +675,38 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
             }
         }
         // ---- ReLU, then the 32 -> 1 conv as tap planes: 16 x v_mfma_f32_16x16x1_4b per parity, the four parities' chains interleaved
+#ifdef EFE_B4_T4X4
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            f32x4 Tq[2][3];                                  // [column parity][kh]: registers kw = 0..2 (3 = padding) of this lane's pixel and channel half
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[2 * ph][e] = relu_bits(acc[2 * ph][e]); acc[2 * ph + 1][e] = relu_bits(acc[2 * ph + 1][e]); }
+#pragma unroll
+            for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) Tq[pw][kh] = (f32x4)(0.f);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    Tq[0][kh] = __builtin_amdgcn_mfma_f32_4x4x1f32(w4g[kh][e], acc[2 * ph][e], Tq[0][kh], 0, 0, 0);
+                    Tq[1][kh] = __builtin_amdgcn_mfma_f32_4x4x1f32(w4g[kh][e], acc[2 * ph + 1][e], Tq[1][kh], 0, 0, 0);
+                }
+            // horizontal presum per channel half (the halves are added by the gather): lane = (pixel c' = lane & 31, half h)
+            const int orow = 2 * (SR * s + w) + ph;
+            float* hp = sH + (((orow % DB_YROWS) * 2 + h) * 3) * 64 + 2 * j;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                float l = wave_shr1(Tq[1][kh][2]), r = wave_shl1(Tq[0][kh][0]);
+                l = (j == 0) ? 0.f : l;                       // lane 32 received lane 31 (the other channel half's pixel 31): image edge
+                r = (j == 31) ? 0.f : r;
+                float2 eo;
+                eo.x = (Tq[1][kh][0] + Tq[0][kh][1]) + l;
+                eo.y = (r + Tq[1][kh][1]) + Tq[0][kh][2];
+                *reinterpret_cast<float2*>(hp + kh * 64) = eo;
+            }
+        }
+#else
         // one output-row parity ph (two column parities) at a time: 2 x 16 tap-plane registers live instead of 4 x 16
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
@@ -710,6 +759,7 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
             }
 #endif
         }
+#endif
         __syncthreads();
         {   // request strip s+1 behind the MFMA phase (vmcnt retires in order: an HBM load in front of the weight-fragment loads stalls them)
             const int sn = (s < NS - 1) ? s + 1 : NS - 1;
@@ -734,7 +784,12 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
             for (int kh = 0; kh < 3; ++kh) {
                 const int tr = oh + 1 - kh;
                 const bool rv = tr >= 0 && tr <= 63;
+#ifdef EFE_B4_T4X4
+                const float* hq = sH + ((((rv ? tr : 0) % DB_YROWS) * 2) * 3 + kh) * 64 + ow;
+                v += rv ? hq[0] + hq[3 * 64] : 0.f;          // the two channel halves
+#else
                 v += rv ? sH[(((rv ? tr : 0) % DB_YROWS) * 3 + kh) * 64 + ow] : 0.f;
+#endif
             }
             const float pr = 1.0f / (1.0f + EFE_EXP(-v));
             if (po) {
@@ -754,7 +809,11 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
 }
 
 constexpr size_t DB_LDS4 = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 66 * sizeof(float);
+#ifdef EFE_B4_T4X4
+constexpr size_t DB_LDS4H = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 2 * 3 * 64 * sizeof(float);  // k_dec_b4: H planes per channel half
+#else
 constexpr size_t DB_LDS4H = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 3 * 64 * sizeof(float);      // k_dec_b4: H planes instead of tap planes
+#endif
 int init_dec_b_kernels() {
     if (hipFuncSetAttribute((const void*)(k_dec_b4), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4H) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)(k_dec_b<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4) != hipSuccess) return 1;
