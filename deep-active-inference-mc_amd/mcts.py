@@ -232,6 +232,16 @@ class BatchedMCTS:
         self.sims = torch.zeros(max(1, params.simulation_repeats), E, device=dev)
         self.stop_at = torch.full((E,), -1, dtype=torch.int32, device=dev)
         self.n_active = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.q0 = torch.zeros(E, A, device=dev)
+        # The simulation of an iteration (habit rollout from the leaf + G over its trajectory: ~1 ms of small launches) is
+        # independent of the expansion of the same leaf (~6 ms of large ones): with more than a few episodes it runs on a second
+        # stream through a replica context, so its launch-bound chain hides under the expansion's MFMA-bound kernels.
+        self.overlap = E >= 8 and getattr(params, 'overlap_simulate', True)
+        if self.overlap:
+            self.sim_model = model.replica()
+            self.sim_stream = torch.cuda.Stream(device=dev)
+            self.ev_sel = torch.cuda.Event()
+            self.ev_sim = torch.cuda.Event()
 
     def _call(self, fn, *args):
         e = self.model._ready()
@@ -242,14 +252,14 @@ class BatchedMCTS:
         import ctypes as C
         return C.c_void_p(t.data_ptr())
 
-    def _expand(self, nodes, mask, states_rep):
+    def _expand(self, nodes, mask, states_rep, stage=None):
         """ONE engine call over E x pi_dim rows (Node.expand, mcts.py:64-86); tree bookkeeping only where mask[e]"""
         m, p_ = self.model, self._p
         ro = self.ep0 * self.pi_dim
         if self.p.use_means:
-            G, _, ps_next, _ = m.calculate_G_mean(states_rep, self.pi_hot, row_offset=ro)
+            G, _, ps_next, _ = m.calculate_G_mean(states_rep, self.pi_hot, row_offset=ro, stage=stage)
         else:
-            G, _, ps_next, _, _ = m.calculate_G(states_rep, self.pi_hot, samples=getattr(self.p, 'samples', 1), row_offset=ro)
+            G, _, ps_next, _, _ = m.calculate_G(states_rep, self.pi_hot, samples=getattr(self.p, 'samples', 1), row_offset=ro, stage=stage)
         G, ps_next = G.contiguous(), ps_next.contiguous()
         self._call(m._engine.lib.efe_mcts_expand, p_(self.n_nodes), p_(nodes), p_(mask), p_(G), p_(ps_next))
 
@@ -304,13 +314,29 @@ class BatchedMCTS:
                 break
             self._call(lib.efe_mcts_select, p_(active), float(p.C), 1 if p.using_prior_for_exploration else 0, self.max_depth,
                        p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))
-            self._expand(self.leaf, active, self.leaf_rep)
-            q0 = None
-            for r in range(p.simulation_repeats):
-                G, _, q0 = m.simulate_batch(self.leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0)
-                self.sims[r].copy_(G)
+            # noise stages in the reference's call order: the expansion takes one stage, then each simulation one
+            st_exp = m._take_stage(None, 1 + p.simulation_repeats)
+            if self.overlap:
+                cur = torch.cuda.current_stream(m.device)
+                self.ev_sel.record(cur)
+                with torch.cuda.stream(self.sim_stream):
+                    self.sim_stream.wait_event(self.ev_sel)              # leaf_s is ready; the previous back-propagation has read sims / q0
+                    for r in range(p.simulation_repeats):
+                        G, _, q0 = self.sim_model.simulate_batch(self.leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0,
+                                                                 stage=st_exp + 1 + r)
+                        self.sims[r].copy_(G)
+                        self.q0.copy_(q0)
+                    self.ev_sim.record(self.sim_stream)
+                self._expand(self.leaf, active, self.leaf_rep, stage=st_exp)
+                cur.wait_event(self.ev_sim)
+            else:
+                self._expand(self.leaf, active, self.leaf_rep, stage=st_exp)
+                for r in range(p.simulation_repeats):
+                    G, _, q0 = m.simulate_batch(self.leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0, stage=st_exp + 1 + r)
+                    self.sims[r].copy_(G)
+                    self.q0.copy_(q0)
             self._call(lib.efe_mcts_backprop, p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(active),
-                       p_(self.sims), int(p.simulation_repeats), p_(q0.contiguous()), self.max_depth, p_(self.H_g[repeat]), p_(self.H_active[repeat]))
+                       p_(self.sims), int(p.simulation_repeats), p_(self.q0), self.max_depth, p_(self.H_g[repeat]), p_(self.H_active[repeat]))
             n_iter += 1
         # read the history back once
         H_act, H_len = self.H_act[:n_iter].cpu(), self.H_len[:n_iter].cpu()

@@ -309,6 +309,16 @@ class ActiveInferenceModel:
             self._weights_dirty = False
         return e
 
+    def replica(self):
+        """a second engine context on the same device with the same geometry, seed and weights: lets two engine calls run
+        concurrently on two HIP streams (one context has one scratch arena and orders its calls)"""
+        r = ActiveInferenceModel(self.s_dim, self.pi_dim, float(self.gamma), float(self.beta_s), float(self.beta_o),
+                                 colour_channels=self.colour_channels, resolution=self.resolution, device=self.device, seed=self.seed,
+                                 row_offset=self.row_offset, init_weights=False)
+        r.load_state_dicts(self.model_top._sd, self.model_mid._sd, self.model_down._sd)
+        r.eps_source, r.u_source = self.eps_source, self.u_source
+        return r
+
     def reserve(self, rows, steps, samples):
         """pre-size the engine's scratch arena for calculate_G_repeated(rows, steps, samples): later calls never hipMalloc"""
         e = self._ready()

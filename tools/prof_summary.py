@@ -83,7 +83,7 @@ def main(d):
                 k = short(r['Kernel_Name'])
                 if r['Counter_Name'] != key or not k.startswith('k_dec'):
                     continue
-                k = k.split('<')[0]
+                k = 'k_dec_b' if k.startswith('k_dec_b') else k.split('<')[0]      # k_dec_b4 / k_dec_b<SR,RW>: one workgroup = one image
                 e = tr.setdefault(k, {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0, 'images_f': 0, 'images_w': 0})
                 e[key] += float(r['Counter_Value'])
                 e['images_f' if key == 'FETCH_SIZE' else 'images_w'] += int(r['Grid_Size']) // int(r['Workgroup_Size'])
