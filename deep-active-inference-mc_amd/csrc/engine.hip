@@ -52,6 +52,7 @@ struct efe_ctx {
     // (pi_dim, channels, resolution) runs the generic layer-by-layer convolution path (generic.hip; SURVEY 8a-13, parity unpinned)
     int pi_dim = 4, chan = 1, res = 64;
     bool generic = false;
+    bool last_s1 = false;           // resolution 32: the reference's own variant (torchmodel.py:77-80, last_strides = 1): decoder base res/2, third ConvT stride 1
     int base = 16, enc_hw[5] = {64, 31, 15, 7, 3};
     size_t img_store = 4096;        // floats per stored D1 image: C*H*W NCHW (dSprites, C = 1) or H*W*8 NHWC8 (generic)
     Layer g_fc4, g_ct[3], g_enc[4];
@@ -251,7 +252,7 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
 // generic geometry (generic.hip): dense head -> Linear(256, 64*B*B) -> ConvT(64,64,s1) -> ConvT(64,64,s2) -> ConvT(64,32,s2) -> final conv
 int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, int reward0, int store0, float* val, float* po_store,
                   hipStream_t st) {
-    const int B = ctx->base, H2 = 2 * B, H3 = 4 * B;
+    const int B = ctx->base, H2 = 2 * B, H3 = ctx->last_s1 ? 2 * B : 4 * B;
     const int C = (int)std::min<int64_t>(std::min<int64_t>(ctx->dec_chunk, 4096), N);
     float* hA = ctx->allocT<float>((size_t)N * 256);
     float* hB = ctx->allocT<float>((size_t)N * 256);
@@ -280,7 +281,7 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
         conv(ctx->g_ct[0], x4, y1, c, B, 64, B, 64, 1);
         conv(ctx->g_ct[1], y1, y2, c, B, 64, H2, 64, 2);
         ctx->cls = PROF_CT3;
-        conv(ctx->g_ct[2], y2, y3, c, H2, 64, H3, 32, 2);
+        conv(ctx->g_ct[2], y2, y3, c, H2, 64, H3, 32, ctx->last_s1 ? 1 : 2);
         FinalGArgs f{};
         f.y3 = y3; f.w = ctx->g_wf; for (int i = 0; i < 4; ++i) f.b[i] = ctx->g_bf[i];
         f.rows = c; f.m0 = m0; f.rows_per_group = nc.rows_per_group; f.H = H3; f.W = H3; f.C = ctx->chan; f.gm = nc.gm;
@@ -550,7 +551,8 @@ int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channel
     ctx->device = device;
     ctx->pi_dim = pi_dim; ctx->chan = channels; ctx->res = resolution;
     ctx->generic = !(channels == 1 && resolution == 64);
-    ctx->base = resolution / 4;
+    ctx->last_s1 = resolution == 32;
+    ctx->base = ctx->last_s1 ? resolution / 2 : resolution / 4;
     ctx->enc_hw[0] = resolution;
     for (int i = 1; i < 5; ++i) ctx->enc_hw[i] = (ctx->enc_hw[i - 1] - 3) / 2 + 1;      // Conv2d(k3, s2, p0), SURVEY appendix A.3
     if (ctx->enc_hw[4] < 1) { delete ctx; return 7; }
@@ -558,6 +560,7 @@ int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channel
         const int64_t B = ctx->base, r = resolution;
         ctx->img_store = (size_t)r * r * 8;
         ctx->mac_dec = 10 * 256 + 2 * 256 * 256 + 256 * 64 * B * B + B * B * 9 * 64 * 64 * 2 + 4 * B * B * 9 * 64 * 32 + r * r * 9 * 32 * channels;
+        // (the stride-1 third layer of the resolution-32 variant works on 2B x 2B inputs: the same 4 B^2 * 9 * 64 * 32 MACs)
         const int* hw = ctx->enc_hw;
         ctx->mac_enc = (int64_t)hw[1] * hw[1] * 9 * channels * 32 + (int64_t)hw[2] * hw[2] * 9 * 32 * 32 + (int64_t)hw[3] * hw[3] * 9 * 32 * 64
                      + (int64_t)hw[4] * hw[4] * 9 * 64 * 64 + (int64_t)hw[4] * hw[4] * 64 * 256 + 2 * 256 * 256 + 256 * 20;
@@ -1145,7 +1148,7 @@ int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples) {
         t += al(D * 2 * S * R * 32 * 4) + al(D * 3 * S * R * 16 * 4) + al(2 * R * 16 * 4) + al(D * 3 * S * R * 4) + al(D * S * R * IS * 4)
            + al(D * S * R * 32 * 4) + al(3 * R * 4);
         {   const size_t N = D * 3 * S * R, C = std::min<size_t>(std::min<size_t>((size_t)dec_chunk, 4096), N);
-            t += 2 * al(N * 256 * 4) + 2 * al(C * B * B * 64 * 4) + al(C * 4 * B * B * 64 * 4) + al(C * 16 * B * B * 32 * 4); }
+            t += 2 * al(N * 256 * 4) + 2 * al(C * B * B * 64 * 4) + al(C * 4 * B * B * 64 * 4) + al(C * (size_t)ctx->res * ctx->res * 32 * 4); }
         enc(D * S * R);
         return (int64_t)(t + ((size_t)1 << 20));
     }

@@ -31,7 +31,7 @@ def layer_shapes(pi_dim=4, channels=1, resolution=64):
     h = resolution
     for _ in range(4):
         h = (h - 3) // 2 + 1
-    base = resolution // 4
+    base = resolution // 2 if resolution == 32 else resolution // 4      # resolution 32: the reference's own variant (last_strides = 1, torchmodel.py:79-80)
     return {
         'top': {'qpi_net.0': (128, 10), 'qpi_net.2': (128, 128), 'qpi_net.4': (pi_dim, 128)},
         'mid': {'ps_net.0': (512, pi_dim + 10), 'ps_net.3': (512, 512), 'ps_net.6': (512, 512), 'ps_net.9': (20, 512)},

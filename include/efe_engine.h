@@ -41,7 +41,8 @@ int efe_create(efe_ctx** out, int device);                       /* ActiveInfere
  * kernels; any other geometry (BASELINE configs[4]: pi 3, 3 x 84 x 84) is BUILD-DEFINED -- the reference rejects it (torchmodel.py:77-82)
  * and its reward (calc_reward_animalai, torchmodel.py:214) is undefined -- and runs the generic convolution path: encoder
  * Conv2d(k3,s2) x 4 + dense head with 64 * h4 * h4 inputs, decoder dense head -> Linear(256, 64 * (res/4)^2) -> ConvT(64,64,s1) ->
- * ConvT(64,64,s2) -> ConvT(64,32,s2) -> ConvT(32,C,s1) + sigmoid, reward = SUM over (c,h,w) of the NCHW-broadcast log-likelihood of
+ * ConvT(64,64,s2) -> ConvT(64,32,s2) -> ConvT(32,C,s1) + sigmoid (resolution 32 = the reference's own variant, torchmodel.py:77-80: decoder base
+ * 16 x 16 and a stride-1 third layer; its NETWORKS are pinned against the reference, tests/golden/nets32_*.npz), reward = SUM over (c,h,w) of the NCHW-broadcast log-likelihood of
  * torchutils.py:34-37.  Observations are NCHW [M, C, res, res].  Parity unpinned: validated against oracle/efe_oracle.py (cfg=) only. */
 int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channels, int resolution);
 int efe_get_config(efe_ctx* ctx, int* s_dim, int* pi_dim, int* channels, int* resolution);      /* outputs may be NULL */

@@ -157,7 +157,9 @@ class OracleModel:
         self.noise = noise
         self.s_dim = s_dim
         self.pi_dim = pi_dim
-        self.channels, self.resolution, self.base = channels, resolution, resolution // 4
+        self.channels, self.resolution = channels, resolution
+        self.last_stride = 1 if resolution == 32 else 2          # torchmodel.py:77-80
+        self.base = resolution // 2 if resolution == 32 else resolution // 4
         self.generic = (channels, resolution) != (1, 64)
         self.pi_one_hot = torch.eye(pi_dim)      # torchmodel.py:164-165
 
@@ -208,7 +210,8 @@ class OracleModel:
         h = h.reshape(M, 64, self.base, self.base)
         h = F.relu(F.conv_transpose2d(h, w['down.po_net.13.weight'], w['down.po_net.13.bias'], stride=1, padding=1))
         h = F.relu(F.conv_transpose2d(h, w['down.po_net.15.weight'], w['down.po_net.15.bias'], stride=2, padding=1, output_padding=1))
-        h = F.relu(F.conv_transpose2d(h, w['down.po_net.17.weight'], w['down.po_net.17.bias'], stride=2, padding=1, output_padding=1))
+        ls = getattr(self, 'last_stride', 2)
+        h = F.relu(F.conv_transpose2d(h, w['down.po_net.17.weight'], w['down.po_net.17.bias'], stride=ls, padding=1, output_padding=ls - 1))
         h = torch.sigmoid(F.conv_transpose2d(h, w['down.po_net.19.weight'], w['down.po_net.19.bias'], stride=1, padding=1))
         return h
 

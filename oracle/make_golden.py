@@ -371,6 +371,44 @@ def main():
              root_N=rootN, **meta)
         report['mcts_batch_s10'] = dict(reps=[int(x) for x in repd], n_paths=[int(x) for x in npaths])
 
+    # ---------------- the reference's resolution-32 variant (pi 3, 3 x 32 x 32, last_strides = 1) -------------------
+    # Its NETWORKS are constructible and runnable (with the same kind of shim as the dSprites model: the first encoder Linear
+    # ships 256 inputs, torchmodel.py:94, where the trunk emits 64); its calculate_G is not (calc_reward_animalai is undefined,
+    # torchmodel.py:213-214).  So: network-level fixtures only; the EFE terms of this geometry stay build-defined.
+    if True:
+        sys.path.insert(0, REF)
+        sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+        from src.torchmodel import ActiveInferenceModel
+        A32, C32, R32, NSEED = 3, 3, 32, 7
+        weights = synth.make_weights(WSEED, 1.15, A32, C32, R32)
+        ref = ActiveInferenceModel(10, A32, 0.0, 1.0, 1.0, colour_channels=C32, resolution=R32)
+        ref.model_down.qs_net[9] = nn.Linear(64, 256)                      # shim (as 576 for resolution 64)
+        for part, mod in (('top', ref.model_top), ('mid', ref.model_mid), ('down', ref.model_down)):
+            mod.load_state_dict({k[len(part) + 1:]: torch.from_numpy(v.copy()) for k, v in weights.items() if k.startswith(part + '.')})
+        inj = Injector(NSEED)
+        import torch.nn.functional as F
+        F.dropout = inj.dropout
+        torch.randn_like = inj.randn_like
+        M, stage = 5, 60
+        s = torch.from_numpy(PX.uniform_fill(3, (M, 10), 90, -1.5, 1.5))
+        pi = torch.eye(A32)[torch.tensor([0, 1, 2, 1, 0])]
+        frames = torch.from_numpy(synth.make_frames_rgb(15, M, C32, R32))
+        inj.p_trans(PX.PASS_T1, 0, stage, 0)
+        t_ps1, t_mean, t_lv = ref.model_mid.transition_with_sample(pi, s)
+        inj.q.extend(('mask', PX.TAG_DEC + l, PX.PASS_D1, 0, stage, 0, f) for l, f in enumerate([256, 256, 256, 16384]))
+        d_po = ref.model_down.decoder(s)
+        inj.p_enc(PX.PASS_E1, 0, stage, 0)
+        e_s, e_mean, e_lv = ref.model_down.encoder_with_sample(frames)
+        h_logits, h_q, h_logq = ref.model_top.encode_s(s)
+        assert not inj.q
+        orc = OracleModel(weights, PhiloxNoise(NSEED), pi_dim=A32, channels=C32, resolution=R32)
+        o_po = orc.decoder(s, PX.PASS_D1, 0, stage)
+        o_es, o_em, o_elv = orc.encoder_with_sample(frames, PX.PASS_E1, 0, stage)
+        report['nets32_g115'] = dict(dec=maxdiff(d_po, o_po), enc=max(maxdiff(e_mean, o_em), maxdiff(e_s, o_es)),
+                                     trans=maxdiff(t_ps1, orc.transition_with_sample(pi, s, PX.PASS_T1, 0, stage)[0]))
+        save('nets32_g115', frames=frames, s=s, pi=pi, stage=stage, t_ps1=t_ps1, t_mean=t_mean, t_lv=t_lv, d_po=d_po, e_s=e_s, e_mean=e_mean,
+             e_lv=e_lv, h_logits=h_logits, h_q=h_q, h_logq=h_logq, wseed=WSEED, gain=1.15, nseed=NSEED, pi_dim=A32, channels=C32, resolution=R32)
+
     with open(os.path.join(GOLD, 'MANIFEST.json'), 'w') as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print(json.dumps(report, indent=1))

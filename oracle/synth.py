@@ -41,7 +41,7 @@ def specs_for(pi_dim=4, channels=1, resolution=64):
     h = resolution
     for _ in range(4):
         h = (h - 3) // 2 + 1
-    base = resolution // 4
+    base = resolution // 2 if resolution == 32 else resolution // 4
     repl = {'top.qpi_net.4': (pi_dim, 128), 'mid.ps_net.0': (512, pi_dim + 10), 'down.qs_net.0': (32, channels, 3, 3),
             'down.qs_net.9': (256, 64 * h * h), 'down.po_net.9': (64 * base * base, 256), 'down.po_net.19': (32, channels, 3, 3)}
     return [(k, repl.get(k, shp)) for k, shp in SPECS]

@@ -148,3 +148,38 @@ def test_configs4_full_shape_properties(pair):
         m.eps_source = src
     assert torch.equal(G1, G2) and torch.isfinite(G1).all()
     np.testing.assert_allclose(c(-t1[0] + t1[1] + t1[2]), c(G1), rtol=1e-5)
+
+
+def test_resolution32_networks_vs_reference_fixture():
+    """the engine's generic path on the reference's OWN Animal-AI-branch geometry (pi 3, 3 x 32 x 32, decoder 16 -> 16 -> 32 -> 32 with a
+    stride-1 third layer, torchmodel.py:77-80) against fixtures captured from the reference's networks: transition, decoder, encoder,
+    habit are PINNED at network level for this branch (its EFE terms are not: the reference's reward function does not exist)"""
+    import daimc_amd
+    from conftest import load_golden
+    g = load_golden('nets32_g115')
+    A32, C32, R32, seed, st = int(g['pi_dim']), int(g['channels']), int(g['resolution']), int(g['nseed']), int(g['stage'])
+    m = daimc_amd.ActiveInferenceModel(10, A32, 0.0, 1.0, 1.0, colour_channels=C32, resolution=R32, device='cuda:0', seed=seed, init_weights=False)
+    m.load_flat_weights(synth.make_weights(int(g['wseed']), float(g['gain']), A32, C32, R32))
+    M = len(g['s'])
+    ps1, mean, lv = m.model_mid.transition_with_sample(g['pi'], g['s'], stage=st, pass_=PX.PASS_T1, eps=PX.normals(seed, M, 10, PX.PASS_T1, 0, st))
+    np.testing.assert_allclose(c(mean), g['t_mean'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(lv), g['t_lv'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(ps1), g['t_ps1'], rtol=1e-5, atol=2e-6)
+    po = m.model_down.decoder(g['s'], stage=st, pass_=PX.PASS_D1)
+    assert po.shape == (M, C32, R32, R32)
+    np.testing.assert_allclose(c(po), g['d_po'], rtol=1e-5, atol=1e-5)
+    s, emean, elv = m.model_down.encoder_with_sample(g['frames'], stage=st, pass_=PX.PASS_E1, eps=PX.normals(seed, M, 10, PX.PASS_E1, 0, st))
+    np.testing.assert_allclose(c(emean), g['e_mean'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(elv), g['e_lv'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(s), g['e_s'], rtol=1e-5, atol=2e-6)
+    logits, q, logq = m.model_top.encode_s(g['s'])
+    np.testing.assert_allclose(c(logits), g['h_logits'], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(c(q), g['h_q'], rtol=1e-5, atol=1e-6)
+    # the shipped 256-input first encoder Linear of this variant is rejected with the same explanation as the dSprites one
+    sd = m.model_down.state_dict(); sd['qs_net.9.weight'] = torch.zeros(256, 256)
+    with pytest.raises(ValueError, match='torchmodel.py:94'):
+        m.model_down.load_state_dict(sd)
+    # a whole EFE call runs on this geometry too (build-defined reward): finite and deterministic
+    G1 = m.calculate_G(g['s'][:3], np.eye(3, dtype=np.float32), samples=2, stage=1)[0]
+    G2 = m.calculate_G(g['s'][:3], np.eye(3, dtype=np.float32), samples=2, stage=1)[0]
+    assert torch.equal(G1, G2) and torch.isfinite(G1).all()

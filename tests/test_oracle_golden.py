@@ -171,3 +171,22 @@ def test_oracle_planner_ten_samples_vs_reference(golden, weights_cache, e):
     np.testing.assert_allclose(np.array(all_G), g['all_paths_G'][e][:n], atol=1e-3)
     assert path == [int(a) for a in g['final_path'][e] if a >= 0]
     assert np.array_equal(root_N.numpy(), g['root_N'][e])
+
+
+def test_resolution32_networks_vs_reference(golden):
+    """the reference's own Animal-AI-branch model (pi 3, 3 x 32 x 32, last_strides = 1, torchmodel.py:77-80): its networks run (its
+    calculate_G does not: calc_reward_animalai is undefined), so the geometry-generic restatement is pinned at network level"""
+    g = golden('nets32_g115')
+    A, C, R = int(g['pi_dim']), int(g['channels']), int(g['resolution'])
+    m = EO.OracleModel(synth.make_weights(int(g['wseed']), float(g['gain']), A, C, R), EO.PhiloxNoise(int(g['nseed'])),
+                       pi_dim=A, channels=C, resolution=R)
+    st = int(g['stage'])
+    with torch.no_grad():
+        ps1, mean, lv = m.transition_with_sample(torch.from_numpy(g['pi']), torch.from_numpy(g['s']), PX.PASS_T1, 0, st)
+        po = m.decoder(torch.from_numpy(g['s']), PX.PASS_D1, 0, st)
+        es, em, elv = m.encoder_with_sample(torch.from_numpy(g['frames']), PX.PASS_E1, 0, st)
+        hl, hq, hlq = m.encode_s(torch.from_numpy(g['s']))
+    assert po.shape == (5, 3, 32, 32) and hq.shape == (5, 3)
+    for a, b in ((ps1, 't_ps1'), (mean, 't_mean'), (lv, 't_lv'), (po, 'd_po'), (es, 'e_s'), (em, 'e_mean'), (elv, 'e_lv'),
+                 (hl, 'h_logits'), (hq, 'h_q'), (hlq, 'h_logq')):
+        np.testing.assert_allclose(a.numpy(), g[b], rtol=1e-6, atol=1e-6)
