@@ -534,6 +534,11 @@ __device__ __forceinline__ float dpp_ror15(float x) { return __builtin_bit_cast(
 // and only the three H planes of a source row go through LDS (two ds_write_b64 per parity row instead of twenty ds_write_b32; the
 // gather reads 3 values per pixel instead of 9).  The plane ring shrinks from 23.7 to 7.7 KiB: 49 KiB of LDS per workgroup.
 // ---------------------------------------------------------------------------------------------------------
+// Measured alternatives of this kernel (profiles/r2_decb4_variants.txt): persistent over images with a ticket queue (prologue 28k ->
+// 0 cycles per image) and / or three workgroups per CU (166 VGPRs without spills after laundering the lane index per strip, tap
+// weights re-read from LDS, channel halves merged with a cross-lane add: 50 KiB LDS) all land on the same 5.96-5.98 ms per 19200
+// images; the per-strip index laundering alone costs 2-3 % at two waves.  The shader clock is at 2.38 GHz in steady state (it
+// ramps from 2.05 GHz over the first four launches after idle): the kernel is not clock- or power-limited.
 #ifndef EFE_B4_WAVES
 #define EFE_B4_WAVES 2
 #endif

@@ -349,9 +349,9 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
     fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, N, true, true, TAG_DEC + 1, nc, 0, st);
     fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, N, true, true, TAG_DEC + 2, nc, 0, st);
     const int nchunks = (N + C - 1) / C;
-    int* queues = ctx->allocT<int>((size_t)nchunks);        // one image-ticket counter per k_dec_a launch
+    int* queues = ctx->allocT<int>((size_t)2 * nchunks);    // one image-ticket counter per k_dec_a launch, then one per k_dec_b4 launch
     if (!queues) return 1;
-    if (hipMemsetAsync(queues, 0, (size_t)nchunks * sizeof(int), st) != hipSuccess) return ctx->fail("hipMemsetAsync failed");
+    if (hipMemsetAsync(queues, 0, (size_t)2 * nchunks * sizeof(int), st) != hipSuccess) return ctx->fail("hipMemsetAsync failed");
     for (int m0 = 0; m0 < N; m0 += C) {
         const int c = std::min(C, N - m0);
         ctx->cls = PROF_DEC_FC4;
@@ -367,7 +367,7 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         DecBArgs db{};
         db.y2 = y2; db.w3 = ctx->dec_ct[2].Wp; db.b3 = ctx->dec_ct[2].bias; db.w4 = ctx->dec_wf; db.b4 = ctx->dec_bf;
         db.rows = c; db.m0 = m0; db.rows_per_group = nc.rows_per_group; db.gm = nc.gm; db.reward0 = reward0; db.store0 = store0;
-        db.val = val; db.po = po_store; db.dbg = (int)ctx->dbg_b;
+        db.val = val; db.po = po_store; db.dbg = (int)ctx->dbg_b; db.queue = queues + nchunks + m0 / C;
         e0 = ctx->prof_begin(st);
         launch_dec_b(db, st);
         ctx->prof_end(e0, st);

@@ -86,6 +86,7 @@ struct DecBArgs {
     int store0;           // groups with pidx == 0 store their image at slot t*S + sample
     float* val;           // [batch] per-image pixel sum (entropy sum, or log-likelihood sum)
     float* po;            // [slots][rows_per_group][4096] stored images
+    int* queue;           // k_dec_b4: zero-initialised ticket counter of this launch (images beyond the first per workgroup are claimed dynamically)
     int dbg;              // experiments only: 2 = skip gather/epilogue math, 8 = 4-row strips / 8 waves, 16 = 4-row strips / 4 waves
     long long* tl;        // EFE_PHASE_CLK builds only: per-workgroup phase cycle sums [rows][8]
 };

@@ -51,6 +51,8 @@ int main(int argc, char** argv) {
         std::vector<long long> h(512 * 16); hipMemcpy(h.data(), tl, 512 * 16 * 8, hipMemcpyDeviceToHost);
         const char* nm[10] = {"end barrier", "stage+barrier", "prefetch+CT1 loop", "CT1 barrier", "CT1 epilogue+barrier", "CT2 loops", "CT2 epilogues", "-", "-", "tail"};
         const int grid = rows < 512 ? rows : 512; const double imgs = (double)rows / grid;
+        { double cyc = 0, wall = 0; for (int b = 0; b < grid; ++b) { cyc += (double)h[b * 16 + 10]; wall += (double)h[b * 16 + 11]; }
+          printf("cycle counter rate inside the kernel: %.3f GHz (mean wall per workgroup %.1f us)\n", cyc / (wall / 100e6) / 1e9, wall / grid / 100.0); }
         for (int half = 0; half < 2; ++half) {
             double tot = 0; printf("WGs %d..%d, cycles per image (wave 0):", half * 256, half * 256 + 255);
             for (int i = 0; i < 10; ++i) {
