@@ -1,9 +1,10 @@
 """GPU parity tests (-m gpu): the HIP engine, called through the C ABI via the Python mirror, against
 (1) the fixtures captured from the shimmed reference and (2) the CPU oracle on fresh seeded inputs.
 
-Tolerances (fp32, stated per SURVEY 8c): network outputs rtol 1e-5 / atol 2e-6 (+ sigmoid outputs atol 1e-5);
-term0/term1 atol 1e-3; term2 and G: atol = 5e-6 * max(|term2_1|, 1) + 1e-3 (term2 is a cancelling
-difference of two 4096-pixel sums)."""
+Tolerances (fp32; observed maxima over the fixtures in profiles/r2_observed_errors.txt, tools/measure_errors.py):
+network outputs rtol 1e-5 / atol 2e-6 (observed 1.9e-6), sigmoid images atol 4e-6 (observed 1.6e-6); term0 / term1 atol 1e-4
+(observed 1.1e-5 / 2.9e-6); term2 and G: atol = 1e-6 * max(|term2_1|, 1) + 5e-4, i.e. 3.3e-3 at |term2_1| = 2.8e3 (observed
+4.9e-4 = 2 ulp of the 4096-pixel sums whose cancelling difference term2 is: the oracle's own fp32 rounding bounds it)."""
 import os
 
 import numpy as np
@@ -54,7 +55,7 @@ def c(t):
 
 
 def gtol(t21):
-    return 5e-6 * max(float(np.max(np.abs(t21))), 1.0) + 1e-3
+    return 1e-6 * max(float(np.max(np.abs(t21))), 1.0) + 5e-4
 
 
 @pytest.mark.parametrize('gain', GAINS)
@@ -73,7 +74,7 @@ def test_networks_vs_golden(golden, models, gain):
 
     po = m.model_down.decoder(g['s'], stage=st, pass_=PX.PASS_D1)
     assert po.shape == (M, 1, 64, 64)
-    np.testing.assert_allclose(c(po), g['d_po'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c(po), g['d_po'], rtol=1e-5, atol=4e-6)
 
     eps_e = PX.normals(seed, M, 10, PX.PASS_E1, 0, st)
     s, emean, elv = m.model_down.encoder_with_sample(g['frames'], stage=st, pass_=PX.PASS_E1, eps=eps_e)
@@ -98,11 +99,11 @@ def test_calculate_G_vs_golden(golden, models, gain, case):
     G, terms, ps1, ps1_mean, po1 = m.calculate_G(g['s0'], g['pi0'], samples=S, stage=st, eps=eps, _parts=parts)
     np.testing.assert_allclose(c(ps1), g['ps1'], rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(c(ps1_mean), g['ps1_mean'], rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(c(po1), g['po1'], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=1e-3)
-    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=1e-3)
-    np.testing.assert_allclose(c(parts[0][0]), g['t2_1'], rtol=1e-5, atol=1e-3)
-    np.testing.assert_allclose(c(parts[0][1]), g['t2_2'], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(c(po1), g['po1'], rtol=1e-5, atol=4e-6)
+    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=1e-4)
+    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=1e-4)
+    np.testing.assert_allclose(c(parts[0][0]), g['t2_1'], rtol=1e-6, atol=1e-3)
+    np.testing.assert_allclose(c(parts[0][1]), g['t2_2'], rtol=1e-6, atol=1e-3)
     np.testing.assert_allclose(c(terms[2]), g['t2'], atol=gtol(g['t2_1']))
     np.testing.assert_allclose(c(G), g['G'], atol=gtol(g['t2_1']))
 
@@ -115,9 +116,9 @@ def test_calculate_G_mean_vs_golden(golden, models, gain):
     eps = eps_calcG(int(g['nseed']), 4, 1, st)
     G, terms, ps1_mean, po1 = m.calculate_G_mean(g['s0'], m.pi_one_hot, stage=st, eps=eps)
     np.testing.assert_allclose(c(ps1_mean), g['ps1_mean'], rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(c(po1), g['po1'], rtol=1e-5, atol=1e-5)
-    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=1e-3)
-    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=1e-3)
+    np.testing.assert_allclose(c(po1), g['po1'], rtol=1e-5, atol=4e-6)
+    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=1e-4)
+    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=1e-4)
     np.testing.assert_allclose(c(G), g['G'], atol=gtol(g['t2_1']))
 
 
@@ -129,8 +130,8 @@ def test_rollout_vs_golden(golden, models, name):
     eps = eps_rollout(int(g['nseed']), M, D, S, st)
     sum_G, terms, po1 = m.calculate_G_repeated(g['o'], g['pi'], steps=D, calc_mean=bool(g['calc_mean']), samples=S, stage=st, eps=eps)
     tol = D * gtol(np.array([2800.0]))
-    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=2e-3)
-    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=2e-3)
+    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=2e-4)
+    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=2e-4)
     np.testing.assert_allclose(c(terms[2]), g['t2'], atol=tol)
     np.testing.assert_allclose(c(sum_G), g['sum_G'], atol=tol)
     np.testing.assert_allclose(c(po1), g['po1'], rtol=1e-5, atol=2e-5)
@@ -151,8 +152,8 @@ def test_rollout4_vs_golden(golden, models, name):
     eps = eps_rollout(int(g['nseed']), 4, D, Seff, st)
     sum_G, terms, po1 = m.calculate_G_4_repeated(g['o'], steps=D, calc_mean=bool(g['calc_mean']), samples=S, stage=st, eps=eps)
     tol = D * gtol(np.array([2800.0]))
-    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=2e-3)
-    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=2e-3)
+    np.testing.assert_allclose(c(terms[0]), g['t0'], atol=2e-4)
+    np.testing.assert_allclose(c(terms[1]), g['t1'], atol=2e-4)
     np.testing.assert_allclose(c(sum_G), g['sum_G'], atol=tol)
     np.testing.assert_allclose(c(po1), g['po1'], rtol=1e-5, atol=2e-5)
 
@@ -348,8 +349,8 @@ def test_calculate_G_ten_samples_vs_oracle(models, weights_cache):
     with torch.no_grad():
         oG, oT, ops1, ops1m, opo1 = orc.calculate_G(torch.from_numpy(s0), torch.from_numpy(pi0), S, st)
     G, terms, ps1, ps1m, po1 = m.calculate_G(s0, pi0, samples=S, stage=st, eps=eps_calcG(seed, M, S, st))
-    np.testing.assert_allclose(c(terms[0]), oT[0].numpy(), atol=1e-3)
-    np.testing.assert_allclose(c(terms[1]), oT[1].numpy(), atol=1e-3)
+    np.testing.assert_allclose(c(terms[0]), oT[0].numpy(), atol=1e-4)
+    np.testing.assert_allclose(c(terms[1]), oT[1].numpy(), atol=1e-4)
     np.testing.assert_allclose(c(G), oG.numpy(), atol=gtol(orc.last_term2_parts[0].numpy()))
     np.testing.assert_allclose(c(po1), opo1.numpy(), rtol=1e-5, atol=1e-5)
 
@@ -366,8 +367,8 @@ def test_calculate_G_many_rows_vs_oracle(models, weights_cache):
     with torch.no_grad():
         oG, oT, ops1, ops1m, opo1 = orc.calculate_G(torch.from_numpy(s0), torch.from_numpy(pi0), S, st)
     G, terms, ps1, ps1m, po1 = m.calculate_G(s0, pi0, samples=S, stage=st, eps=eps_calcG(seed, M, S, st))
-    np.testing.assert_allclose(c(terms[0]), oT[0].numpy(), atol=1e-3)
-    np.testing.assert_allclose(c(terms[1]), oT[1].numpy(), atol=1e-3)
+    np.testing.assert_allclose(c(terms[0]), oT[0].numpy(), atol=1e-4)
+    np.testing.assert_allclose(c(terms[1]), oT[1].numpy(), atol=1e-4)
     np.testing.assert_allclose(c(G), oG.numpy(), atol=gtol(orc.last_term2_parts[0].numpy()))
     np.testing.assert_allclose(c(po1), opo1.numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(c(ps1), ops1.numpy(), rtol=1e-5, atol=2e-6)
@@ -490,8 +491,8 @@ def test_full_depth_rollout_vs_oracle(models, weights_cache):
     with torch.no_grad():
         oG, oT, opo1 = orc.calculate_G_repeated(torch.from_numpy(o), torch.from_numpy(pi), D, False, S, st)
     G, T, po1 = m.calculate_G_repeated(o, pi, steps=D, samples=S, stage=st, eps=eps_rollout(seed, M, D, S, st))
-    np.testing.assert_allclose(c(T[0]), oT[0].numpy(), atol=5e-3)
-    np.testing.assert_allclose(c(T[1]), oT[1].numpy(), atol=5e-3)
+    np.testing.assert_allclose(c(T[0]), oT[0].numpy(), atol=5e-4)
+    np.testing.assert_allclose(c(T[1]), oT[1].numpy(), atol=5e-4)
     np.testing.assert_allclose(c(G), oG.numpy(), atol=D * gtol(np.array([2800.0])))
     np.testing.assert_allclose(c(po1), opo1.numpy(), rtol=1e-5, atol=5e-5)
 
@@ -635,8 +636,8 @@ def test_full_size_cfg2_vs_oracle(models, weights_cache):
     with torch.no_grad():
         oG, oT, opo1 = orc.calculate_G_repeated(torch.from_numpy(o), torch.from_numpy(pi), D, False, S, st)
     G, T, po1 = m.calculate_G_repeated(o, pi, steps=D, samples=S, stage=st, eps=eps_rollout(seed, M, D, S, st))
-    np.testing.assert_allclose(c(T[0]), oT[0].numpy(), atol=5e-3)
-    np.testing.assert_allclose(c(T[1]), oT[1].numpy(), atol=5e-3)
+    np.testing.assert_allclose(c(T[0]), oT[0].numpy(), atol=5e-4)
+    np.testing.assert_allclose(c(T[1]), oT[1].numpy(), atol=5e-4)
     np.testing.assert_allclose(c(G), oG.numpy(), atol=D * gtol(np.array([2800.0])))
     np.testing.assert_allclose(c(po1), opo1.numpy(), rtol=1e-5, atol=5e-5)
     P, _ = m.action_posterior(G)
