@@ -287,8 +287,9 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
         f.rows = c; f.m0 = m0; f.rows_per_group = nc.rows_per_group; f.H = H3; f.W = H3; f.C = ctx->chan; f.gm = nc.gm;
         f.reward0 = reward0; f.store0 = store0; f.val = val; f.po = po_store;
         hipEvent_t e0 = ctx->prof_begin(st);
-        launch_final_g(f, st);
+        const int frc = launch_final_g(f, st);
         ctx->prof_end(e0, st);
+        if (frc) return ctx->fail("final decoder layer: unsupported geometry");
     }
     ctx->cls = PROF_OTHER;
     ctx->last_macs += (int64_t)N * ctx->mac_dec;
@@ -542,11 +543,11 @@ int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channel
     if (!out) return 1;
     *out = nullptr;
     // s_dim is 10 everywhere in the reference (train.py / test_demo.py); x rows are 16 floats = [pi | s | pad]
-    if (s_dim != 10 || pi_dim < 2 || pi_dim > 6 || channels < 1 || channels > 4 || resolution < 32 || resolution > 256 || resolution % 4) return 7;
+    if (s_dim != 10 || pi_dim < 2 || pi_dim > 6 || channels < 1 || channels > 3 || resolution < 32 || resolution > 128 || resolution % 4) return 7;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return 2;
     if (hipSetDevice(device) != hipSuccess) return 3;
-    if (init_small_kernels() || init_decoder_kernels() || init_fused_kernels()) return 5;       // per device: a second context on another GPU needs them too
+    if (init_small_kernels() || init_decoder_kernels() || init_fused_kernels() || init_generic_kernels()) return 5;       // per device: a second context on another GPU needs them too
     efe_ctx* ctx = new efe_ctx();
     ctx->device = device;
     ctx->pi_dim = pi_dim; ctx->chan = channels; ctx->res = resolution;

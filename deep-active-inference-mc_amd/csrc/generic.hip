@@ -135,14 +135,33 @@ void launch_conv_g(const ConvGArgs& a, hipStream_t st) {
 //   entropy : sum_{c,h,w} -(1-p) ln((d+1)-p) - p ln(d+p)                                              (torchutils.py:26-27)
 //   reward  : sum_{c,h,w} [ h < H/2 ? p ln(d+1) + (1-p) ln((d+1)-1) : p ln(d) + (1-p) ln(d+1) ]       (build-defined, SURVEY 8a-13: the
 //             NCHW-broadcast target of torchutils.py:34-37, summed like the reference's resolution-32 branch, torchmodel.py:214)
-// One workgroup per image; a thread owns pixels tid, tid + 256, ... and adds them in that order; the block reduction is a fixed tree.
+//
+// Two-phase form (the structure of k_dec_b4, with run-time geometry): the contraction over the 32 input channels is a GEMM with
+// the 9 taps x C outputs as its rows (27 of an MFMA tile's 32 when C = 3) and the image's pixels as its columns,
+//     T[tap * 3 + c][pixel] = sum_ci W[ci][c][tap] y3[pixel][ci],
+// whose B operand is read straight from global memory (every y3 element is loaded ONCE; the first version gathered each pixel's nine
+// neighbours per thread on the VALU and was bound by the 9x re-read through L1/L2: 30 % of the configs[4] step), and the spatial part
+// is a gather of 27 T values per output pixel.  One workgroup walks down one image, three input rows per iteration: its waves
+// write the T rows into an eight-row LDS ring of 27 planes (row stride W + 2: the zero columns either side are the padding),
+// one barrier, then every thread gathers one output pixel of the rows whose three source rows are complete.  The next iteration's
+// B operand is already in flight during the gather.  Sums are formed in a fixed order (thread-serial over iterations, then a lane
+// tree, then the four waves in order).
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_final_g(const FinalGArgs a) {
-    __shared__ float sw[9 * 32 * 4];
+constexpr int FG_RING = 8;         // T rows in the ring: rows being written (RI) + rows being gathered (RI + 2) <= 8 for RI <= 3
+constexpr int FG_MAXT = 2;         // 32-pixel tiles per wave per iteration (RI * W <= 256)
+constexpr int FG_MAXW = 128;
+
+__global__ void __launch_bounds__(256, 2) k_final_g(const FinalGArgs a) {
+    extern __shared__ float fg_T[];                           // [27][FG_RING][W + 2]
     __shared__ float sred[4];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 9 * 32 * 4; i += 256) sw[i] = a.w[i];
-    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int H = a.H, W = a.W, C = a.C;
+    const int WS = W + 2, PS = FG_RING * WS;
+    const int RI = W <= 85 ? 3 : (W <= 128 ? 2 : 1);
+    for (int i = tid; i < 27 * PS; i += 256) fg_T[i] = 0.0f;
+
     const int img = blockIdx.x;
     const int mg = a.m0 + img;
     const int g = mg / a.rows_per_group;
@@ -151,53 +170,122 @@ __global__ void __launch_bounds__(256) k_final_g(const FinalGArgs a) {
     group_decode(a.gm, g, gt, gp, gs);
     const int mode = (gp == 0 && a.reward0) ? 1 : 0;
     const int slot = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
-    const int H = a.H, W = a.W, C = a.C;
     float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + r) * ((size_t)H * W * 8) : nullptr;
     const float* y = a.y3 + (size_t)img * H * W * 32;
     const float D1 = 1.00001f, D0 = 0.00001f;
+    const float bias[3] = {a.b[0], a.b[1], a.b[2]};
+
+    // A fragments: row m = tap * 3 + c of the 32 x 32 tile, k = channel 8 kc + 4 h + e of MFMA (kc, e)
+    float aw[16];
+    {
+        const int tap = j / 3, c = j - tap * 3;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ci = 8 * (i >> 2) + 4 * h + (i & 3);
+            aw[i] = (j < 27 && c < C) ? a.w[(tap * 32 + ci) * 4 + c] : 0.0f;
+        }
+    }
+    // B operand of iteration it: pixels [it * RI * W, min((it + 1) * RI, H) * W), tile t = wv + 4 n
+    float4 bv[FG_MAXT][4];
+    auto load_b = [&](int it) {
+        const int q0 = it * RI * W;
+        const int nq = (min((it + 1) * RI, H) - it * RI) * W;
+#pragma unroll
+        for (int n = 0; n < FG_MAXT; ++n) {
+            const int q = (wv + 4 * n) * 32 + j;
+            const float* src = y + (size_t)(q0 + min(q, nq - 1)) * 32 + 4 * h;      // clamped: columns of T are independent, the extra ones are not written
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) bv[n][kc] = *reinterpret_cast<const float4*>(src + 8 * kc);
+        }
+    };
+    const int niter = (H + RI - 1) / RI;
+    load_b(0);
+    __syncthreads();
     float part = 0.f;
-    for (int p = tid; p < H * W; p += 256) {
-        const int oh = p / W, ow = p - oh * W;
-        float acc[4] = {a.b[0], a.b[1], a.b[2], a.b[3]};
-        for (int kh = 0; kh < 3; ++kh) {
-            const int sy = oh + 1 - kh;
-            if (sy < 0 || sy >= H) continue;
-            for (int kw = 0; kw < 3; ++kw) {
-                const int sx = ow + 1 - kw;
-                if (sx < 0 || sx >= W) continue;
-                const float4* src = reinterpret_cast<const float4*>(y + ((size_t)sy * W + sx) * 32);
-                const float* wt = sw + (kh * 3 + kw) * 128;
+    for (int it = 0; it < niter; ++it) {
+        const int i0 = it * RI;
+        const int nq = (min(i0 + RI, H) - i0) * W;
 #pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) {
-                    const float4 v = src[c8];
-                    const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int n = 0; n < FG_MAXT; ++n) {
+            const int t = wv + 4 * n;
+            if (t * 32 < nq) {                                 // wave-uniform
+                f32x16 acc;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float4 ww = *reinterpret_cast<const float4*>(wt + (c8 * 4 + e) * 4);
-                        acc[0] = fmaf(vv[e], ww.x, acc[0]); acc[1] = fmaf(vv[e], ww.y, acc[1]);
-                        acc[2] = fmaf(vv[e], ww.z, acc[2]); acc[3] = fmaf(vv[e], ww.w, acc[3]);
+                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[kc * 4 + 0], bv[n][kc].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[kc * 4 + 1], bv[n][kc].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[kc * 4 + 2], bv[n][kc].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[kc * 4 + 3], bv[n][kc].w, acc, 0, 0, 0);
+                }
+                const int q = t * 32 + j;
+                if (q < nq) {
+                    const int row = q / W, x = q - row * W;
+                    float* tp = fg_T + ((i0 + row) & (FG_RING - 1)) * WS + 1 + x;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = (e & 3) + 8 * (e >> 2) + 4 * h;      // C/D layout: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+                        if (m < 27) tp[m * PS] = acc[e];
                     }
                 }
             }
         }
-        float pr[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < C; ++c) {
-            pr[c] = 1.0f / (1.0f + expf(-acc[c]));
-            if (mode == 0) part += -(1.0f - pr[c]) * logf(D1 - pr[c]) - pr[c] * logf(D0 + pr[c]);
-            else part += (oh < H / 2) ? pr[c] * logf(D1) + (1.0f - pr[c]) * logf(D1 - 1.0f) : pr[c] * logf(D0) + (1.0f - pr[c]) * logf(D1);
-        }
-        if (po) {
-            reinterpret_cast<float4*>(po + (size_t)p * 8)[0] = make_float4(pr[0], pr[1], pr[2], pr[3]);
-            reinterpret_cast<float4*>(po + (size_t)p * 8)[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it + 1 < niter) load_b(it + 1);
+        __syncthreads();
+        // output rows whose source rows oh - 1 .. oh + 1 are now in the ring
+        const int o0 = max(i0 - 1, 0);
+        const int o1 = (it + 1 == niter) ? H : i0 + RI - 1;
+        const int nout = (o1 - o0) * W;
+        for (int q = tid; q < nout; q += 256) {
+            const int orow = q / W, x = q - orow * W;
+            const int oh = o0 + orow;
+            float acc[3] = {bias[0], bias[1], bias[2]};
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int sr = oh + 1 - kh;
+                const bool ok = sr >= 0 && sr < H;
+                const float* tp = fg_T + (sr & (FG_RING - 1)) * WS + 1 + x;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = tp[((kh * 3 + kw) * 3 + c) * PS + 1 - kw];
+                        acc[c] += ok ? v : 0.0f;
+                    }
+            }
+            const bool top = oh < H / 2;
+            float p[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                p[c] = 1.0f / (1.0f + expf(-acc[c]));
+                const float p_ = p[c];
+                const float term = mode == 0 ? -(1.0f - p_) * logf(D1 - p_) - p_ * logf(D0 + p_)
+                                             : (top ? p_ * logf(D1) + (1.0f - p_) * logf(D1 - 1.0f) : p_ * logf(D0) + (1.0f - p_) * logf(D1));
+                if (c < C) part += term;
+            }
+            if (po) {
+                float* pp = po + ((size_t)oh * W + x) * 8;
+                reinterpret_cast<float4*>(pp)[0] = make_float4(p[0], C > 1 ? p[1] : 0.f, C > 2 ? p[2] : 0.f, 0.f);
+                reinterpret_cast<float4*>(pp)[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
 #pragma unroll
     for (int k = 32; k > 0; k >>= 1) part += __shfl_xor(part, k);
-    if ((tid & 63) == 0) sred[tid >> 6] = part;
+    if (lane == 0) sred[wv] = part;
     __syncthreads();
     if (tid == 0) a.val[mg] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
-void launch_final_g(const FinalGArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_final_g, dim3(a.rows), dim3(256), 0, st, a); }
+static size_t final_g_lds(int W) { return (size_t)27 * FG_RING * (W + 2) * sizeof(float); }
+int init_generic_kernels() {
+    return hipFuncSetAttribute((const void*)k_final_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)final_g_lds(FG_MAXW)) != hipSuccess;
+}
+int launch_final_g(const FinalGArgs& a, hipStream_t st) {
+    if (a.W > FG_MAXW || a.C > 3) return 1;
+    hipLaunchKernelGGL(k_final_g, dim3(a.rows), dim3(256), final_g_lds(a.W), st, a);
+    return 0;
+}
 
 // NCHW [M][C][H][W] -> NHWC8 [M][H*W][8] (channels >= C zero) and back (first C channels)
 __global__ void k_to_nhwc8(const float* in, float* out, long n_pix_total, int HW, int C) {

@@ -199,7 +199,8 @@ struct FinalGArgs {
     float* val;                       // [batch] per-image sums
     float* po;                        // [slots][rows_per_group][H*W][8] stored images (NHWC, channels padded to 8)
 };
-void launch_final_g(const FinalGArgs& a, hipStream_t st);
+int launch_final_g(const FinalGArgs& a, hipStream_t st);       // non-zero: geometry outside the kernel's limits (W <= 128, C <= 3)
+int init_generic_kernels();
 void launch_to_nhwc8(const float* in, float* out, long M, int HW, int C, hipStream_t st);
 void launch_to_nchw(const float* in, float* out, long M, int HW, int C, hipStream_t st);
 void launch_check_reward_g(const float* o, float* out, int M, int C, int H, int W, hipStream_t st);

@@ -63,7 +63,7 @@ class _Engine:
         rc = self.lib.efe_create_cfg(C.byref(self.ctx), device_index, *[int(v) for v in cfg])
         if rc == 7:
             raise ValueError(f'unsupported model geometry (s_dim, pi_dim, colour_channels, resolution) = {tuple(cfg)}: the engine takes '
-                             's_dim 10, pi_dim 2..6, 1..4 channels, resolution a multiple of 4 in [32, 256]')
+                             's_dim 10, pi_dim 2..6, 1..3 channels, resolution a multiple of 4 in [32, 128]')
         if rc != 0:
             raise RuntimeError(f'efe_create failed with code {rc}')
         self.h = int(self.ctx.value)              # context handle as the torch.ops.efe ops take it

@@ -37,7 +37,7 @@ typedef struct efe_ctx efe_ctx;
 /* lifecycle ------------------------------------------------------------------------------------ */
 int efe_create(efe_ctx** out, int device);                       /* ActiveInferenceModel.__init__, torchmodel.py:150-165 (10, 4, 1, 64) */
 /* ActiveInferenceModel(s_dim, pi_dim, ..., colour_channels, resolution), torchmodel.py:150: s_dim must be 10 (the reference never uses
- * another), pi_dim 2..6, channels 1..4, resolution a multiple of 4 in [32, 256].  (1, 64) is the Dynamic-dSprites geometry on the fused
+ * another), pi_dim 2..6, channels 1..3, resolution a multiple of 4 in [32, 128].  (1, 64) is the Dynamic-dSprites geometry on the fused
  * kernels; any other geometry (BASELINE configs[4]: pi 3, 3 x 84 x 84) is BUILD-DEFINED -- the reference rejects it (torchmodel.py:77-82)
  * and its reward (calc_reward_animalai, torchmodel.py:214) is undefined -- and runs the generic convolution path: encoder
  * Conv2d(k3,s2) x 4 + dense head with 64 * h4 * h4 inputs, decoder dense head -> Linear(256, 64 * (res/4)^2) -> ConvT(64,64,s1) ->
