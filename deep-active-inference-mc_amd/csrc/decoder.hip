@@ -842,11 +842,12 @@ void launch_dec_b(const DecBArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_fc4: Linear(256, 16384) + ReLU + Dropout(0.5) (torchmodel.py:116-118), output written NHWC (rows permuted at
-// pack time).  A workgroup stages 64 batch rows x K=256 in swizzled LDS once and sweeps FC4_STEPS x 256 features;
-// every wave owns 64 features x 64 rows per step.  Dropout mask = one Philox call per row per 128 features.
+// k_fc4: Linear(256, 64 * base^2) + ReLU + Dropout(0.5) (torchmodel.py:116-118; 16384 features for Dynamic dSprites, 28224 for the
+// 84 x 84 geometry), output written NHWC (rows permuted at pack time).  A workgroup stages 64 batch rows x K=256 in swizzled LDS once
+// and sweeps steps of 256 features; every wave owns 64 features x 64 rows per step.  Dropout mask = one Philox call per row per 128
+// features.  The feature steps (ceil(mtiles / 8)) are dealt to 8 groups of SPG = ceil(steps / 8) consecutive steps (8 x 8 for 16384).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int FC4_STEPS = 8;
+__host__ __device__ inline int fc4_spg(int mtiles) { return ((mtiles + 7) / 8 + 7) / 8; }
 __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 sm[];        // [64 rows][64 quads], quad ^= row & 15
     const int tid = threadIdx.x;
@@ -859,7 +860,8 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
     // 230-us workgroups of a 19200-row launch ran as 4.7 waves over the 512 slots and the last, 70 %-full wave cost ~8 %.
     const int fgrp = blockIdx.x & 7;
     const int nper = gridDim.x >> 3, k = blockIdx.x >> 3;
-    const int nsteps = ((a.n_pix + 63) / 64) * FC4_STEPS;              // (row tile, step) pairs of this feature group
+    const int SPG = fc4_spg(a.mtiles);
+    const int nsteps = ((a.n_pix + 63) / 64) * SPG;                    // (row tile, step) pairs of this feature group
     const int q0 = (int)(((long)nsteps * k) / nper), q1 = (int)(((long)nsteps * (k + 1)) / nper);
     f32x4* smv = reinterpret_cast<f32x4*>(sm);
     const float4* Wl = reinterpret_cast<const float4*>(a.Wp);
@@ -873,7 +875,7 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
     bool rv[2] = {false, false};
 #pragma unroll 1
     for (int q = q0; q < q1; ++q) {
-        const int rt = q / FC4_STEPS, fs = q - rt * FC4_STEPS;
+        const int rt = q / SPG, fs = q - rt * SPG;
         const int row0 = rt * 64;
         if (rt != cur_rt) {                                            // (re)stage the 64-row tile: at most twice more than once per workgroup
             if (cur_rt >= 0) __syncthreads();                          // every wave is done reading the previous tile
@@ -899,7 +901,8 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
                 kstream[nt] = key.x; kstage[nt] = key.y;
             }
         }
-        const int mt0 = (fgrp * FC4_STEPS + fs) * 8 + 2 * w;           // this wave's first 32-feature tile
+        const int mt0 = (fgrp * SPG + fs) * 8 + 2 * w;                 // this wave's first 32-feature tile
+        if (mt0 >= a.mtiles) continue;                                 // wave-uniform: past the last feature tile (mtiles is even)
         f32x16 acc[2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -938,9 +941,8 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
 }
 
 void launch_fc4(const GemmArgs& a, hipStream_t st) {
-    static_assert(FC4_STEPS == 8, "512 feature tiles = 8 groups x 8 steps x 8 tiles");
     // persistent: 2 workgroups per CU (64 KiB LDS each), 8 feature groups x (up to) 64 workgroups, each with >= 1 (row tile, step) pair
-    const int nsteps = ((a.n_pix + 63) / 64) * FC4_STEPS;
+    const int nsteps = ((a.n_pix + 63) / 64) * fc4_spg(a.mtiles);
     const int nper = nsteps < 64 ? nsteps : 64;
     hipLaunchKernelGGL(k_fc4, dim3(8 * nper), dim3(256), 64 * 64 * sizeof(float4), st, a);
 }

@@ -209,8 +209,8 @@ void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float*
     a.relu = relu; a.dropout = drop; a.tag = tag; a.k0 = nc.k0; a.k1 = nc.k1; a.gm = nc.gm;
     a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = m0;
     hipEvent_t e0 = ctx->prof_begin(st);
-    if (L.mtiles == 512 && L.cin == 256 && ldx == 256 && x_mod == 0 && relu && drop) {
-        launch_fc4(a, st);          // Linear(256,16384): batch tile staged in LDS
+    if (L.mtiles >= 64 && !(L.mtiles & 1) && L.cin == 256 && ldx == 256 && x_mod == 0 && relu && drop) {
+        launch_fc4(a, st);          // Linear(256, 64 * base^2): batch tile staged in LDS
     } else {
         // tile shape by problem size: small launches (transition / habit / heads) use 32x32 wave tiles so that the
         // grid still covers the 256 CUs
@@ -268,7 +268,7 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
     auto conv = [&](const Layer& L, const float* in, float* out, int n, int hin, int cin, int hout, int cout, int mode) {
         ConvGArgs a{};
         a.in = in; a.out = out; a.Wp = L.Wp; a.bias = L.bias; a.zeros = ctx->zeros; a.n_img = n; a.Hin = hin; a.Win = hin; a.Cin = cin;
-        a.Hout = hout; a.Wout = hout; a.Cout = cout; a.mtiles = L.mtiles; a.mode = mode; a.relu = 1; a.ldo = cout;
+        a.Hout = hout; a.Wout = hout; a.Cout = cout; a.mtiles = L.mtiles; a.mode = mode; a.relu = 1; a.ldo = cout; a.dbg = (int)ctx->dbg_b;
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_conv_g(a, st);
         ctx->prof_end(e0, st);

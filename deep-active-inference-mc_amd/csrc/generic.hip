@@ -117,7 +117,168 @@ __global__ void __launch_bounds__(256) k_conv_g(const ConvGArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Decoder ConvTranspose layers, LDS-tiled (modes 1 and 2 of k_conv_g; that kernel read every B operand straight from L2, i.e. each
+// input element up to nine times, and ran at 0.23 - 0.37 of the MFMA peak on BASELINE configs[4]).  One workgroup = one full-width
+// strip of TH input rows of one image (32 * NTW pixels, NTW = 4 / mtiles; TH = 32 NTW / Win): the strip and its halo are copied to
+// LDS once ([row][col][Cin + 4]: the + 4 spreads the 16-byte operand reads over the banks; cells outside the image are zero = the
+// padding), then wave (nt, mt) computes output channels [32 mt, 32 mt + 32) of pixels [32 nt, 32 nt + 32) of the strip, with the PIXELS as
+// the MFMA rows and the channels as its columns -- a lane then holds one channel of 16 pixels, and every store instruction
+// writes whole 128-byte NHWC lines (the channels-as-rows orientation scattered 16-byte pieces over 32 lines per instruction):
+//   MODE 1  ConvT(k3, s1, p1): nine shifted views of the strip, one accumulator tile
+//   MODE 2  ConvT(k3, s2, p1, op1) in sub-pixel form: four views x[ih + dy][iw + dx] feed the four output parities' accumulator
+//           tiles through 4 / 2 / 2 / 1 taps -- 9 MFMAs per 4 operand reads, no zero-insertion work
+// A fragments come from the packed weights with buffer loads (L1-resident; next channel block prefetched).
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) k_convt_l(const ConvGArgs a) {
+    __shared__ int cl_off[128];                      // per strip pixel: float offset of its (first-parity) output pixel inside the image, -1 = none
+    extern __shared__ float4 cl_x[];                 // [row][col][Cin / 4 + 1] float4: indexed in 16-byte units so that the operand reads are single ds_read_b128
+    constexpr int PADT = MODE == 1 ? 1 : 0;
+    constexpr int NV = MODE == 1 ? 9 : 4;          // shifted operand views
+    constexpr int NA = MODE == 1 ? 1 : 4;          // accumulator tiles
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int Cin = a.Cin, KC = Cin >> 3, C4 = Cin >> 2, PS4 = C4 + 1;
+    const int ntw = 4 / a.mtiles;
+    const int TH = (32 * ntw) / a.Win;
+    const int spi = (a.Hin + TH - 1) / TH;
+    const int img = blockIdx.x / spi, r0 = (blockIdx.x - img * spi) * TH;
+    const int nrow = min(TH, a.Hin - r0);
+    const int nq = nrow * a.Win;
+    const int WSL = a.Win + PADT + 1, NR = nrow + PADT + 1;
+
+    // ---- strip + halo -> LDS
+    {
+        const float* src = a.in + (size_t)img * a.Hin * a.Win * Cin;
+        // thread -> (pixel, 16-byte channel group): C4 divides 256, so a thread keeps its channel group and walks the pixels
+        const int c4 = tid % C4, pstep = 256 / C4, npix = NR * WSL;
+        int pix = tid / C4;
+        int lr = pix / WSL, lx = pix - lr * WSL;
+#pragma unroll 8
+        for (; pix < npix; pix += pstep) {
+            const int gr = r0 - PADT + lr, gx = lx - PADT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr >= 0 && gr < a.Hin && gx >= 0 && gx < a.Win && !(a.dbg & 4)) v = *reinterpret_cast<const float4*>(src + ((size_t)gr * a.Win + gx) * Cin + 4 * c4);
+            cl_x[pix * PS4 + c4] = v;
+            lx += pstep;
+            while (lx >= WSL) { lx -= WSL; ++lr; }
+        }
+    }
+    if (tid < 128) {
+        const int rw = tid / a.Win, xw = tid - rw * a.Win;
+        cl_off[tid] = tid < nq ? ((MODE == 2 ? 2 * (r0 + rw) : r0 + rw) * a.Wout + (MODE == 2 ? 2 * xw : xw)) * a.ldo : -1;
+    }
+    __syncthreads();
+
+    const int nt = wave % ntw, mt = wave / ntw;
+    const int q = nt * 32 + j;
+    const bool valid = q < nq;
+    const int qq = valid ? q : 0;
+    const int row = qq / a.Win, x = qq - row * a.Win;
+    if (nt * 32 >= nq) return;                         // wave-uniform: a short last strip
+
+    // view v: MODE 1 -> tap (kh, kw) = (v / 3, v % 3), source (row + 1 - kh, x + 1 - kw) = local (row + 2 - kh, x + 2 - kw)
+    //         MODE 2 -> (dy, dx) = (v >> 1, v & 1), local (row + dy, x + dx)
+    int vb[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int lr = MODE == 1 ? row + 2 - v / 3 : row + (v >> 1);
+        const int lx = MODE == 1 ? x + 2 - v % 3 : x + (v & 1);
+        vb[v] = (lr * WSL + lx) * PS4 + h;
+    }
+    // MFMA list: (view, tap, accumulator)
+    constexpr int NM = 9;
+    constexpr int mv[2][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 0, 0, 0, 1, 1, 2, 2, 3}};
+    constexpr int mtap[2][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {4, 5, 7, 8, 3, 6, 1, 2, 0}};
+    constexpr int macc[2][9] = {{0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 1, 3, 2, 3, 3}};
+    constexpr int MI = MODE - 1;
+
+    f32x16 acc[NA];
+#pragma unroll
+    for (int p = 0; p < NA; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[p][e] = 0.0f;
+
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wp), 0, 0x7fffffff, 0x00020000);
+    const unsigned wl = (unsigned)lane * 16u;
+    auto load_a = [&](float4 (&av)[NM], int kc) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((mtap[MI][m] * a.mtiles + mt) * KC + ((a.dbg & 1) ? 0 : kc)) * 64) * 16u, 0);
+            av[m] = __builtin_bit_cast(float4, v);
+        }
+    };
+    auto step = [&](const float4 (&av)[NM], int kc) {
+        float4 bv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) bv[v] = cl_x[vb[v] + 2 * kc];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const float4 b = bv[mv[MI][m]];
+            f32x16& c = acc[macc[MI][m]];
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, av[m].x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, av[m].y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, av[m].z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, av[m].w, c, 0, 0, 0);
+        }
+    };
+    float4 a0[NM], a1[NM];
+    load_a(a0, 0);
+    for (int kc = 0; kc < KC; kc += 2) {               // KC is even
+        load_a(a1, kc + 1);
+        __builtin_amdgcn_sched_barrier(0);             // keeps each prefetch a full channel block ahead of its use
+        step(a0, kc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + 2 < KC) load_a(a0, kc + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        step(a1, kc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // epilogue: C/D layout column = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (pixel of the tile)
+    if ((a.dbg & 2) && acc[0][0] != 12345.678f) return;
+    const int co = mt * 32 + j;
+    if (co >= a.Cout) return;
+    const float bias = a.bias[co];
+    float* yimg = a.out + (size_t)img * a.Hout * a.Wout * a.ldo + co;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const int4 off = *reinterpret_cast<const int4*>(cl_off + nt * 32 + 8 * g4 + 4 * h);
+        const int offs[4] = {off.x, off.y, off.z, off.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (offs[i] < 0) continue;
+#pragma unroll
+            for (int p = 0; p < NA; ++p) {
+                float v = acc[p][4 * g4 + i] + bias;
+                if (a.relu) v = fmaxf(v, 0.0f);
+                yimg[offs[i] + ((p >> 1) * a.Wout + (p & 1)) * a.ldo] = v;
+            }
+        }
+    }
+}
+static size_t convt_l_lds(const ConvGArgs& a) {
+    const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win, padt = a.mode == 1 ? 1 : 0;
+    return (size_t)(TH + padt + 1) * (a.Win + padt + 1) * (a.Cin + 4) * sizeof(float);
+}
+constexpr size_t CONVT_L_MAX_LDS = 64 * 1024;
+// the LDS-tiled kernels take the decoder's transposed layers when a full-width strip fits: Cin a power of two >= 16, one or two
+// 32-channel output tiles, Win <= 32 * (4 / mtiles)
+static bool convt_l_ok(const ConvGArgs& a) {
+    if (a.mode != 1 && a.mode != 2) return false;
+    if ((a.Cin & 15) || (a.Cin & (a.Cin - 1)) || a.Cin > 256 || a.mtiles < 1 || a.mtiles > 2 || a.Win > 32 * (4 / a.mtiles)) return false;
+    return convt_l_lds(a) <= CONVT_L_MAX_LDS;
+}
+
 void launch_conv_g(const ConvGArgs& a, hipStream_t st) {
+    if (convt_l_ok(a)) {
+        const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win, spi = (a.Hin + TH - 1) / TH;
+        if (a.mode == 1) hipLaunchKernelGGL(k_convt_l<1>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
+        else hipLaunchKernelGGL(k_convt_l<2>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
+        return;
+    }
     const long npix = (long)a.n_img * (a.mode == 2 ? a.Hin * a.Win : a.Hout * a.Wout);
     const unsigned gz = a.mode == 2 ? 4u : 1u;
     if (a.mtiles >= 2) {
@@ -150,6 +311,7 @@ void launch_conv_g(const ConvGArgs& a, hipStream_t st) {
 constexpr int FG_RING = 8;         // T rows in the ring: rows being written (RI) + rows being gathered (RI + 2) <= 8 for RI <= 3
 constexpr int FG_MAXT = 2;         // 32-pixel tiles per wave per iteration (RI * W <= 256)
 constexpr int FG_MAXW = 128;
+__host__ __device__ constexpr int fg_plane(int W) { return ((FG_RING * (W + 2) + 7) / 16) * 16 + 8; }      // plane stride: 8 mod 16 floats, so rows m and m + 4 (the two lane halves of a T write) are 32 banks apart
 
 __global__ void __launch_bounds__(256, 2) k_final_g(const FinalGArgs a) {
     extern __shared__ float fg_T[];                           // [27][FG_RING][W + 2]
@@ -158,7 +320,7 @@ __global__ void __launch_bounds__(256, 2) k_final_g(const FinalGArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int H = a.H, W = a.W, C = a.C;
-    const int WS = W + 2, PS = FG_RING * WS;
+    const int WS = W + 2, PS = fg_plane(W);
     const int RI = W <= 85 ? 3 : (W <= 128 ? 2 : 1);
     for (int i = tid; i < 27 * PS; i += 256) fg_T[i] = 0.0f;
 
@@ -277,9 +439,12 @@ __global__ void __launch_bounds__(256, 2) k_final_g(const FinalGArgs a) {
     __syncthreads();
     if (tid == 0) a.val[mg] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
-static size_t final_g_lds(int W) { return (size_t)27 * FG_RING * (W + 2) * sizeof(float); }
+static size_t final_g_lds(int W) { return (size_t)27 * fg_plane(W) * sizeof(float); }
 int init_generic_kernels() {
-    return hipFuncSetAttribute((const void*)k_final_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)final_g_lds(FG_MAXW)) != hipSuccess;
+    if (hipFuncSetAttribute((const void*)k_final_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)final_g_lds(FG_MAXW)) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_l<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_l<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
+    return 0;
 }
 int launch_final_g(const FinalGArgs& a, hipStream_t st) {
     if (a.W > FG_MAXW || a.C > 3) return 1;

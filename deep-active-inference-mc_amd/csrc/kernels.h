@@ -188,6 +188,7 @@ struct ConvGArgs {
     int mode;                         // 0 Conv2d(k3,s2,p0)   1 ConvTranspose2d(k3,s1,p1)   2 ConvTranspose2d(k3,s2,p1,op1), sub-pixel form
     int relu;
     int ldo;                          // floats per output pixel
+    int dbg;                          // development switches (engine option dbg_b): 1 one weight slab, 2 no stores, 4 no strip loads -- wrong results, timing only
 };
 void launch_conv_g(const ConvGArgs& a, hipStream_t st);
 struct FinalGArgs {
