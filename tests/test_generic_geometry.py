@@ -183,3 +183,35 @@ def test_resolution32_networks_vs_reference_fixture():
     G1 = m.calculate_G(g['s'][:3], np.eye(3, dtype=np.float32), samples=2, stage=1)[0]
     G2 = m.calculate_G(g['s'][:3], np.eye(3, dtype=np.float32), samples=2, stage=1)[0]
     assert torch.equal(G1, G2) and torch.isfinite(G1).all()
+
+
+@pytest.mark.parametrize('A2,C2,R2', [(4, 1, 48), (3, 3, 64), (5, 2, 128), (2, 3, 36)])
+def test_other_geometries_networks(A2, C2, R2):
+    """every strip shape of the LDS-tiled ConvT kernels (two or three rows per strip, short last strips, Win not a divisor of
+    the tile) and the final layer's 3 / 2 rows per iteration, against the oracle restatement of the same geometry"""
+    import daimc_amd
+    w = synth.make_weights(77 + R2, 1.15, A2, C2, R2)
+    m = daimc_amd.ActiveInferenceModel(10, A2, 0.0, 1.0, 1.0, colour_channels=C2, resolution=R2, device='cuda:0', seed=5, init_weights=False)
+    m.load_flat_weights(w)
+    m.eps_source, m.u_source = PX.normals, PX.uniforms
+    orc = EO.OracleModel(w, EO.PhiloxNoise(5), pi_dim=A2, channels=C2, resolution=R2)
+    st, M = 2, 3
+    s = PX.uniform_fill(4, (M, 10), 60, -1.5, 1.5)
+    fr = synth.make_frames_rgb(12, M, C2, R2)
+    with torch.no_grad():
+        opo = orc.decoder(torch.from_numpy(s), PX.PASS_D1, 0, st)
+        oes, oem, oelv = orc.encoder_with_sample(torch.from_numpy(fr), PX.PASS_E1, 0, st)
+    po = m.model_down.decoder(s, stage=st, pass_=PX.PASS_D1)
+    assert po.shape == (M, C2, R2, R2)
+    np.testing.assert_allclose(c(po), opo.numpy(), rtol=1e-5, atol=1e-5)
+    es, em, elv = m.model_down.encoder_with_sample(fr, stage=st, pass_=PX.PASS_E1)
+    np.testing.assert_allclose(c(em), oem.numpy(), rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(c(elv), oelv.numpy(), rtol=1e-5, atol=5e-6)
+    # the per-image entropy sum of the fused final layer against the oracle's calculate_G term (one sample, mean mode off)
+    pi = np.eye(A2, dtype=np.float32)[np.arange(M) % A2]
+    with torch.no_grad():
+        oG, oterms = orc.calculate_G(torch.from_numpy(s), torch.from_numpy(pi), 2, st)[:2]
+    G, terms = m.calculate_G(s, pi, samples=2, stage=st)[:2]
+    np.testing.assert_allclose(c(terms[0]), oterms[0].numpy(), atol=sumtol(oterms[0].numpy()))
+    np.testing.assert_allclose(c(terms[1]), oterms[1].numpy(), atol=1e-3)
+    np.testing.assert_allclose(c(G), oG.numpy(), atol=3 * sumtol(oterms[0].numpy()))
