@@ -95,7 +95,9 @@ __global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) 
         const int j = tl_ & 31, h = (tl_ >> 5) & 1;
         const int pcol = j & 15;
         const int prow0 = 2 * NTW * w + (j >> 4);                      // tile nt covers rows prow0 + 2*nt
-        {   // swz(it*(NTHR/16) + (tid>>4), tid&15) = it*NTHR + sbase: one address register, immediate offsets
+        // a dead row of the call (efe_set_row_mask) keeps the schedule -- barriers, ticket, the next image's prefetch -- and skips the work
+        const bool live = row_live(a.live, img);
+        if (live) {   // swz(it*(NTHR/16) + (tid>>4), tid&15) = it*NTHR + sbase: one address register, immediate offsets
             const int sbase = (tl_ >> 4) * 16 + ((tl_ & 15) ^ ((tl_ >> 4) & 15));
 #pragma unroll
             for (int it = 0; it < NPH; ++it) smv[sbase + it * NTHR] = pfa[it];
@@ -141,6 +143,7 @@ __global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) 
                 }
         };
         // ---------------- layer 1: out[oh,ow] = sum_{kh,kw} in[oh+1-kh, ow+1-kw] . W[:, :, kh, kw] --------------
+        if (live) {
         acc_init(0);
         tap_loop_pd<2, NTW, 1>(acc, 9, W1, sm, h, [&](int t, int (&bs)[NTW], int (&sw)[NTW], int& wt) {
             const int kh = t / 3, kw = t - kh * 3;
@@ -153,12 +156,14 @@ __global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) 
                 bs[nt] = sp * 16; sw[nt] = sp & 15;
             }
         }, ConvWIdx{});
+        }
         TL(2);
         EFE_X_BAR();                // every wave is done reading the input image (and slot[0])
         if (tid == 0) slot[0] = ticket;
         TL(3);
 #ifndef EFE_X_NOEPI1          // timing experiment (wrong results): no layer-1 epilogue
         // bias + ReLU, written back IN PLACE as the input image of layer 2 (same swizzled layout)
+        if (live)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const int pix = 32 * NTW * w + 32 * nt + j;
@@ -183,7 +188,7 @@ __global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) 
         float keep = 0.f;
 #endif
 #pragma unroll 1
-        for (int par = 0; par < 4; ++par) {
+        for (int par = 0; par < (live ? 4 : 0); ++par) {
             const int ph = par >> 1, pw = par & 1;
             acc_init(16);
             tap_loop_pd<2, NTW, 1>(acc, (1 + ph) * (1 + pw), W2, sm, h, ConvT2Addr<NTW>{ph, pw, prow0, 2, pcol, 16, 16, 256}, ConvWIdx{});
@@ -299,6 +304,7 @@ __global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs 
     const int pg = (NW == 8 ? (w ^ (w >> 2)) : w) & 1;
 #endif
     const int img = blockIdx.x;
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
 
     const int mg = a.m0 + img;
     const int g = mg / a.rows_per_group;
@@ -561,6 +567,7 @@ __global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int img = blockIdx.x;
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
 
     const int mg = a.m0 + img;
     const int g = mg / a.rows_per_group;

@@ -79,6 +79,7 @@ struct efe_ctx {
     int64_t arena_align = 256;
     void* tl_buf = nullptr;   // EFE_TIMELINE experiments: device buffer of 64 int64 stamps (option "tl_buf" = device pointer)
     int64_t last_macs = 0;
+    const uint8_t* row_mask = nullptr; int row_mask_div = 1;      // efe_set_row_mask
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
     unsigned prof = 0;        // bitmask of ProfClass values to time
     int cls = PROF_OTHER;
@@ -199,7 +200,10 @@ struct NoiseCfg {
     GroupMap gm{1, 1, {0, 0, 0}, 0, 0};
     int rows_per_group = 1;
     uint32_t row_offset = 0;
+    const uint8_t* mask = nullptr;      // liveness of the logical rows (efe_set_row_mask), entry = row / mask_div
+    int mask_div = 1;
 };
+inline RowMask live_of(const NoiseCfg& nc, int m0) { return RowMask{nc.mask, nc.mask_div, m0, nc.rows_per_group}; }
 
 void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float* Y, int ldy, int M, bool relu, bool drop,
         uint32_t tag, const NoiseCfg& nc, int m0, hipStream_t st) {
@@ -265,16 +269,19 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
     fc(ctx, ctx->dec_fc[0], dec_in, 16, 0, hA, 256, N, true, true, TAG_DEC + 0, nc, 0, st);
     fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, N, true, true, TAG_DEC + 1, nc, 0, st);
     fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, N, true, true, TAG_DEC + 2, nc, 0, st);
+    int cur_m0 = 0;
     auto conv = [&](const Layer& L, const float* in, float* out, int n, int hin, int cin, int hout, int cout, int mode) {
         ConvGArgs a{};
         a.in = in; a.out = out; a.Wp = L.Wp; a.bias = L.bias; a.zeros = ctx->zeros; a.n_img = n; a.Hin = hin; a.Win = hin; a.Cin = cin;
         a.Hout = hout; a.Wout = hout; a.Cout = cout; a.mtiles = L.mtiles; a.mode = mode; a.relu = 1; a.ldo = cout; a.dbg = (int)ctx->dbg_b;
+        a.live = live_of(nc, cur_m0);
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_conv_g(a, st);
         ctx->prof_end(e0, st);
     };
     for (int m0 = 0; m0 < N; m0 += C) {
         const int c = std::min(C, N - m0);
+        cur_m0 = m0;
         ctx->cls = PROF_DEC_FC4;
         fc(ctx, ctx->g_fc4, hA + (size_t)m0 * 256, 256, 0, x4, B * B * 64, c, true, true, TAG_DEC + 3, nc, m0, st);
         ctx->cls = PROF_CT2;
@@ -285,7 +292,7 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
         FinalGArgs f{};
         f.y3 = y3; f.w = ctx->g_wf; for (int i = 0; i < 4; ++i) f.b[i] = ctx->g_bf[i];
         f.rows = c; f.m0 = m0; f.rows_per_group = nc.rows_per_group; f.H = H3; f.W = H3; f.C = ctx->chan; f.gm = nc.gm;
-        f.reward0 = reward0; f.store0 = store0; f.val = val; f.po = po_store;
+        f.reward0 = reward0; f.store0 = store0; f.val = val; f.po = po_store; f.live = live_of(nc, m0);
         hipEvent_t e0 = ctx->prof_begin(st);
         const int frc = launch_final_g(f, st);
         ctx->prof_end(e0, st);
@@ -360,14 +367,14 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         ctx->cls = PROF_CT2;
         DecAArgs da{};
         da.x4 = x4; da.y2 = y2; da.w1 = ctx->dec_ct[0].Wp; da.b1 = ctx->dec_ct[0].bias; da.w2 = ctx->dec_ct[1].Wp;
-        da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.queue = queues + m0 / C; da.dbg = (int)ctx->dbg_a; da.tl = (long long*)ctx->tl_buf;
+        da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.live = live_of(nc, m0); da.queue = queues + m0 / C; da.dbg = (int)ctx->dbg_a; da.tl = (long long*)ctx->tl_buf;
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_dec_a(da, st);
         ctx->prof_end(e0, st);
         ctx->cls = PROF_CT3;
         DecBArgs db{};
         db.y2 = y2; db.w3 = ctx->dec_ct[2].Wp; db.b3 = ctx->dec_ct[2].bias; db.w4 = ctx->dec_wf; db.b4 = ctx->dec_bf;
-        db.rows = c; db.m0 = m0; db.rows_per_group = nc.rows_per_group; db.gm = nc.gm; db.reward0 = reward0; db.store0 = store0;
+        db.rows = c; db.live = live_of(nc, m0); db.m0 = m0; db.rows_per_group = nc.rows_per_group; db.gm = nc.gm; db.reward0 = reward0; db.store0 = store0;
         db.val = val; db.po = po_store; db.dbg = (int)ctx->dbg_b; db.queue = queues + nchunks + m0 / C;
         e0 = ctx->prof_begin(st);
         launch_dec_b(db, st);
@@ -392,7 +399,7 @@ int run_encoder(efe_ctx* ctx, const float* o, int N, const NoiseCfg& nc, float* 
         EncArgs ea{};
         ea.o = o + (size_t)m0 * 4096; ea.out = c4; ea.w1 = ctx->enc_w1; ea.b1 = ctx->enc_b1;
         ea.w2 = ctx->enc_conv[0].Wp; ea.b2 = ctx->enc_conv[0].bias; ea.w3 = ctx->enc_conv[1].Wp; ea.b3 = ctx->enc_conv[1].bias;
-        ea.w4 = ctx->enc_conv[2].Wp; ea.b4 = ctx->enc_conv[2].bias; ea.rows = c;
+        ea.w4 = ctx->enc_conv[2].Wp; ea.b4 = ctx->enc_conv[2].bias; ea.rows = c; ea.live = live_of(nc, m0);
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_enc_trunk(ea, st);
         ctx->prof_end(e0, st);
@@ -424,6 +431,7 @@ struct CoreIO {
     int R, D, S, mean_mode, carry_mean;
     uint32_t k0, k1, stage0, row_offset;
     const float* eps;         // nullable, per stage [3S][R][10]
+    const uint8_t* mask = nullptr; int mask_div = 1;        // liveness of the R logical rows (efe_set_row_mask)
     // trajectory mode (D == 1, S == 1): T1 is given
     const float* given_ps1 = nullptr; const float* given_mean = nullptr; const float* given_logvar = nullptr;
     float *G = nullptr, *terms = nullptr, *ps1 = nullptr, *ps1_mean = nullptr, *po1 = nullptr, *t2parts = nullptr;
@@ -470,11 +478,13 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
     {   // one batched decoder pass over D x 3S groups
         NoiseCfg nc; nc.k0 = io.k0; nc.k1 = io.k1; nc.rows_per_group = R; nc.row_offset = io.row_offset;
         nc.gm = GroupMap{3 * S, S, {PASS_D1, PASS_D2A, PASS_D2B}, io.stage0, 0};
+        nc.mask = io.mask; nc.mask_div = io.mask_div;
         if (run_decoder(ctx, dec_in, D * 3 * S * R, nc, 1, 1, val, po_store, st)) return 1;
     }
     {   // one batched encoder pass over the D x S loop-1 images
         NoiseCfg nc; nc.k0 = io.k0; nc.k1 = io.k1; nc.rows_per_group = R; nc.row_offset = io.row_offset;
         nc.gm = GroupMap{S, S, {PASS_E1, 0, 0}, io.stage0, 0};
+        nc.mask = io.mask; nc.mask_div = io.mask_div;
         if (run_encoder(ctx, po_store, D * S * R, nc, enc, st)) return 1;
     }
     TermsArgs ta{};
@@ -1001,6 +1011,7 @@ int efe_calculate_g(efe_ctx* ctx, const float* s0, const float* pi0, int M, int 
     io.x0 = x; io.R = M; io.D = 1; io.S = mean_mode ? 1 : samples; io.mean_mode = mean_mode; io.carry_mean = 0;
     io.k0 = (uint32_t)nz->seed; io.k1 = (uint32_t)(nz->seed >> 32); io.stage0 = nz->stage; io.row_offset = nz->row_offset;
     io.eps = eps; io.G = G; io.terms = terms; io.ps1 = ps1; io.ps1_mean = ps1_mean; io.po1 = po1; io.t2parts = t2parts;
+    io.mask = ctx->row_mask; io.mask_div = ctx->row_mask_div;
     if (run_core(ctx, io, st)) return 1;
     return finish(ctx, st);
 }
@@ -1040,7 +1051,7 @@ int efe_rollout(efe_ctx* ctx, const float* o, const float* pi, int M, int steps,
 
 static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, const float* mean_traj, const float* lv_traj,
                            const float* pi0_traj, int T, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t row_offset,
-                           const float* eps, float* G, hipStream_t st) {
+                           const float* eps, float* G, const uint8_t* mask, int mask_div, hipStream_t st) {
     float* x = ctx->allocT<float>((size_t)T * 16);
     if (!x) return 1;
     launch_pack_x(pi0_traj, s0_traj, x, T, ctx->pi_dim, S_DIM, st);
@@ -1048,7 +1059,7 @@ static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_
     io.x0 = x; io.R = T; io.D = 1; io.S = 1; io.mean_mode = 0; io.carry_mean = 0;
     io.k0 = k0; io.k1 = k1; io.stage0 = stage; io.row_offset = row_offset; io.eps = eps;
     io.given_ps1 = ps1_traj; io.given_mean = mean_traj; io.given_logvar = lv_traj;
-    io.G = G;
+    io.G = G; io.mask = mask; io.mask_div = mask_div;
     return run_core(ctx, io, st);
 }
 
@@ -1061,7 +1072,7 @@ int efe_trajectory(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, co
     if (!s0_traj || !ps1_traj || !ps1_mean_traj || !ps1_logvar_traj || !pi0_traj || !nz || !G || T < 1)
         return ctx->fail("efe_trajectory: bad arguments");
     if (trajectory_impl(ctx, s0_traj, ps1_traj, ps1_mean_traj, ps1_logvar_traj, pi0_traj, T, (uint32_t)nz->seed,
-                        (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, eps, G, st)) return 1;
+                        (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, eps, G, nullptr, 1, st)) return 1;
     return finish(ctx, st);
 }
 
@@ -1094,7 +1105,7 @@ int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int us
         ctx->last_macs += (int64_t)E * T * (ctx->mac_trans + ctx->mac_habit);
     }
     if (trajectory_impl(ctx, s0t, ps1t, mt, lvt, pi0, E * T, k0, k1, nz->stage, nz->row_offset * (uint32_t)T,
-                        eps ? eps + (size_t)T * E * 10 : nullptr, Gt, st)) return 1;
+                        eps ? eps + (size_t)T * E * 10 : nullptr, Gt, ctx->row_mask, T, st)) return 1;     // trajectory row e * T + t belongs to episode e
     launch_mean_rows(Gt, G_mean, E, T, st);
     return finish(ctx, st);
 }
@@ -1106,6 +1117,14 @@ int efe_action_posterior(efe_ctx* ctx, const float* sum_G, int n_groups, int n, 
     HIPCHK(hipSetDevice(ctx->device));
     launch_posterior(sum_G, P, logP, n_groups, n, temperature, (hipStream_t)stream);
     return finish(ctx);
+}
+
+int efe_set_row_mask(efe_ctx* ctx, const uint8_t* mask, int rows_per_entry) {
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
+    if (mask && rows_per_entry < 1) return ctx->fail("efe_set_row_mask: rows_per_entry < 1");
+    ctx->row_mask = mask; ctx->row_mask_div = mask ? rows_per_entry : 1;
+    return 0;
 }
 
 // ---- scratch management --------------------------------------------------------------------------------

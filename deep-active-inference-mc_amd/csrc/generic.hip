@@ -145,6 +145,7 @@ __global__ void __launch_bounds__(256, 2) k_convt_l(const ConvGArgs a) {
     const int TH = (32 * ntw) / a.Win;
     const int spi = (a.Hin + TH - 1) / TH;
     const int img = blockIdx.x / spi, r0 = (blockIdx.x - img * spi) * TH;
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
     const int nrow = min(TH, a.Hin - r0);
     const int nq = nrow * a.Win;
     const int WSL = a.Win + PADT + 1, NR = nrow + PADT + 1;
@@ -325,6 +326,7 @@ __global__ void __launch_bounds__(256, 2) k_final_g(const FinalGArgs a) {
     for (int i = tid; i < 27 * PS; i += 256) fg_T[i] = 0.0f;
 
     const int img = blockIdx.x;
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
     const int mg = a.m0 + img;
     const int g = mg / a.rows_per_group;
     const int r = mg - g * a.rows_per_group;

@@ -41,6 +41,16 @@ __device__ __forceinline__ uint2 group_key(const GroupMap& gm, int g) {
     return make_uint2(stream_id(pass, gm.sample0 + (uint32_t)samp), gm.stage0 + (uint32_t)t);
 }
 
+// Optional liveness mask of the logical rows of a call (efe_set_row_mask: the lock-step planner's early-stopped episodes): image m of
+// a launch belongs to logical row (m0 + m) % rows_per_group and is evaluated iff mask == nullptr or mask[row / div] != 0.  The
+// per-image kernels (decoder stages, encoder trunk) skip dead images; the outputs of dead rows are unspecified.
+struct RowMask {
+    const uint8_t* mask; int div, m0, rows_per_group;
+};
+__device__ __forceinline__ bool row_live(const RowMask& k, int m) {
+    return !k.mask || k.mask[((k.m0 + m) % k.rows_per_group) / k.div] != 0;
+}
+
 struct GemmArgs {
     const float* Wp;      // packed weights [tap][mtile][kc][64 lanes][4]
     const float* bias;    // [mtiles*32]
@@ -69,6 +79,7 @@ struct DecAArgs {
     const float* w1; const float* b1;   // packed [9][2][8][64][4], bias [64]
     const float* w2; const float* b2;
     int rows;
+    RowMask live;
     int* queue;           // zero-initialised ticket counter of this launch: images beyond the first two per workgroup are claimed dynamically
     int dbg;              // experiments only (0 in production): 2 = skip next-image prefetch, 4 = eight-wave workgroups
     long long* tl;        // timeline experiments only (EFE_TIMELINE builds): s_memtime stamps of workgroup 0 / wave 0
@@ -79,6 +90,7 @@ struct DecBArgs {
     const float* w3; const float* b3;   // packed [9][1][8][64][4], bias [32]
     const float* w4; float b4;          // [9 taps][32 ch], scalar bias
     int rows;             // decoder rows (images) in this launch
+    RowMask live;
     int m0;               // index of row 0 inside the [group][row] batch
     int rows_per_group;
     GroupMap gm;
@@ -98,6 +110,7 @@ struct EncArgs {
     const float* w3; const float* b3;   // packed [9][2][4][64][4]
     const float* w4; const float* b4;   // packed [9][2][8][64][4]
     int rows;
+    RowMask live;
 };
 void launch_enc_trunk(const EncArgs& a, hipStream_t st);
 void launch_fc4(const GemmArgs& a, hipStream_t st);      // Linear(256,16384)+ReLU+Dropout with the batch tile staged in LDS
@@ -188,6 +201,7 @@ struct ConvGArgs {
     int mode;                         // 0 Conv2d(k3,s2,p0)   1 ConvTranspose2d(k3,s1,p1)   2 ConvTranspose2d(k3,s2,p1,op1), sub-pixel form
     int relu;
     int ldo;                          // floats per output pixel
+    RowMask live;                     // LDS-tiled ConvT kernels only (the decoder's layers)
     int dbg;                          // development switches (engine option dbg_b): 1 one weight slab, 2 no stores, 4 no strip loads -- wrong results, timing only
 };
 void launch_conv_g(const ConvGArgs& a, hipStream_t st);
@@ -197,6 +211,7 @@ struct FinalGArgs {
     int rows, m0, rows_per_group, H, W, C;
     GroupMap gm;
     int reward0, store0;
+    RowMask live;
     float* val;                       // [batch] per-image sums
     float* po;                        // [slots][rows_per_group][H*W][8] stored images (NHWC, channels padded to 8)
 };

@@ -283,6 +283,9 @@ class BatchedMCTS:
             return self._run(frames, o_shape)
         finally:
             torch.set_num_threads(prev)
+            self.model.set_row_mask(None)
+            if self.overlap:
+                self.sim_model.set_row_mask(None)
 
     def _run(self, frames, o_shape):
         m, E, p, A, p_ = self.model, self.E, self.p, self.pi_dim, self._p
@@ -300,6 +303,12 @@ class BatchedMCTS:
                     res[e] = ([int(torch.multinomial(q_cpu[e], 1))], 0, 0, [], [])
                     active_h[e] = False
         active = active_h.to(torch.uint8).to(m.device)
+        # early-stopped (and habit-decided) episodes stop costing flops: the engine's per-image kernels read `active` on the device
+        # and skip their rows (efe_set_row_mask; efe_mcts_stop clears entries as the loop runs, no host round trip involved)
+        if getattr(p, 'skip_stopped', True):
+            m.set_row_mask(active, A)
+            if self.overlap:
+                self.sim_model.set_row_mask(active, 1)
         self._expand(torch.zeros(E, dtype=torch.int32, device=m.device), active, self.S[:, 0].repeat_interleave(A, dim=0).contiguous())
         n_iter = 0
         # The per-episode early stop (mcts.py:176) is applied on the device every iteration (stopped episodes are masked out of

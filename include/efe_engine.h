@@ -71,6 +71,14 @@ int efe_reserve(efe_ctx* ctx, int64_t bytes);
 int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples);
 int efe_arena_stats(efe_ctx* ctx, int64_t* capacity_bytes, int64_t* high_water_bytes, int64_t* grow_count);
 
+/* Liveness mask of the logical rows of the following efe_calculate_g / efe_simulate calls on this context -- the lock-step planner's
+ * early-stopped episodes (the per-episode break of /root/reference/src/mcts.py:176).  `mask` is a DEVICE array, one byte per entry,
+ * read when the kernels run (earlier work on the same stream may update it): efe_calculate_g row r belongs to entry
+ * r / rows_per_entry, efe_simulate episode e to entry e.  The per-image kernels (decoder stages, encoder trunk: ~90 % of the work)
+ * skip dead rows, whose outputs are then unspecified; live rows are bit-identical to an unmasked call.  NULL clears the mask; the
+ * other entry points ignore it. */
+int efe_set_row_mask(efe_ctx* ctx, const uint8_t* mask, int rows_per_entry);
+
 typedef struct efe_noise {
     uint64_t seed;
     uint32_t stage;       /* call / stage counter */

@@ -724,3 +724,63 @@ def test_torch_ops_are_the_dispatch_path(models):
         ops.habit(e.h, s0.cpu())                          # no CPU kernel is registered: no fallback
     with pytest.raises(RuntimeError):
         ops.calculate_g(e.h, s0, m.pi_one_hot, 0, False, 19, 7, 0, None)
+
+
+# ------------------------------------------------------------------------------------------------------
+# efe_set_row_mask: early-stopped episodes are skipped by the per-image kernels, live rows do not change
+# ------------------------------------------------------------------------------------------------------
+def test_row_mask_live_rows_are_bit_identical(models):
+    m = models(1234, 1.15, 33)
+    A, Eps = 4, 5
+    M = A * Eps
+    s0 = PX.uniform_fill(2, (M, 10), 77, -1, 1)
+    pi0 = np.eye(4, dtype=np.float32)[np.arange(M) % 4]
+    starts = PX.uniform_fill(9, (Eps, 10), 78, -1, 1)
+    ref = m.calculate_G(s0, pi0, samples=3, stage=4)
+    rsim = m.simulate_batch(starts, 3, use_means=False, stage=9)
+    alive = torch.tensor([1, 0, 1, 1, 0], dtype=torch.uint8, device=m.device)
+    try:
+        m.set_row_mask(alive, A)
+        out = m.calculate_G(s0, pi0, samples=3, stage=4)
+        osim = m.simulate_batch(starts, 3, use_means=False, stage=9)
+    finally:
+        m.set_row_mask(None)
+    rows = alive.bool().repeat_interleave(A)
+    assert torch.equal(out[0][rows], ref[0][rows])                       # G
+    for k in range(3):
+        assert torch.equal(out[1][k][rows], ref[1][k][rows])             # terms
+    assert torch.equal(out[2][rows], ref[2][rows]) and torch.equal(out[4][rows], ref[4][rows])      # ps1, po1
+    ep = alive.bool()
+    assert torch.equal(osim[0][ep], rsim[0][ep]) and torch.equal(osim[1][ep], rsim[1][ep])
+    # and after clearing the mask everything is evaluated again
+    again = m.calculate_G(s0, pi0, samples=3, stage=4)
+    assert torch.equal(again[0], ref[0])
+    with pytest.raises(ValueError):
+        m.set_row_mask(torch.ones(5, dtype=torch.float32, device=m.device), A)
+
+
+def test_batched_mcts_skipping_stopped_episodes_changes_nothing(models):
+    """the lock-step planner with the engine skipping early-stopped episodes == the same planner evaluating every episode"""
+    import daimc_amd
+    m = models(1234, 1.15, 21)
+    p = daimc_amd.MCTS_Params()
+    p.repeats, p.simulation_depth, p.use_means = 12, 3, False
+    p.samples = 2
+    frames = torch.from_numpy(synth.make_frames(56, 9)[:, 0][:, None])
+    mixed = False
+    for thr in (0.3, 0.25, 0.2, 0.15, 0.1):                 # the first threshold at which some, not all, episodes stop early
+        p.threshold = thr
+        res = []
+        for skip in (True, False):
+            p.skip_stopped = skip
+            m._stage = 0
+            res.append(daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64)))
+        (out_a, dist_a), (out_b, dist_b) = res
+        for e in range(len(out_a)):
+            assert out_a[e][0] == out_b[e][0] and out_a[e][1] == out_b[e][1] and out_a[e][3] == out_b[e][3] and out_a[e][4] == out_b[e][4]
+        assert torch.equal(dist_a, dist_b)
+        stops = [o[1] for o in out_a]
+        if min(stops) < max(stops):
+            mixed = True
+            break
+    assert mixed, 'no threshold stopped some episodes early: the fixture does not exercise the skip'
