@@ -260,6 +260,191 @@ __global__ void __launch_bounds__(256, 2) k_convt_l(const ConvGArgs a) {
         }
     }
 }
+// ---------------------------------------------------------------------------------------------------------
+// k_convt_p: the same strips, one workgroup per IMAGE walking down its strips.  The strip tile is a ring of TH + PADT + 1 rows in LDS
+// (slot of global row g = (g + PADT) mod ring): consecutive strips share their halo row(s) in place, only the TH new rows of the next
+// strip are fetched -- into registers, during the last two channel blocks of the current strip's contraction (after the last
+// weight-fragment request: vmcnt retires in order, a prefetch issued earlier would sit in front of every fragment wait) -- and
+// written to LDS between two barriers after the strip's stores have been issued.  k_convt_l's workgroups lived fill -> compute ->
+// store with nothing overlapped inside a workgroup and three workgroups per CU (LDS) to hide it: 0.56 / 0.70 of the MFMA rate.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int CP_PF = 10;          // float4 per thread of the next strip's new rows: TH * (Win + 2) * Cin / 4 / 256 <= 10 for Cin <= 64
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) k_convt_p(const ConvGArgs a) {
+    __shared__ int cl_off[128];                      // per strip pixel: float offset of its (first-parity) output pixel for r0 = 0
+    extern __shared__ float4 cl_x[];                 // [ring row][col][Cin / 4 + 1] float4
+    constexpr int PADT = MODE == 1 ? 1 : 0;
+    constexpr int NV = MODE == 1 ? 9 : 4;
+    constexpr int NA = MODE == 1 ? 1 : 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int Cin = a.Cin, KC = Cin >> 3, C4 = Cin >> 2, PS4 = C4 + 1;
+    const int ntw = 4 / a.mtiles;
+    const int TH = (32 * ntw) / a.Win;
+    const int spi = (a.Hin + TH - 1) / TH;
+    const int img = blockIdx.x;
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    const int WSL = a.Win + PADT + 1, NRT = TH + PADT + 1;
+    const float* src = a.in + (size_t)img * a.Hin * a.Win * Cin;
+    const int c4 = tid % C4, pstep = 256 / C4;
+
+    // rows [g0, g0 + nr) of the image (zeros outside it) -> their ring slots
+    auto rows_to_lds = [&](int g0, int nr) {
+        const int npix = nr * WSL;
+        int pix = tid / C4;
+        int lr = pix / WSL, lx = pix - lr * WSL;
+#pragma unroll 8
+        for (; pix < npix; pix += pstep) {
+            const int gr = g0 + lr, gx = lx - PADT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr >= 0 && gr < a.Hin && gx >= 0 && gx < a.Win && !(a.dbg & 4)) v = *reinterpret_cast<const float4*>(src + ((size_t)gr * a.Win + gx) * Cin + 4 * c4);
+            cl_x[(((gr + PADT) % NRT) * WSL + lx) * PS4 + c4] = v;
+            lx += pstep;
+            while (lx >= WSL) { lx -= WSL; ++lr; }
+        }
+    };
+    rows_to_lds(-PADT, NRT);                           // strip 0: rows -PADT .. TH
+    if (tid < 128) {
+        const int rw = tid / a.Win, xw = tid - rw * a.Win;
+        cl_off[tid] = rw < TH ? ((MODE == 2 ? 2 * rw : rw) * a.Wout + (MODE == 2 ? 2 * xw : xw)) * a.ldo * 4 : 0x40000000;     // bytes; the sentinel is outside every image
+    }
+    __syncthreads();
+
+    const int nt = wave % ntw, mt = wave / ntw;
+    const int q = nt * 32 + j;
+    const int qq = q < TH * a.Win ? q : 0;
+    const int row = qq / a.Win, x = qq - row * a.Win;
+    const int co = mt * 32 + j;
+    const float bias = co < a.Cout ? a.bias[co] : 0.0f;
+    // a strip pixel outside the image has a first-parity offset >= the image size: dropped whether or not the scalar parity offset is part of the check
+    const int img_floats = a.Hout * a.Wout * a.ldo;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)img * img_floats, 0, img_floats * 4, 0x00020000);
+    const int strip_floats = (MODE == 2 ? 2 : 1) * TH * a.Wout * a.ldo;
+
+    constexpr int NM = 9;
+    constexpr int mv[2][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 0, 0, 0, 1, 1, 2, 2, 3}};
+    constexpr int mtap[2][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {4, 5, 7, 8, 3, 6, 1, 2, 0}};
+    constexpr int macc[2][9] = {{0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 1, 3, 2, 3, 3}};
+    constexpr int MI = MODE - 1;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wp), 0, 0x7fffffff, 0x00020000);
+    const unsigned wl = (unsigned)lane * 16u;
+
+    for (int s = 0; s < spi; ++s) {
+        const int r0 = s * TH;
+        const int nq = min(TH, a.Hin - r0) * a.Win;
+        const bool more = s + 1 < spi;
+        const bool busy = nt * 32 < nq;                // wave-uniform: a short last strip leaves waves without pixels
+        // operand views of this strip: view v = local row row + dv, column x + dx; ring slot of the tile's first row = r0 mod NRT
+        int vb[NV];
+        {
+            const int s0 = r0 % NRT;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                int lr = s0 + row + (MODE == 1 ? 2 - v / 3 : (v >> 1));
+                if (lr >= NRT) lr -= NRT;
+                const int lx = MODE == 1 ? x + 2 - v % 3 : x + (v & 1);
+                vb[v] = (lr * WSL + lx) * PS4 + h;
+            }
+        }
+        float4 pf[CP_PF];
+        // the next strip's new rows g = r0 + TH + 1 .. r0 + 2 TH: this thread's elements (same walk as rows_to_lds)
+        auto request_next = [&]() {
+            const int npix = TH * WSL;
+            int pix = tid / C4;
+            int lr = pix / WSL, lx = pix - lr * WSL;
+#pragma unroll
+            for (int i = 0; i < CP_PF; ++i) {
+                const int gr = r0 + TH + 1 + lr, gx = lx - PADT;
+                pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pix < npix && gr < a.Hin && gx >= 0 && gx < a.Win && !(a.dbg & 4)) pf[i] = *reinterpret_cast<const float4*>(src + ((size_t)gr * a.Win + gx) * Cin + 4 * c4);
+                pix += pstep; lx += pstep;
+                while (lx >= WSL) { lx -= WSL; ++lr; }
+            }
+        };
+        f32x16 acc[NA];
+        if (busy) {
+#pragma unroll
+            for (int p = 0; p < NA; ++p)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[p][e] = bias;          // a lane owns one output channel: the bias is the accumulator's start value
+            auto load_a = [&](float4 (&av)[NM], int kc) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((mtap[MI][m] * a.mtiles + mt) * KC + kc) * 64) * 16u, 0);
+                    av[m] = __builtin_bit_cast(float4, v);
+                }
+            };
+            auto load_b = [&](float4 (&bv)[NV], int kc) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) bv[v] = cl_x[vb[v] + 2 * kc];
+            };
+            auto step = [&](const float4 (&av)[NM], const float4 (&bv)[NV]) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    const float4 b = bv[mv[MI][m]];
+                    f32x16& c = acc[macc[MI][m]];
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, av[m].x, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, av[m].y, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, av[m].z, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, av[m].w, c, 0, 0, 0);
+                }
+            };
+            // both operands one channel block ahead: fragments a0 / a1 (L1 / L2), strip views b0 / b1 (LDS)
+            float4 a0[NM], a1[NM], b0[NV], b1[NV];
+            load_a(a0, 0); load_b(b0, 0);
+            for (int kc = 0; kc < KC; kc += 2) {           // KC is even
+                load_a(a1, kc + 1); load_b(b1, kc + 1);
+                if (kc + 2 >= KC && more) request_next();  // behind the last fragment request
+                __builtin_amdgcn_sched_barrier(0);
+                step(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kc + 2 < KC) { load_a(a0, kc + 2); load_b(b0, kc + 2); }
+                __builtin_amdgcn_sched_barrier(0);
+                step(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // epilogue: C/D layout column = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (pixel of the tile).
+            // Stores go through a buffer resource that covers exactly this image: a strip pixel outside it (a short last strip, the
+            // table's sentinel) has an out-of-range offset and is dropped by the hardware -- no branches around 64 stores.
+            if (co < a.Cout && !((a.dbg & 2) && acc[0][0] != 12345.678f)) {
+                const unsigned sbase = (unsigned)(s * strip_floats + co) * 4u;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int4 off = *reinterpret_cast<const int4*>(cl_off + nt * 32 + 8 * g4 + 4 * h);
+                    const unsigned offs[4] = {(unsigned)off.x, (unsigned)off.y, (unsigned)off.z, (unsigned)off.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned o = offs[i] + sbase;            // byte offset of the first-parity pixel's channel co
+#pragma unroll
+                        for (int p = 0; p < NA; ++p) {
+                            float v = acc[p][4 * g4 + i];
+                            if (a.relu) v = fmaxf(v, 0.0f);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, o, (unsigned)(((p >> 1) * a.Wout + (p & 1)) * a.ldo) * 4u, 0);
+                        }
+                    }
+                }
+            }
+        } else if (more) {
+            request_next();
+        }
+        if (!more) break;
+        __syncthreads();                                   // every wave is done reading the rows that are replaced
+        {
+            const int npix = TH * WSL;
+            int pix = tid / C4;
+            int lr = pix / WSL, lx = pix - lr * WSL;
+#pragma unroll
+            for (int i = 0; i < CP_PF; ++i) {
+                if (pix < npix) cl_x[(((r0 + TH + 1 + lr + PADT) % NRT) * WSL + lx) * PS4 + c4] = pf[i];
+                pix += pstep; lx += pstep;
+                while (lx >= WSL) { lx -= WSL; ++lr; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static size_t convt_l_lds(const ConvGArgs& a) {
     const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win, padt = a.mode == 1 ? 1 : 0;
     return (size_t)(TH + padt + 1) * (a.Win + padt + 1) * (a.Cin + 4) * sizeof(float);
@@ -270,14 +455,21 @@ constexpr size_t CONVT_L_MAX_LDS = 64 * 1024;
 static bool convt_l_ok(const ConvGArgs& a) {
     if (a.mode != 1 && a.mode != 2) return false;
     if ((a.Cin & 15) || (a.Cin & (a.Cin - 1)) || a.Cin > 256 || a.mtiles < 1 || a.mtiles > 2 || a.Win > 32 * (4 / a.mtiles)) return false;
+    const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win;
+    if ((long)TH * (a.Win + 2) * (a.Cin / 4) > 256L * CP_PF) return false;       // k_convt_p's register prefetch of a strip's new rows
     return convt_l_lds(a) <= CONVT_L_MAX_LDS;
 }
 
 void launch_conv_g(const ConvGArgs& a, hipStream_t st) {
     if (convt_l_ok(a)) {
         const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win, spi = (a.Hin + TH - 1) / TH;
-        if (a.mode == 1) hipLaunchKernelGGL(k_convt_l<1>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
-        else hipLaunchKernelGGL(k_convt_l<2>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
+        if (a.dbg & 8) {               // one workgroup per strip (the first LDS-tiled form; kept for A/B)
+            if (a.mode == 1) hipLaunchKernelGGL(k_convt_l<1>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
+            else hipLaunchKernelGGL(k_convt_l<2>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
+        } else {
+            if (a.mode == 1) hipLaunchKernelGGL(k_convt_p<1>, dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
+            else hipLaunchKernelGGL(k_convt_p<2>, dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
+        }
         return;
     }
     const long npix = (long)a.n_img * (a.mode == 2 ? a.Hin * a.Win : a.Hout * a.Wout);
@@ -446,6 +638,8 @@ int init_generic_kernels() {
     if (hipFuncSetAttribute((const void*)k_final_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)final_g_lds(FG_MAXW)) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_convt_l<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_convt_l<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_p<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_p<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
     return 0;
 }
 int launch_final_g(const FinalGArgs& a, hipStream_t st) {
