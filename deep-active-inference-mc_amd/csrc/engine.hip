@@ -75,7 +75,7 @@ struct efe_ctx {
     hipEvent_t done_ev = nullptr;
     size_t high_water = 0;         // largest arena use of any call so far (bytes)
     int64_t arena_grows = 0;       // number of hipMalloc calls the arena has made
-    int64_t dec_chunk = 32768, enc_chunk = 32768, dbg_a = 0, dbg_b = 0;
+    int64_t dec_chunk = 32768, enc_chunk = 32768, dbg_a = 0, dbg_b = 0, poison = -1, trace = 0;      // trace: development only -- synchronise and log around every profiled launch
     int64_t arena_align = 256;
     void* tl_buf = nullptr;   // EFE_TIMELINE experiments: device buffer of 64 int64 stamps (option "tl_buf" = device pointer)
     int64_t last_macs = 0;
@@ -90,11 +90,14 @@ struct efe_ctx {
         if (ev_used == ev_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev_pool.push_back(e); }
         return ev_pool[ev_used++];
     }
+    int trace_n = 0;
     hipEvent_t prof_begin(hipStream_t st) {
+        if (trace) { (void)hipStreamSynchronize(st); fprintf(stderr, "[efe trace] launch %d class %d ...\n", ++trace_n, cls); fflush(stderr); return (hipEvent_t)1; }
         if (!(prof & (1u << cls))) return nullptr;
         hipEvent_t a = ev_get(); (void)hipEventRecord(a, st); return a;
     }
     void prof_end(hipEvent_t a, hipStream_t st) {
+        if (trace) { hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[efe trace] launch %d done: %s\n", trace_n, hipGetErrorString(e)); fflush(stderr); return; }
         if (!a) return;
         hipEvent_t b = ev_get(); (void)hipEventRecord(b, st);
         ev_spans.push_back({cls, {a, b}});
@@ -510,6 +513,9 @@ int check_ready(efe_ctx* ctx, hipStream_t st) {
         if (hipStreamWaitEvent(st, ctx->done_ev, 0) != hipSuccess) return ctx->fail("hipStreamWaitEvent failed");
     }
     ctx->arena.reset();
+    if (ctx->poison >= 0)                  // development: every call starts on scratch filled with this byte (reads of never-written scratch show up)
+        for (auto& b : ctx->arena.blocks)
+            if (hipMemsetAsync(b.first, (int)(ctx->poison & 0xff), b.second, st) != hipSuccess) return ctx->fail("poison memset failed");
     ctx->last_macs = 0;
     return 0;
 }
@@ -578,7 +584,10 @@ int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channel
     }
     ctx->mac_trans = (int64_t)(pi_dim + 10) * 512 + 2 * 512 * 512 + 512 * 20;
     ctx->mac_habit = 10 * 128 + 128 * 128 + 128 * pi_dim;
-    if (hipMalloc((void**)&ctx->zeros, 8192) != hipSuccess || hipMemset(ctx->zeros, 0, 8192) != hipSuccess) { delete ctx; return 4; }
+    // rows beyond the batch read their K operand values from this block (k_dense / k_conv_g): it must cover the longest contraction,
+    // the encoder head's 64 * h4 * h4 inputs (3136 floats at resolution 128 -- an 8 KiB block was read past its end there)
+    const size_t zeros_bytes = std::max<size_t>(8192, ((size_t)ctx->enc_hw[4] * ctx->enc_hw[4] * 64 + 64) * sizeof(float));
+    if (hipMalloc((void**)&ctx->zeros, zeros_bytes) != hipSuccess || hipMemset(ctx->zeros, 0, zeros_bytes) != hipSuccess) { delete ctx; return 4; }
     ctx->owned.push_back(ctx->zeros);
     if (hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(ctx->zeros); delete ctx; return 6; }
     *out = ctx;
@@ -627,6 +636,8 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "tl_buf")) { ctx->tl_buf = (void*)(intptr_t)value; return 0; }
     if (!strcmp(name, "dbg_a")) { ctx->dbg_a = value; return 0; }
     if (!strcmp(name, "dbg_b")) { ctx->dbg_b = value; return 0; }
+    if (!strcmp(name, "poison")) { ctx->poison = value; return 0; }
+    if (!strcmp(name, "trace")) { ctx->trace = value; return 0; }
     if (!strcmp(name, "arena_align")) { if (value < 256 || (value & (value - 1))) return ctx->fail("arena_align must be a power of two >= 256"); ctx->arena_align = value; return 0; }
     if (!strcmp(name, "mid_unfused")) { ctx->mid_unfused = value; return 0; }
     if (!strcmp(name, "enc_chunk")) { if (value < 1) return ctx->fail("enc_chunk < 1"); ctx->enc_chunk = value; return 0; }

@@ -15,6 +15,7 @@ every draw is a pure function of (seed, stage, pass, sample, global row, element
 """
 import ctypes as C
 import os
+import sys
 import pickle
 
 import numpy as np
@@ -91,6 +92,10 @@ class _Engine:
 
     def __del__(self):
         try:
+            # at interpreter shutdown the HIP runtime / torch allocator may already be half torn down: the process is about to
+            # release everything anyway (one suite run in ~10 ended with a fatal signal after "N passed" before this guard)
+            if sys.is_finalizing():
+                return
             if self.ctx:
                 self.lib.efe_destroy(self.ctx)
                 self.ctx = C.c_void_p()
