@@ -3,6 +3,7 @@
 host-side bookkeeping (pi_dim floats per node); every network evaluation goes to the HIP engine through
 `model.calculate_G[_mean]` / `model.mcts_step_simulate`.
 """
+import numpy as np
 import torch
 
 _OPPOSITE = {4: {(0, 1), (1, 0), (2, 3), (3, 2)}, 3: {(1, 2), (2, 1)}}
@@ -238,7 +239,7 @@ class BatchedMCTS:
         # stream through a replica context, so its launch-bound chain hides under the expansion's MFMA-bound kernels.
         self.overlap = E >= 8 and getattr(params, 'overlap_simulate', True)
         if self.overlap:
-            self.sim_model = model.replica()
+            self.sim_model = model.cached_replica()
             self.sim_stream = torch.cuda.Stream(device=dev)
             self.ev_sel = torch.cuda.Event()
             self.ev_sim = torch.cuda.Event()
@@ -264,11 +265,11 @@ class BatchedMCTS:
         self._call(m._engine.lib.efe_mcts_expand, p_(self.n_nodes), p_(nodes), p_(mask), p_(G), p_(ps_next))
 
     def action_selection(self, e, N=None, child=None):
-        N = self.N.cpu() if N is None else N
-        child = self.child.cpu() if child is None else child
+        N = self.N.cpu().numpy() if N is None else np.asarray(N)
+        child = self.child.cpu().numpy() if child is None else np.asarray(child)
         visited, node = [], 0
         while True:
-            a = int(torch.argmax(N[e, node]))
+            a = int(np.argmax(N[e, node]))
             visited.append(a)
             node = int(child[e, node, a])
             if child[e, node, 0] < 0:
@@ -347,16 +348,16 @@ class BatchedMCTS:
             self._call(lib.efe_mcts_backprop, p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(active),
                        p_(self.sims), int(p.simulation_repeats), p_(self.q0), self.max_depth, p_(self.H_g[repeat]), p_(self.H_active[repeat]))
             n_iter += 1
-        # read the history back once
-        H_act, H_len = self.H_act[:n_iter].cpu(), self.H_len[:n_iter].cpu()
-        H_g, H_active = self.H_g[:n_iter].cpu(), self.H_active[:n_iter].cpu().bool()
-        stop_at, N, child = self.stop_at.cpu(), self.N.cpu(), self.child.cpu()
+        # read the history back once, then plain numpy on the host (per-element torch indexing here cost ~30 ms per 64-episode decision)
+        H_act, H_len = self.H_act[:n_iter].cpu().numpy(), self.H_len[:n_iter].cpu().numpy()
+        H_g, H_active = self.H_g[:n_iter].cpu().numpy(), self.H_active[:n_iter].cpu().numpy().astype(bool)
+        stop_at, N, child = self.stop_at.cpu().numpy(), self.N.cpu().numpy(), self.child.cpu().numpy()
         for e in range(E):
             if res[e] is not None:
                 continue
-            its = [i for i in range(n_iter) if H_active[i, e]]
-            paths = [H_act[i, e, :int(H_len[i, e])].tolist() for i in its]
-            Gs = [H_g[i, e].item() for i in its]
+            its = np.nonzero(H_active[:, e])[0]
+            paths = [H_act[i, e, :H_len[i, e]].tolist() for i in its]
+            Gs = [float(g) for g in H_g[its, e]]
             reps = int(stop_at[e]) if stop_at[e] >= 0 else p.repeats
             explored = len(its) * p.simulation_depth * p.simulation_repeats
             res[e] = (self.action_selection(e, N, child), reps, explored, paths, Gs)

@@ -136,6 +136,7 @@ class _Module:
                 new[key] = t
         self._sd = new
         self._owner._weights_dirty = True
+        self._owner._weights_version = getattr(self._owner, '_weights_version', 0) + 1
 
     def parameters(self):
         return list(self._sd.values())
@@ -321,6 +322,18 @@ class ActiveInferenceModel:
                                  colour_channels=self.colour_channels, resolution=self.resolution, device=self.device, seed=self.seed,
                                  row_offset=self.row_offset, init_weights=False)
         r.load_state_dicts(self.model_top._sd, self.model_mid._sd, self.model_down._sd)
+        r.eps_source, r.u_source = self.eps_source, self.u_source
+        return r
+
+    def cached_replica(self):
+        """the replica the lock-step planner runs its simulations on, created once per weight version (a replica packs and uploads
+        all weights: ~40 ms -- per planning decision it was 12 % of configs[2]) and refreshed with this model's noise settings"""
+        ver = getattr(self, '_weights_version', 0)
+        r = getattr(self, '_replica', None)
+        if r is None or self._replica_version != ver:
+            r = self.replica()
+            self._replica, self._replica_version = r, ver
+        r.seed, r.row_offset = self.seed, self.row_offset
         r.eps_source, r.u_source = self.eps_source, self.u_source
         return r
 
