@@ -86,6 +86,20 @@ int main(void) {
     for (int i = 0; i < M; ++i) {
         if (!isfinite(hG[0][i]) || hG[0][i] != hG[1][i]) { fprintf(stderr, "calculate_G not finite/deterministic\n"); return 1; }
     }
+    {   /* liveness mask: entry 0 (rows 0..3) dead, the other rows must not change */
+        unsigned char hmask[M / 4], *dmask;
+        for (int g = 0; g < M / 4; ++g) hmask[g] = g != 0;
+        HIP(hipMalloc((void**)&dmask, M / 4));
+        HIP(hipMemcpy(dmask, hmask, M / 4, hipMemcpyHostToDevice));
+        CHECK(efe_set_row_mask(ctx, dmask, 4));
+        CHECK(efe_calculate_g(ctx, ds, dpi, M, S, 0, &nz, NULL, dG, dT, dps1, dmean, dpo1, NULL, NULL));
+        CHECK(efe_set_row_mask(ctx, NULL, 1));
+        float hGm[M];
+        HIP(hipMemcpy(hGm, dG, M * 4, hipMemcpyDeviceToHost));
+        for (int i = 4; i < M; ++i) if (hGm[i] != hG[0][i]) { fprintf(stderr, "row mask changed a live row\n"); return 1; }
+        CHECK(efe_calculate_g(ctx, ds, dpi, M, S, 0, &nz, NULL, dG, dT, dps1, dmean, dpo1, NULL, NULL));     /* dG complete again for the posterior */
+        HIP(hipFree(dmask));
+    }
     CHECK(efe_action_posterior(ctx, dG, M / 4, 4, 10.0f, dP, dlogP, NULL));
     float hP[M];
     HIP(hipMemcpy(hP, dP, M * 4, hipMemcpyDeviceToHost));

@@ -215,3 +215,22 @@ def test_other_geometries_networks(A2, C2, R2):
     np.testing.assert_allclose(c(terms[0]), oterms[0].numpy(), atol=sumtol(oterms[0].numpy()))
     np.testing.assert_allclose(c(terms[1]), oterms[1].numpy(), atol=1e-3)
     np.testing.assert_allclose(c(G), oG.numpy(), atol=3 * sumtol(oterms[0].numpy()))
+
+
+def test_row_mask_generic_geometry(pair):
+    """efe_set_row_mask on the generic path (ConvT / final-layer kernels skip dead images): live rows bit-identical"""
+    m, _ = pair
+    Eps = 4
+    M = A * Eps
+    s0 = PX.uniform_fill(4, (M, 10), 160, -1.0, 1.0)
+    pi0 = np.eye(A, dtype=np.float32)[np.arange(M) % A]
+    ref = m.calculate_G(s0, pi0, samples=2, stage=6)
+    alive = torch.tensor([0, 1, 1, 0], dtype=torch.uint8, device=m.device)
+    try:
+        m.set_row_mask(alive, A)
+        out = m.calculate_G(s0, pi0, samples=2, stage=6)
+    finally:
+        m.set_row_mask(None)
+    rows = alive.bool().repeat_interleave(A)
+    assert torch.equal(out[0][rows], ref[0][rows]) and torch.equal(out[2][rows], ref[2][rows]) and torch.equal(out[4][rows], ref[4][rows])
+    assert torch.equal(m.calculate_G(s0, pi0, samples=2, stage=6)[0], ref[0])

@@ -784,3 +784,30 @@ def test_batched_mcts_skipping_stopped_episodes_changes_nothing(models):
             mixed = True
             break
     assert mixed, 'no threshold stopped some episodes early: the fixture does not exercise the skip'
+
+
+def test_cached_simulation_replica_follows_the_weights(models, weights_cache):
+    """the lock-step planner's simulation replica is cached on the model per weight version: after new weights are loaded the
+    next decision must plan with them (== a fresh model with those weights), not with the cached copy"""
+    import daimc_amd
+    p = daimc_amd.MCTS_Params()
+    p.repeats, p.simulation_depth, p.use_means, p.threshold, p.samples = 4, 3, False, 0.9, 2
+    frames = torch.from_numpy(synth.make_frames(57, 8)[:, 0][:, None])           # 8 episodes: the overlapped (replica) path
+    m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=3, init_weights=False)
+    m.load_flat_weights(weights_cache(1234, 1.0))
+    m._stage = 0
+    daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
+    r1 = m._replica
+    m._stage = 0
+    daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
+    assert m._replica is r1                                                      # reused
+    m.load_flat_weights(weights_cache(1234, 1.35))
+    m._stage = 0
+    out, dist = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
+    assert m._replica is not r1
+    fresh = models(1234, 1.35, 3)
+    fresh._stage = 0
+    out2, dist2 = daimc_amd.active_inference_mcts_batch(fresh, frames, p, o_shape=(1, 64, 64))
+    for e in range(8):
+        assert out[e][0] == out2[e][0] and out[e][3] == out2[e][3] and out[e][4] == out2[e][4]
+    assert torch.equal(dist, dist2)
