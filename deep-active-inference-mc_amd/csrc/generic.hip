@@ -289,19 +289,40 @@ __global__ void __launch_bounds__(256, 2) k_convt_p(const ConvGArgs a) {
     const float* src = a.in + (size_t)img * a.Hin * a.Win * Cin;
     const int c4 = tid % C4, pstep = 256 / C4;
 
+    // This thread's walk over the (pixel, 16-byte channel group) elements of a block of rows: pixel += pstep per step, as a
+    // branch-free (row, column) update.  Loads are unconditional, so that the
+    // requests of a block stay in ONE basic block, back to back (with a branch per element hipcc serialised load -> wait -> LDS write).
+    const int dlr = pstep / WSL, dlx = pstep - dlr * WSL;
+    auto advance = [&](int& lr, int& lx) {
+        lr += dlr; lx += dlx;
+        const bool wrap = lx >= WSL;
+        lx = wrap ? lx - WSL : lx; lr = wrap ? lr + 1 : lr;
+    };
+    // (a buffer resource over the image: an element outside it -- halo, rows past the end, lanes past the block -- gets an
+    // out-of-range offset and the hardware returns zeros: no select, one 32-bit offset register per request)
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, a.Hin * a.Win * Cin * 4, 0x00020000);
+    auto fetch = [&](int gr, int lx, bool in_block) -> float4 {
+        const int gx = lx - PADT;
+        const bool ok = in_block && gr >= 0 && gr < a.Hin && gx >= 0 && gx < a.Win && !(a.dbg & 4);
+        const unsigned off = ok ? (unsigned)(((gr * a.Win + gx) * Cin + 4 * c4) * 4) : 0x80000000u;
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+    };
     // rows [g0, g0 + nr) of the image (zeros outside it) -> their ring slots
     auto rows_to_lds = [&](int g0, int nr) {
         const int npix = nr * WSL;
         int pix = tid / C4;
         int lr = pix / WSL, lx = pix - lr * WSL;
-#pragma unroll 8
-        for (; pix < npix; pix += pstep) {
-            const int gr = g0 + lr, gx = lx - PADT;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gr >= 0 && gr < a.Hin && gx >= 0 && gx < a.Win && !(a.dbg & 4)) v = *reinterpret_cast<const float4*>(src + ((size_t)gr * a.Win + gx) * Cin + 4 * c4);
-            cl_x[(((gr + PADT) % NRT) * WSL + lx) * PS4 + c4] = v;
-            lx += pstep;
-            while (lx >= WSL) { lx -= WSL; ++lr; }
+        while (pix < npix) {
+            float4 v[8]; int dst[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = fetch(g0 + lr, lx, pix < npix);
+                dst[i] = pix < npix ? (((g0 + lr + PADT) % NRT) * WSL + lx) * PS4 + c4 : -1;
+                pix += pstep; advance(lr, lx);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (dst[i] >= 0) cl_x[dst[i]] = v[i];
         }
     };
     rows_to_lds(-PADT, NRT);                           // strip 0: rows -PADT .. TH
@@ -349,17 +370,18 @@ __global__ void __launch_bounds__(256, 2) k_convt_p(const ConvGArgs a) {
         }
         float4 pf[CP_PF];
         // the next strip's new rows g = r0 + TH + 1 .. r0 + 2 TH: this thread's elements (same walk as rows_to_lds)
+        // the walk's start is laundered per strip: its ten (offset, validity) pairs are loop invariants that hipcc would otherwise
+        // keep in registers across the whole strip loop (256 VGPRs + spills)
+        int pix0 = tid / C4; asm volatile("" : "+v"(pix0));
+        const int lr0s = pix0 / WSL, lx0s = pix0 - lr0s * WSL;
         auto request_next = [&]() {
             const int npix = TH * WSL;
-            int pix = tid / C4;
-            int lr = pix / WSL, lx = pix - lr * WSL;
+            int pix = pix0;
+            int lr = lr0s, lx = lx0s;
 #pragma unroll
             for (int i = 0; i < CP_PF; ++i) {
-                const int gr = r0 + TH + 1 + lr, gx = lx - PADT;
-                pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pix < npix && gr < a.Hin && gx >= 0 && gx < a.Win && !(a.dbg & 4)) pf[i] = *reinterpret_cast<const float4*>(src + ((size_t)gr * a.Win + gx) * Cin + 4 * c4);
-                pix += pstep; lx += pstep;
-                while (lx >= WSL) { lx -= WSL; ++lr; }
+                pf[i] = fetch(r0 + TH + 1 + lr, lx, pix < npix);
+                pix += pstep; advance(lr, lx);
             }
         };
         f32x16 acc[NA];
@@ -371,7 +393,7 @@ __global__ void __launch_bounds__(256, 2) k_convt_p(const ConvGArgs a) {
             auto load_a = [&](float4 (&av)[NM], int kc) {
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
-                    const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((mtap[MI][m] * a.mtiles + mt) * KC + kc) * 64) * 16u, 0);
+                    const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((mtap[MI][m] * a.mtiles + mt) * KC + ((a.dbg & 1) ? 0 : kc)) * 64) * 16u, 0);
                     av[m] = __builtin_bit_cast(float4, v);
                 }
             };
@@ -432,13 +454,17 @@ __global__ void __launch_bounds__(256, 2) k_convt_p(const ConvGArgs a) {
         __syncthreads();                                   // every wave is done reading the rows that are replaced
         {
             const int npix = TH * WSL;
-            int pix = tid / C4;
-            int lr = pix / WSL, lx = pix - lr * WSL;
+            int pix = pix0;
+            int lr = lr0s, lx = lx0s;
+            int slot = (r0 + TH + 1 + lr + PADT) % NRT;    // ring slot of this thread's row, advanced without divisions
 #pragma unroll
             for (int i = 0; i < CP_PF; ++i) {
-                if (pix < npix) cl_x[(((r0 + TH + 1 + lr + PADT) % NRT) * WSL + lx) * PS4 + c4] = pf[i];
-                pix += pstep; lx += pstep;
-                while (lx >= WSL) { lx -= WSL; ++lr; }
+                if (pix < npix) cl_x[(slot * WSL + lx) * PS4 + c4] = pf[i];
+                pix += pstep;
+                const int lr0 = lr;
+                advance(lr, lx);
+                slot += lr - lr0;
+                while (slot >= NRT) slot -= NRT;
             }
         }
         __syncthreads();
