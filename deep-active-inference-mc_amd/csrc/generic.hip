@@ -14,6 +14,7 @@
 //                tile), the per-image Bernoulli-entropy / reward sums in a fixed order, and the image store
 //   k_to_nhwc8 / k_to_nchw : layout changes at the API boundary (observations are NCHW, torchmodel.py:134)
 #include "kernels.h"
+#include <type_traits>
 
 namespace efe {
 
@@ -269,8 +270,8 @@ __global__ void __launch_bounds__(256, 2) k_convt_l(const ConvGArgs a) {
 // store with nothing overlapped inside a workgroup and three workgroups per CU (LDS) to hide it: 0.56 / 0.70 of the MFMA rate.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int CP_PF = 10;          // float4 per thread of the next strip's new rows: TH * (Win + 2) * Cin / 4 / 256 <= 10 for Cin <= 64
-template <int MODE>
-__global__ void __launch_bounds__(256, 2) k_convt_p(const ConvGArgs a) {
+template <int MODE, bool SPLIT>
+__global__ void __launch_bounds__(256, SPLIT ? 3 : 2) k_convt_p(const ConvGArgs a) {
     __shared__ int cl_off[128];                      // per strip pixel: float offset of its (first-parity) output pixel for r0 = 0
     extern __shared__ float4 cl_x[];                 // [ring row][col][Cin / 4 + 1] float4
     constexpr int PADT = MODE == 1 ? 1 : 0;
@@ -384,6 +385,80 @@ __global__ void __launch_bounds__(256, 2) k_convt_p(const ConvGArgs a) {
                 pix += pstep; advance(lr, lx);
             }
         };
+        if constexpr (SPLIT && MODE == 2) {
+            // Two passes over the strip, one per output-row parity (3 taps -> parities (0,0) (0,1); 6 taps -> (1,0) (1,1)): 32 accumulator
+            // registers live instead of 64, so three waves per SIMD fit (the strip's LDS already allowed three workgroups per CU).
+            if (busy) {
+                auto run_pass = [&](auto PC) {
+                    constexpr int P = decltype(PC)::value;
+                    constexpr int NMP = P == 0 ? 3 : 6, NVP = P == 0 ? 2 : 4;
+                    constexpr int pvw[2][6] = {{0, 0, 1, 0, 0, 0}, {0, 0, 1, 2, 2, 3}};
+                    constexpr int ptp[2][6] = {{4, 5, 3, 0, 0, 0}, {7, 8, 6, 1, 2, 0}};
+                    constexpr int pac[2][6] = {{0, 1, 1, 0, 0, 0}, {0, 1, 1, 0, 1, 1}};
+                    f32x16 ac[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) ac[p][e] = bias;
+                    auto load_a = [&](float4 (&av)[NMP], int kc) {
+#pragma unroll
+                        for (int m = 0; m < NMP; ++m) {
+                            const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + kc) * 64) * 16u, 0);
+                            av[m] = __builtin_bit_cast(float4, v);
+                        }
+                    };
+                    auto step = [&](const float4 (&av)[NMP], int kc) {
+                        float4 bv[NVP];
+#pragma unroll
+                        for (int v = 0; v < NVP; ++v) bv[v] = cl_x[vb[v] + 2 * kc];
+#pragma unroll
+                        for (int m = 0; m < NMP; ++m) {
+                            const float4 b = bv[pvw[P][m]];
+                            f32x16& c = ac[pac[P][m]];
+                            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, av[m].x, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, av[m].y, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, av[m].z, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, av[m].w, c, 0, 0, 0);
+                        }
+                    };
+                    float4 a0[NMP], a1[NMP];
+                    load_a(a0, 0);
+                    for (int kc = 0; kc < KC; kc += 2) {
+                        load_a(a1, kc + 1);
+                        if (P == 1 && kc + 2 >= KC && more) request_next();     // behind the strip's last fragment request
+                        __builtin_amdgcn_sched_barrier(0);
+                        step(a0, kc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kc + 2 < KC) load_a(a0, kc + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                        step(a1, kc + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (co < a.Cout && !((a.dbg & 2) && ac[0][0] != 12345.678f)) {
+                        const unsigned sbase = (unsigned)(s * strip_floats + co) * 4u;
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int4 off = *reinterpret_cast<const int4*>(cl_off + nt * 32 + 8 * g4 + 4 * h);
+                            const unsigned offs[4] = {(unsigned)off.x, (unsigned)off.y, (unsigned)off.z, (unsigned)off.w};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const unsigned o = offs[i] + sbase;
+#pragma unroll
+                                for (int pw = 0; pw < 2; ++pw) {
+                                    float v = ac[pw][4 * g4 + i];
+                                    if (a.relu) v = fmaxf(v, 0.0f);
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, o, (unsigned)((P * a.Wout + pw) * a.ldo) * 4u, 0);
+                                }
+                            }
+                        }
+                    }
+                };
+                run_pass(std::integral_constant<int, 0>{});
+                run_pass(std::integral_constant<int, 1>{});
+            } else if (more) {
+                request_next();
+            }
+        } else {
         f32x16 acc[NA];
         if (busy) {
 #pragma unroll
@@ -450,6 +525,7 @@ __global__ void __launch_bounds__(256, 2) k_convt_p(const ConvGArgs a) {
         } else if (more) {
             request_next();
         }
+        }
         if (!more) break;
         __syncthreads();                                   // every wave is done reading the rows that are replaced
         {
@@ -493,8 +569,9 @@ void launch_conv_g(const ConvGArgs& a, hipStream_t st) {
             if (a.mode == 1) hipLaunchKernelGGL(k_convt_l<1>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
             else hipLaunchKernelGGL(k_convt_l<2>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
         } else {
-            if (a.mode == 1) hipLaunchKernelGGL(k_convt_p<1>, dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
-            else hipLaunchKernelGGL(k_convt_p<2>, dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
+            if (a.mode == 1) hipLaunchKernelGGL((k_convt_p<1, false>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
+            else if (a.dbg & 16) hipLaunchKernelGGL((k_convt_p<2, false>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
+            else hipLaunchKernelGGL((k_convt_p<2, true>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
         }
         return;
     }
@@ -664,8 +741,9 @@ int init_generic_kernels() {
     if (hipFuncSetAttribute((const void*)k_final_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)final_g_lds(FG_MAXW)) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_convt_l<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_convt_l<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)k_convt_p<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)k_convt_p<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_p<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_p<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_p<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
     return 0;
 }
 int launch_final_g(const FinalGArgs& a, hipStream_t st) {
