@@ -75,7 +75,8 @@ struct efe_ctx {
     hipEvent_t done_ev = nullptr;
     size_t high_water = 0;         // largest arena use of any call so far (bytes)
     int64_t arena_grows = 0;       // number of hipMalloc calls the arena has made
-    int64_t dec_chunk = 32768, enc_chunk = 32768, dbg_a = 0, dbg_b = 0, poison = -1, trace = 0;      // trace: development only -- synchronise and log around every profiled launch
+    int64_t dec_chunk = 32768, enc_chunk = 32768, dbg_a = 0, dbg_b = 0, poison = -1, trace = 0, dec_chunk_g = 16384;
+    // dec_chunk_g: images per launch group of the generic decoder (1.6 MB of activations each at 84 x 84); poison / trace: development only
     int64_t arena_align = 256;
     void* tl_buf = nullptr;   // EFE_TIMELINE experiments: device buffer of 64 int64 stamps (option "tl_buf" = device pointer)
     int64_t last_macs = 0;
@@ -260,7 +261,7 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
 int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, int reward0, int store0, float* val, float* po_store,
                   hipStream_t st) {
     const int B = ctx->base, H2 = 2 * B, H3 = ctx->last_s1 ? 2 * B : 4 * B;
-    const int C = (int)std::min<int64_t>(std::min<int64_t>(ctx->dec_chunk, 4096), N);
+    const int C = (int)std::min<int64_t>(std::min<int64_t>(ctx->dec_chunk, ctx->dec_chunk_g), N);
     float* hA = ctx->allocT<float>((size_t)N * 256);
     float* hB = ctx->allocT<float>((size_t)N * 256);
     float* x4 = ctx->allocT<float>((size_t)C * B * B * 64);
@@ -636,6 +637,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "tl_buf")) { ctx->tl_buf = (void*)(intptr_t)value; return 0; }
     if (!strcmp(name, "dbg_a")) { ctx->dbg_a = value; return 0; }
     if (!strcmp(name, "dbg_b")) { ctx->dbg_b = value; return 0; }
+    if (!strcmp(name, "dec_chunk_g")) { if (value < 1) return ctx->fail("dec_chunk_g < 1"); ctx->dec_chunk_g = value; return 0; }
     if (!strcmp(name, "poison")) { ctx->poison = value; return 0; }
     if (!strcmp(name, "trace")) { ctx->trace = value; return 0; }
     if (!strcmp(name, "arena_align")) { if (value < 256 || (value & (value - 1))) return ctx->fail("arena_align must be a power of two >= 256"); ctx->arena_align = value; return 0; }
@@ -1178,7 +1180,7 @@ int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples) {
         enc(R);
         t += al(D * 2 * S * R * 32 * 4) + al(D * 3 * S * R * 16 * 4) + al(2 * R * 16 * 4) + al(D * 3 * S * R * 4) + al(D * S * R * IS * 4)
            + al(D * S * R * 32 * 4) + al(3 * R * 4);
-        {   const size_t N = D * 3 * S * R, C = std::min<size_t>(std::min<size_t>((size_t)dec_chunk, 4096), N);
+        {   const size_t N = D * 3 * S * R, C = std::min<size_t>(std::min<size_t>((size_t)dec_chunk, (size_t)ctx->dec_chunk_g), N);
             t += 2 * al(N * 256 * 4) + 2 * al(C * B * B * 64 * 4) + al(C * 4 * B * B * 64 * 4) + al(C * (size_t)ctx->res * ctx->res * 32 * 4); }
         enc(D * S * R);
         return (int64_t)(t + ((size_t)1 << 20));
