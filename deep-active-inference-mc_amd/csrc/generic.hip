@@ -407,10 +407,14 @@ __global__ void __launch_bounds__(256, SPLIT ? 3 : 2) k_convt_p(const ConvGArgs 
                             av[m] = __builtin_bit_cast(float4, v);
                         }
                     };
-                    auto step = [&](const float4 (&av)[NMP], int kc) {
-                        float4 bv[NVP];
-#pragma unroll
-                        for (int v = 0; v < NVP; ++v) bv[v] = cl_x[vb[v] + 2 * kc];
+                    // one contraction step: the strip views of block kc (requested a step earlier) against fragment set av; every
+                    // fragment is re-requested for block kc + 2 right behind the MFMAs that consumed it, every view for block kc + 1
+                    // behind its last reader, so each wait leaves the newer requests in flight (a bulk request per step made hipcc
+                    // wait for all of them in the middle of the step)
+                    constexpr int vlast[2][4] = {{1, 2, 0, 0}, {1, 2, 4, 5}};      // last MFMA group that reads view v
+                    // (pass 0 keeps two fragment sets, AD = 2 blocks ahead: its three groups are only 768 cycles; pass 1 refills one set, AD = 1)
+                    constexpr int AD = P == 0 ? 2 : 1;
+                    auto step = [&](float4 (&av)[NMP], float4 (&bv)[NVP], int kc) {
 #pragma unroll
                         for (int m = 0; m < NMP; ++m) {
                             const float4 b = bv[pvw[P][m]];
@@ -419,20 +423,32 @@ __global__ void __launch_bounds__(256, SPLIT ? 3 : 2) k_convt_p(const ConvGArgs 
                             c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, av[m].y, c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, av[m].z, c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, av[m].w, c, 0, 0, 0);
+                            if (kc + AD < KC) {
+                                const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + kc + AD) * 64) * 16u, 0);
+                                av[m] = __builtin_bit_cast(float4, v);
+                            }
+#pragma unroll
+                            for (int v = 0; v < NVP; ++v)
+                                if (vlast[P][v] == m && kc + 1 < KC) bv[v] = cl_x[vb[v] + 2 * (kc + 1)];      // view v is free: block kc + 1 in place
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     };
-                    float4 a0[NMP], a1[NMP];
+                    float4 a0[NMP], a1[AD == 2 ? NMP : 1], bv[NVP];
                     load_a(a0, 0);
+                    if (AD == 2) {
+#pragma unroll
+                        for (int m = 0; m < NMP; ++m) {
+                            const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + 1) * 64) * 16u, 0);
+                            a1[m % (AD == 2 ? NMP : 1)] = __builtin_bit_cast(float4, v);
+                        }
+                    }
+#pragma unroll
+                    for (int v = 0; v < NVP; ++v) bv[v] = cl_x[vb[v]];
                     for (int kc = 0; kc < KC; kc += 2) {
-                        load_a(a1, kc + 1);
                         if (P == 1 && kc + 2 >= KC && more) request_next();     // behind the strip's last fragment request
                         __builtin_amdgcn_sched_barrier(0);
-                        step(a0, kc);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (kc + 2 < KC) load_a(a0, kc + 2);
-                        __builtin_amdgcn_sched_barrier(0);
-                        step(a1, kc + 1);
-                        __builtin_amdgcn_sched_barrier(0);
+                        step(a0, bv, kc);
+                        if constexpr (AD == 2) step(a1, bv, kc + 1); else step(a0, bv, kc + 1);
                     }
                     if (co < a.Cout && !((a.dbg & 2) && ac[0][0] != 12345.678f)) {
                         const unsigned sbase = (unsigned)(s * strip_floats + co) * 4u;
@@ -551,7 +567,7 @@ static size_t convt_l_lds(const ConvGArgs& a) {
     const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win, padt = a.mode == 1 ? 1 : 0;
     return (size_t)(TH + padt + 1) * (a.Win + padt + 1) * (a.Cin + 4) * sizeof(float);
 }
-constexpr size_t CONVT_L_MAX_LDS = 64 * 1024;
+constexpr size_t CONVT_L_MAX_LDS = 100 * 1024;
 // the LDS-tiled kernels take the decoder's transposed layers when a full-width strip fits: Cin a power of two >= 16, one or two
 // 32-channel output tiles, Win <= 32 * (4 / mtiles)
 static bool convt_l_ok(const ConvGArgs& a) {
@@ -559,7 +575,7 @@ static bool convt_l_ok(const ConvGArgs& a) {
     if ((a.Cin & 15) || (a.Cin & (a.Cin - 1)) || a.Cin > 256 || a.mtiles < 1 || a.mtiles > 2 || a.Win > 32 * (4 / a.mtiles)) return false;
     const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win;
     if ((long)TH * (a.Win + 2) * (a.Cin / 4) > 256L * CP_PF) return false;       // k_convt_p's register prefetch of a strip's new rows
-    return convt_l_lds(a) <= CONVT_L_MAX_LDS;
+    return convt_l_lds(a) <= 64 * 1024;
 }
 
 void launch_conv_g(const ConvGArgs& a, hipStream_t st) {
@@ -571,7 +587,7 @@ void launch_conv_g(const ConvGArgs& a, hipStream_t st) {
         } else {
             if (a.mode == 1) hipLaunchKernelGGL((k_convt_p<1, false>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
             else if (a.dbg & 16) hipLaunchKernelGGL((k_convt_p<2, false>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
-            else hipLaunchKernelGGL((k_convt_p<2, true>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
+            else hipLaunchKernelGGL((k_convt_p<2, true>), dim3((unsigned)a.n_img), dim3(256), (a.dbg & 32) ? CONVT_L_MAX_LDS : (a.dbg & 64) ? (size_t)70 * 1024 : convt_l_lds(a), st, a);     // dbg 32 / 64: occupancy experiments (1 / 2 workgroups per CU by LDS)
         }
         return;
     }
