@@ -811,3 +811,31 @@ def test_cached_simulation_replica_follows_the_weights(models, weights_cache):
     for e in range(8):
         assert out[e][0] == out2[e][0] and out[e][3] == out2[e][3] and out[e][4] == out2[e][4]
     assert torch.equal(dist, dist2)
+
+
+def test_contexts_release_their_device_memory(weights_cache):
+    """efe_destroy (model deletion) returns the context's packed weights and scratch arena: creating, using and dropping
+    contexts in a loop must not grow the device memory in use"""
+    import gc
+    import daimc_amd
+    w = weights_cache(1234, 1.15)
+    s = PX.uniform_fill(2, (8, 10), 5, -1, 1)
+    pi = np.eye(4, dtype=np.float32)[np.arange(8) % 4]
+
+    def once():
+        m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=1, init_weights=False)
+        m.load_flat_weights(w)
+        g = m.calculate_G(s, pi, samples=2, stage=0)[0]
+        torch.cuda.synchronize()
+        del m
+        gc.collect()
+        return g
+
+    once()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        once()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, f'{(free0 - free1) >> 20} MiB of device memory not returned after 6 create/destroy cycles'
