@@ -414,6 +414,7 @@ __global__ void __launch_bounds__(256, SPLIT ? 3 : 2) k_convt_p(const ConvGArgs 
                     constexpr int vlast[2][4] = {{1, 2, 0, 0}, {1, 2, 4, 5}};      // last MFMA group that reads view v
                     // (pass 0 keeps two fragment sets, AD = 2 blocks ahead: its three groups are only 768 cycles; pass 1 refills one set, AD = 1)
                     constexpr int AD = P == 0 ? 2 : 1;
+                    const bool no_a = a.dbg & 128, no_b = a.dbg & 256;      // timing experiments (wrong results): operands not refreshed
                     auto step = [&](float4 (&av)[NMP], float4 (&bv)[NVP], int kc) {
 #pragma unroll
                         for (int m = 0; m < NMP; ++m) {
@@ -423,13 +424,13 @@ __global__ void __launch_bounds__(256, SPLIT ? 3 : 2) k_convt_p(const ConvGArgs 
                             c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, av[m].y, c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, av[m].z, c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, av[m].w, c, 0, 0, 0);
-                            if (kc + AD < KC) {
+                            if (kc + AD < KC && !no_a) {
                                 const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + kc + AD) * 64) * 16u, 0);
                                 av[m] = __builtin_bit_cast(float4, v);
                             }
 #pragma unroll
                             for (int v = 0; v < NVP; ++v)
-                                if (vlast[P][v] == m && kc + 1 < KC) bv[v] = cl_x[vb[v] + 2 * (kc + 1)];      // view v is free: block kc + 1 in place
+                                if (vlast[P][v] == m && kc + 1 < KC && !no_b) bv[v] = cl_x[vb[v] + 2 * (kc + 1)];      // view v is free: block kc + 1 in place
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     };
