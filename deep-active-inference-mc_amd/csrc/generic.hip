@@ -388,19 +388,20 @@ __global__ void __launch_bounds__(256, SPLIT ? 3 : 2) k_convt_p(const ConvGArgs 
                 pix += pstep; advance(lr, lx);
             }
         };
-        if constexpr (SPLIT && MODE == 2) {
-            // Two passes over the strip, one per output-row parity (3 taps -> parities (0,0) (0,1); 6 taps -> (1,0) (1,1)): 32 accumulator
-            // registers live instead of 64, so three waves per SIMD fit (the strip's LDS already allowed three workgroups per CU).
+        if constexpr (SPLIT) {
+            // Stride 2: two passes over the strip, one per output-row parity (3 taps -> parities (0,0) (0,1); 6 taps -> (1,0) (1,1)): 32
+            // accumulator registers live instead of 64, so three waves per SIMD fit (the strip's LDS already allowed three workgroups per
+            // CU).  Stride 1: one pass of nine taps in the same operand-refill form (table row 2).
             if (busy) {
                 auto run_pass = [&](auto PC) {
-                    constexpr int P = decltype(PC)::value;
-                    constexpr int NMP = P == 0 ? 3 : 6, NVP = P == 0 ? 2 : 4;
-                    constexpr int pvw[2][6] = {{0, 0, 1, 0, 0, 0}, {0, 0, 1, 2, 2, 3}};
-                    constexpr int ptp[2][6] = {{4, 5, 3, 0, 0, 0}, {7, 8, 6, 1, 2, 0}};
-                    constexpr int pac[2][6] = {{0, 1, 1, 0, 0, 0}, {0, 1, 1, 0, 1, 1}};
-                    f32x16 ac[2];
+                    constexpr int P = decltype(PC)::value;      // table row: 0 / 1 = the two passes of the stride-2 layers, 2 = the stride-1 layer
+                    constexpr int NMP = P == 0 ? 3 : P == 1 ? 6 : 9, NVP = P == 0 ? 2 : P == 1 ? 4 : 9, NAC = P == 2 ? 1 : 2;
+                    constexpr int pvw[3][9] = {{0, 0, 1, 0, 0, 0, 0, 0, 0}, {0, 0, 1, 2, 2, 3, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};
+                    constexpr int ptp[3][9] = {{4, 5, 3, 0, 0, 0, 0, 0, 0}, {7, 8, 6, 1, 2, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};
+                    constexpr int pac[3][9] = {{0, 1, 1, 0, 0, 0, 0, 0, 0}, {0, 1, 1, 0, 1, 1, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+                    f32x16 ac[NAC];
 #pragma unroll
-                    for (int p = 0; p < 2; ++p)
+                    for (int p = 0; p < NAC; ++p)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) ac[p][e] = bias;
                     auto load_a = [&](float4 (&av)[NMP], int kc) {
@@ -414,7 +415,7 @@ __global__ void __launch_bounds__(256, SPLIT ? 3 : 2) k_convt_p(const ConvGArgs 
                     // fragment is re-requested for block kc + 2 right behind the MFMAs that consumed it, every view for block kc + 1
                     // behind its last reader, so each wait leaves the newer requests in flight (a bulk request per step made hipcc
                     // wait for all of them in the middle of the step)
-                    constexpr int vlast[2][4] = {{1, 2, 0, 0}, {1, 2, 4, 5}};      // last MFMA group that reads view v
+                    constexpr int vlast[3][9] = {{1, 2, 0, 0, 0, 0, 0, 0, 0}, {1, 2, 4, 5, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};      // last MFMA group that reads view v
                     // (pass 0 keeps two fragment sets, AD = 2 blocks ahead: its three groups are only 768 cycles; pass 1 refills one set, AD = 1)
                     constexpr int AD = P == 0 ? 2 : 1;
                     const bool no_a = a.dbg & 128, no_b = a.dbg & 256;      // timing experiments (wrong results): operands not refreshed
@@ -449,7 +450,7 @@ __global__ void __launch_bounds__(256, SPLIT ? 3 : 2) k_convt_p(const ConvGArgs 
 #pragma unroll
                     for (int v = 0; v < NVP; ++v) bv[v] = cl_x[vb[v]];
                     for (int kc = 0; kc < KC; kc += 2) {
-                        if (P == 1 && kc + 2 >= KC && more) request_next();     // behind the strip's last fragment request
+                        if (P >= 1 && kc + 2 >= KC && more) request_next();     // behind the strip's last fragment request
                         __builtin_amdgcn_sched_barrier(0);
                         step(a0, bv, kc);
                         if constexpr (AD == 2) step(a1, bv, kc + 1); else step(a0, bv, kc + 1);
@@ -464,17 +465,21 @@ __global__ void __launch_bounds__(256, SPLIT ? 3 : 2) k_convt_p(const ConvGArgs 
                             for (int i = 0; i < 4; ++i) {
                                 const unsigned o = offs[i] + sbase;
 #pragma unroll
-                                for (int pw = 0; pw < 2; ++pw) {
+                                for (int pw = 0; pw < NAC; ++pw) {
                                     float v = ac[pw][4 * g4 + i];
                                     if (a.relu) v = fmaxf(v, 0.0f);
-                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, o, (unsigned)((P * a.Wout + pw) * a.ldo) * 4u, 0);
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, o, P == 2 ? 0u : (unsigned)((P * a.Wout + pw) * a.ldo) * 4u, 0);
                                 }
                             }
                         }
                     }
                 };
-                run_pass(std::integral_constant<int, 0>{});
-                run_pass(std::integral_constant<int, 1>{});
+                if constexpr (MODE == 2) {
+                    run_pass(std::integral_constant<int, 0>{});
+                    run_pass(std::integral_constant<int, 1>{});
+                } else {
+                    run_pass(std::integral_constant<int, 2>{});
+                }
             } else if (more) {
                 request_next();
             }
@@ -589,7 +594,8 @@ void launch_conv_g(const ConvGArgs& a, hipStream_t st) {
             if (a.mode == 1) hipLaunchKernelGGL(k_convt_l<1>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
             else hipLaunchKernelGGL(k_convt_l<2>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
         } else {
-            if (a.mode == 1) hipLaunchKernelGGL((k_convt_p<1, false>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
+            if (a.mode == 1 && (a.dbg & (16 | 512))) hipLaunchKernelGGL((k_convt_p<1, false>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
+            else if (a.mode == 1) hipLaunchKernelGGL((k_convt_p<1, true>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
             else if (a.dbg & 16) hipLaunchKernelGGL((k_convt_p<2, false>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
             else hipLaunchKernelGGL((k_convt_p<2, true>), dim3((unsigned)a.n_img), dim3(256), (a.dbg & 32) ? CONVT_L_MAX_LDS : (a.dbg & 64) ? (size_t)70 * 1024 : convt_l_lds(a), st, a);     // dbg 32 / 64: occupancy experiments (1 / 2 workgroups per CU by LDS)
         }
@@ -763,6 +769,7 @@ int init_generic_kernels() {
     if (hipFuncSetAttribute((const void*)k_convt_l<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_convt_p<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_convt_p<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_p<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_convt_p<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
     return 0;
 }
