@@ -234,3 +234,22 @@ def test_row_mask_generic_geometry(pair):
     rows = alive.bool().repeat_interleave(A)
     assert torch.equal(out[0][rows], ref[0][rows]) and torch.equal(out[2][rows], ref[2][rows]) and torch.equal(out[4][rows], ref[4][rows])
     assert torch.equal(m.calculate_G(s0, pi0, samples=2, stage=6)[0], ref[0])
+
+
+def test_generic_chunking_invariance(pair):
+    """launch groups of the generic decoder / encoder (options dec_chunk_g, enc_chunk) do not change a bit of the result"""
+    m, _ = pair
+    M = 7
+    s0 = PX.uniform_fill(4, (M, 10), 170, -1.0, 1.0)
+    pi0 = np.eye(A, dtype=np.float32)[np.arange(M) % A]
+    ref = m.calculate_G(s0, pi0, samples=3, stage=8)
+    try:
+        m.set_option('dec_chunk_g', 5)
+        m.set_option('enc_chunk', 4)
+        out = m.calculate_G(s0, pi0, samples=3, stage=8)
+    finally:
+        m.set_option('dec_chunk_g', 16384)
+        m.set_option('enc_chunk', 32768)
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[4], ref[4])
+    for k in range(3):
+        assert torch.equal(out[1][k], ref[1][k])
