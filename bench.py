@@ -319,6 +319,33 @@ def bench_generic(a, device, world, rank, dist, steps, warmup, with_cpu):
            'gflop_per_rollout': 2 * macs_row / 1e9, 'achieved_tflops_total': tf,
            'roofline': {'bound': 'mfma', 'kernel': 'whole step (generic layer-by-layer convolution path)', 'achieved': tf / world,
                         'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s', 'frac': tf / world / PEAK_FP32_MFMA_TF, 'traffic': None}}
+    if not a.no_prof:
+        # per-class HIP-event times of ONE step each (events around every launch inflate a step, so one class per pass)
+        Bq = R // 4
+        imgs = D * 3 * S * rows                                     # decoder images per step
+        macs = {'dec_dense_16384': 256 * 64 * Bq * Bq, 'convT1_generic': Bq * Bq * 9 * 64 * 64, 'dec_a_convT1_convT2': Bq * Bq * 9 * 64 * 64,
+                'dec_b_convT3_final_reduce': 4 * Bq * Bq * 9 * 64 * 32, 'final_layer_generic': R * R * 9 * 32 * C}
+        names = {'dec_dense_16384': 'k_fc4 (Linear 256 -> 64 base^2)', 'convT1_generic': 'k_convt_p<1> (ConvT 64->64 s1)',
+                 'dec_a_convT1_convT2': 'k_convt_p<2> (ConvT 64->64 s2)', 'dec_b_convT3_final_reduce': 'k_convt_p<2> (ConvT 64->32 s2)',
+                 'final_layer_generic': 'k_final_g (ConvT 32->C + sigmoid + reductions)', 'encoder': 'encoder (k_conv_g x4 + dense head)',
+                 'transition_mlp': 'k_trans_fused', 'dec_dense_small': 'decoder head (3 x k_dense)'}
+        kern, kk = {}, warmup + 100
+        for cname in names:
+            model.prof_enable(True, classes=[cname])
+            step(kk); kk += 1
+            ms, n = model.prof_read()[cname]
+            e = {'kernel': names[cname], 'ms': round(ms, 3), 'launches': int(n)}
+            if cname in macs and ms > 0:
+                e['tflops'] = round(2 * macs[cname] * imgs / (ms * 1e-3) / 1e12, 2)
+                e['frac_of_fp32_mfma_peak'] = round(e['tflops'] / PEAK_FP32_MFMA_TF, 4)
+            kern[cname] = e
+        model.prof_enable(False)
+        out['kernels_one_step'] = kern
+        dom = kern['dec_b_convT3_final_reduce']
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'k_convt_p<2, true>: ConvTranspose2d(64, 32, s2) of the generic path (largest class of the step)',
+                           'achieved': dom.get('tflops', 0.0), 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s',
+                           'frac': dom.get('frac_of_fp32_mfma_peak', 0.0), 'traffic': None, 'launches': dom['launches'],
+                           'avg_launch_ms': dom['ms'] / max(dom['launches'], 1), 'whole_step_frac': tf / world / PEAK_FP32_MFMA_TF}
     if with_cpu:
         out['cpu_baseline'] = cpu_baseline_generic(A, C, R, D, S)
         out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
@@ -422,7 +449,7 @@ def main():
         # per-class breakdown from extra, un-timed steps, ONE class at a time: event pairs around every launch of a step slow
         # all of its kernels down by ~10 % (the sum no longer matched ms_per_step)
         for c in model.PROF_CLASSES:
-            if c.startswith('unused'):
+            if c.endswith('_generic'):            # classes of the generic-geometry path only
                 continue
             model.prof_enable(True, classes=[c])
             for _ in range(NB):

@@ -288,11 +288,13 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
         cur_m0 = m0;
         ctx->cls = PROF_DEC_FC4;
         fc(ctx, ctx->g_fc4, hA + (size_t)m0 * 256, 256, 0, x4, B * B * 64, c, true, true, TAG_DEC + 3, nc, m0, st);
-        ctx->cls = PROF_CT2;
+        ctx->cls = PROF_CT1;
         conv(ctx->g_ct[0], x4, y1, c, B, 64, B, 64, 1);
+        ctx->cls = PROF_CT2;
         conv(ctx->g_ct[1], y1, y2, c, B, 64, H2, 64, 2);
         ctx->cls = PROF_CT3;
         conv(ctx->g_ct[2], y2, y3, c, H2, 64, H3, 32, ctx->last_s1 ? 1 : 2);
+        ctx->cls = PROF_FINAL;
         FinalGArgs f{};
         f.y3 = y3; f.w = ctx->g_wf; for (int i = 0; i < 4; ++i) f.b[i] = ctx->g_bf[i];
         f.rows = c; f.m0 = m0; f.rows_per_group = nc.rows_per_group; f.H = H3; f.W = H3; f.C = ctx->chan; f.gm = nc.gm;

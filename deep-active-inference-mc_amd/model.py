@@ -567,8 +567,9 @@ class ActiveInferenceModel:
         e = self._ready()
         return e.ops.action_posterior(e.h, e.tensor(sum_G).reshape(-1), int(single_values), float(temperature))
 
-    PROF_CLASSES = ('transition_mlp', 'dec_dense_small', 'dec_dense_16384', 'unused3', 'dec_a_convT1_convT2',
-                    'dec_b_convT3_final_reduce', 'unused6', 'encoder', 'other')
+    # (generic geometry: the decoder's layers are separate launches -- convT1_generic, dec_a_... = ConvT2, dec_b_... = ConvT3, final_layer_generic)
+    PROF_CLASSES = ('transition_mlp', 'dec_dense_small', 'dec_dense_16384', 'convT1_generic', 'dec_a_convT1_convT2',
+                    'dec_b_convT3_final_reduce', 'final_layer_generic', 'encoder', 'other')
 
     def prof_enable(self, on=True, classes=None):
         """time kernel classes with HIP events on the launch stream; `classes` = iterable of PROF_CLASSES names
