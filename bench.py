@@ -3,17 +3,22 @@
 
 A "step" = one pass of the hot path over one batch of synthetic input: `calculate_G_repeated` over R rows (R/4 root frames
 x 4 actions) with 10 MC samples and depth 5, followed by the action posterior.
-  * N = 1: R = 128 (BASELINE configs[1], the configuration the metric is quoted on).
-  * N > 1: every rank runs 64 episodes = 256 rows (BASELINE configs[3]: 512 episodes over 8 GPUs); episodes shard with no
-    data-path collective (weak scaling) and ONE all_gather of the [64, 4] action posteriors per step is the only RCCL traffic.
+  * every N: R = 128 rows PER GPU (BASELINE configs[1], the configuration the metric is quoted on; 32 episodes x 4 actions),
+    so the N = 1 point of a scaling curve is the BENCH line and every point runs the same per-GPU workload (weak scaling).
+    Episodes shard with no data-path collective; at N > 1 ONE all_gather of the [32, 4] action posteriors per step is the
+    only RCCL traffic (its own time is reported as `all_gather_ms`).
 Inputs are resident in HBM before the timed region.  The timed region is exactly K steps between barrier + synchronize
-pairs; it is REPEATED (same K) until about 2.5 s of GPU time have been measured, and `ms_per_step` / `value` come from the
-median region (all region times are in the JSON), so the run is long enough to be observed from outside.
+pairs, with NO profiling inside it; it is REPEATED (same K) until about 10 s of GPU time have been measured, and
+`ms_per_step` / `value` come from the median region (all region times are in the JSON), so the run is long enough to be
+observed from outside.  Per-kernel HIP-event times (the `roofline` entry included) come from extra, un-timed steps after it.
 
-At N = 1 the same JSON line carries, under "extras", the second BASELINE configuration (configs[2]: full lock-step MCTS,
-64 episodes x 50 expansions x 10 samples, simulation depth 5) with its own roofline and CPU baseline.
+The same JSON line carries, under "extras", the other BASELINE configurations: configs[2] (full lock-step MCTS, 64 episodes
+per GPU x 50 expansions x 10 samples, simulation depth 5; at N > 1 this is configs[3]: the root visit distributions of
+64 x N episodes are all-gathered) and configs[4] (3 x 84 x 84, 30 samples, depth 7, 32 episodes per GPU), each with its own
+roofline and -- at N = 1 -- CPU baseline.
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N --steps 20 --warmup 5          (N > 1 without WORLD_SIZE in the environment: bench.py launches its own
+                                                           N ranks, one per GPU, through torch.distributed.run on 127.0.0.1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -135,10 +140,10 @@ def mcts_flops_per_decision(samples, repeats=50, depth=5):
     return 2.0 * ((repeats + 1) * 4 * g_row + repeats * sim)
 
 
-def cpu_baseline_mcts(samples, depth=5, repeats_sample=12):
+def cpu_baseline_mcts(samples, depth=5, repeats_sample=12, reps=3):
     """BASELINE configs[2] on the CPU as the reference would run it: ONE episode at a time through the oracle planner
-    (oracle/mcts_oracle.py), torch RNG.  Bounded sample: `repeats_sample` planner iterations (+ the root expansion) instead
-    of 50; decisions/s is extrapolated by algorithmic FLOPs (every iteration costs the same)."""
+    (oracle/mcts_oracle.py), torch RNG.  Bounded sample: `reps` timed passes (median) of `repeats_sample` planner iterations
+    (+ the root expansion) instead of 50; decisions/s is extrapolated by algorithmic FLOPs (every iteration costs the same)."""
     from oracle import synth
     from oracle import mcts_oracle as MO
     from oracle.efe_oracle import OracleModel, TorchNoise
@@ -146,16 +151,21 @@ def cpu_baseline_mcts(samples, depth=5, repeats_sample=12):
     torch.set_num_threads(cores)
     m = OracleModel(synth.make_weights(1234, 1.15), TorchNoise())
     p = MO.Params(repeats=repeats_sample, simulation_depth=depth, use_means=False, threshold=2.0, samples=samples)
-    frame = torch.from_numpy(synth.make_frames(6, 1)[0])
-    MO.plan(m, frame, MO.Params(repeats=1, simulation_depth=2, use_means=False, threshold=2.0, samples=1), 0)     # warm-up
-    t = time.perf_counter()
-    MO.plan(m, frame, p, 0)
-    dt = time.perf_counter() - t
+    frames = synth.make_frames(6, reps)
+    MO.plan(m, torch.from_numpy(frames[0]), MO.Params(repeats=1, simulation_depth=2, use_means=False, threshold=2.0, samples=1), 0)     # warm-up
+    times = []
+    for r in range(reps):
+        t = time.perf_counter()
+        MO.plan(m, torch.from_numpy(frames[r]), p, 0)
+        times.append(time.perf_counter() - t)
+    dt = statistics.median(times)
     frac = mcts_flops_per_decision(samples, repeats_sample, depth) / mcts_flops_per_decision(samples, 50, depth)
-    return {'value': frac / dt, 'unit': 'decisions/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
-            'sample': f'one episode, {repeats_sample} of 50 planner iterations (+ root expansion), {samples} MC samples, simulation depth {depth}: '
-                      f'{dt:.1f} s, extrapolated to a full decision by algorithmic FLOPs (x{1 / frac:.1f}); sequential single-episode '
-                      f'oracle planner (oracle/mcts_oracle.py over oracle/efe_oracle.py), torch RNG like the reference'}
+    return {'value': frac / dt, 'unit': 'decisions/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(), 'repeats': reps,
+            'min': frac / max(times), 'max': frac / min(times),
+            'sample': f'{reps} timed passes (median {dt:.1f} s; {sum(times):.1f} s in all) of one episode each, {repeats_sample} of 50 planner '
+                      f'iterations (+ root expansion), {samples} MC samples, simulation depth {depth}, extrapolated to a full decision by '
+                      f'algorithmic FLOPs (x{1 / frac:.1f}); sequential single-episode oracle planner (oracle/mcts_oracle.py over '
+                      f'oracle/efe_oracle.py), torch RNG like the reference'}
 
 
 def natural_key(path):
@@ -176,7 +186,7 @@ def committed_traffic(kernel='k_dec_b'):
     return None, None
 
 
-def timed_regions(step, steps, k0, sync, min_total_s=2.5, max_regions=40):
+def timed_regions(step, steps, k0, sync, min_total_s=10.0, max_regions=60):
     """time EXACTLY `steps` steps between sync() pairs; repeat the region until min_total_s of measured time.
     -> (list of region seconds (max over ranks is taken by the caller), next step index)"""
     out, k = [], k0
@@ -191,55 +201,117 @@ def timed_regions(step, steps, k0, sync, min_total_s=2.5, max_regions=40):
             return out, k
 
 
-def bench_mcts(a, model, device, world, rank, dist, steps, warmup, with_cpu):
+class Ranks:
+    """the process group of this run (None at one rank without --force-dist): barrier, max-over-ranks of the region times,
+    per-rank figures, and the one data-path collective (all_gather of the action posteriors)"""
+
+    def __init__(self, dist, world, rank, device, backend):
+        self.dist, self.world, self.rank, self.device, self.backend = dist, world, rank, device, backend
+        self.on = dist is not None
+        self.red_dev = device if backend == 'nccl' else torch.device('cpu')     # gloo (the --share-device launcher test): host tensors
+
+    def sync(self):
+        torch.cuda.synchronize()
+        if self.on:
+            self.dist.barrier()
+
+    def max_over_ranks(self, xs):
+        if not self.on:
+            return [float(x) for x in xs]
+        t = torch.tensor(xs, device=self.red_dev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
+    def per_rank(self, x):
+        if not self.on:
+            return [float(x)]
+        out = torch.zeros(self.world, device=self.red_dev, dtype=torch.float64)
+        self.dist.all_gather_into_tensor(out, torch.tensor([x], device=self.red_dev, dtype=torch.float64))
+        return [float(v) for v in out]
+
+    def gather(self, P, n_total):
+        import daimc_amd
+        if not self.on:
+            return P
+        return daimc_amd.gather_action_posteriors(P if self.backend == 'nccl' else P.cpu(), n_total)
+
+    def time_gather(self, P, n_total, iters=50):
+        """host-observed milliseconds per all_gather of the action posteriors, back to back (max over ranks)"""
+        if not self.on:
+            return None
+        for _ in range(5):
+            self.gather(P, n_total)
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            self.gather(P, n_total)
+        torch.cuda.synchronize()
+        return self.max_over_ranks([1e3 * (time.perf_counter() - t0) / iters])[0]
+
+    def info(self):
+        if not self.on:
+            return {}
+        return {'rccl_ranks': int(self.dist.get_world_size()), 'backend': str(self.dist.get_backend())}
+
+
+def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min_total_s=2.5):
     """BASELINE configs[2]/[3]: E episodes per GPU, each a full MCTS decision (50 expansions with S MC samples,
-    simulation depth 5, use_means=False, early stop disabled so every episode does all 50), planned in lock-step; the root
-    visit distributions are gathered across ranks."""
+    simulation depth 5, use_means=False), planned in lock-step; the root visit distributions are gathered across ranks
+    (N > 1: configs[3]).  threshold = 2.0 disables the early stop (every episode does all 50 expansions: the FLOP count of the
+    roofline entry is exact); threshold = 0.5 is the reference's default (mcts.py:139) and times the device-side row mask."""
     import daimc_amd
-    E = a.episodes
+    E, world, rank = a.episodes, rk.world, rk.rank
     p = daimc_amd.MCTS_Params()
-    p.repeats, p.simulation_depth, p.use_means, p.threshold, p.samples = 50, 5, False, 2.0, a.samples
+    p.repeats, p.simulation_depth, p.use_means, p.threshold, p.samples = 50, 5, False, threshold, a.samples
     frames = synth_frames(E, device, seed=200 + rank)
+    last = {}
 
     def step(_k):
         out, distn = daimc_amd.active_inference_mcts_batch(model, frames, p, o_shape=(1, 64, 64), episode_offset=rank * E)
-        if world > 1:
-            daimc_amd.gather_action_posteriors(distn.to(device), world * E)
+        last['out'], last['P'] = out, distn.to(device)
+        rk.gather(last['P'], world * E)
         return out
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
     for k in range(warmup):
         step(k)
-    model.prof_enable(True, classes=[DOM])
-    regions, _ = timed_regions(step, steps, 0, sync, min_total_s=1.5, max_regions=6)
-    ms_dom, n_dom = model.prof_read()[DOM]
-    model.prof_enable(False)
-    if world > 1:
-        t = torch.tensor(regions, device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        regions = [float(x) for x in t]
+    regions, _ = timed_regions(step, steps, 0, rk.sync, min_total_s=min_total_s, max_regions=12)
+    per_rank_ms = rk.per_rank(1e3 * statistics.median(regions) / steps)
+    regions = rk.max_over_ranks(regions)
     dt = statistics.median(regions)
     dec = world * E * steps / dt
-    fl = mcts_flops_per_decision(a.samples)
+    iters = [o[1] for o in last['out']]
     out = {'metric': 'MCTS decisions/sec (50 expansions, %d MC samples, sim depth 5)' % a.samples, 'value': dec,
            'unit': 'decisions/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * dt / steps,
            'timed_regions': len(regions), 'region_ms': [round(1e3 * x, 3) for x in regions],
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': f'lock-step MCTS, {E} episodes per GPU x 50 expansions x {a.samples} MC samples, simulation depth 5 '
-                                  f'(BASELINE configs[2])', 'episodes_per_gpu': E},
-           'gflop_per_decision': fl / 1e9, 'rollout_equivalents_per_s': dec * fl / (2 * MAC_ROLLOUT),
-           'achieved_tflops_total': dec * fl / 1e12}
-    # whole-workload roofline (the planner is many launches; its dominant kernel is the same k_dec_b) + the dominant kernel alone
-    n_img = len(regions) * steps * 51 * 3 * a.samples * 4 * E + len(regions) * steps * 50 * 3 * 5 * E     # decoder images in the timed regions
-    ach_dom = 2 * MAC_DECB_ROW * n_img / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
-    out['roofline'] = {'bound': 'mfma', 'kernel': 'whole decision (all kernels); k_dec_b alone under "dominant"',
-                       'achieved': dec * fl / 1e12 / world, 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s',
-                       'frac': dec * fl / 1e12 / world / PEAK_FP32_MFMA_TF, 'traffic': None,
-                       'dominant': {'kernel': 'k_dec_b', 'achieved': ach_dom, 'frac': ach_dom / PEAK_FP32_MFMA_TF, 'launches': int(n_dom),
-                                    'avg_launch_ms': ms_dom / max(n_dom, 1)}}
+           'config': {'workload': f'lock-step MCTS, {E} episodes per GPU x 50 expansions x {a.samples} MC samples, simulation depth 5, '
+                                  f'early-stop threshold {threshold} (BASELINE configs[{2 if world == 1 else 3}])'
+                                  + (' + all_gather of the root visit distributions' if rk.on else ''),
+                      'episodes_per_gpu': E, 'threshold': threshold},
+           'iterations_done_mean': float(np.mean(iters)), 'iterations_done_min': int(min(iters))}
+    out.update(rk.info())
+    if rk.on:
+        out['per_rank_ms_per_step'] = [round(x, 3) for x in per_rank_ms]
+        out['all_gather_ms'] = rk.time_gather(last['P'], world * E)
+    if threshold >= 0.75:        # no early stop: every decision is exactly 51 expansions + 50 simulations
+        fl = mcts_flops_per_decision(a.samples)
+        out.update({'gflop_per_decision': fl / 1e9, 'rollout_equivalents_per_s': dec * fl / (2 * MAC_ROLLOUT),
+                    'achieved_tflops_total': dec * fl / 1e12})
+        # whole-workload roofline (the planner is many launches; its dominant kernel is the same k_dec_b) + the dominant kernel
+        # alone, timed with HIP events in ONE extra, un-timed decision batch
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'whole decision (all kernels); k_dec_b alone under "dominant"',
+                           'achieved': dec * fl / 1e12 / world, 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s',
+                           'frac': dec * fl / 1e12 / world / PEAK_FP32_MFMA_TF, 'traffic': None}
+        if not a.no_prof:
+            model.prof_enable(True, classes=[DOM])
+            step(0)
+            ms_dom, n_dom = model.prof_read()[DOM]
+            model.prof_enable(False)
+            n_img = 51 * 3 * a.samples * 4 * E + 50 * 3 * 5 * E     # decoder images of one decision batch
+            ach_dom = 2 * MAC_DECB_ROW * n_img / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
+            out['roofline']['dominant'] = {'kernel': 'k_dec_b', 'achieved': ach_dom, 'frac': ach_dom / PEAK_FP32_MFMA_TF,
+                                           'launches': int(n_dom), 'avg_launch_ms': ms_dom / max(n_dom, 1),
+                                           'note': 'HIP events of this rank, one un-timed decision batch (includes the replica stream\'s launches)'}
     if with_cpu:
         out['cpu_baseline'] = cpu_baseline_mcts(a.samples)
         out['speedup_vs_cpu_baseline'] = dec / out['cpu_baseline']['value']
@@ -247,19 +319,24 @@ def bench_mcts(a, model, device, world, rank, dist, steps, warmup, with_cpu):
 
 
 def cpu_baseline_generic(A, C, R, depth, samples):
-    """configs[4] on the CPU: the build-defined oracle restatement (parity unpinned), one bounded pass; rollouts/s extrapolated
-    by (depth x samples) -- every (stage, sample) costs the same"""
+    """configs[4] on the CPU: the build-defined oracle restatement (parity unpinned), 3 bounded passes of >= 3 s each;
+    rollouts/s extrapolated by (depth x samples) -- every (stage, sample) costs the same"""
     from oracle import synth
     from oracle.efe_oracle import OracleModel, TorchNoise
     cores = usable_cores()
     torch.set_num_threads(cores)
     m = OracleModel(synth.make_weights(1234, 1.15, A, C, R), TorchNoise(), pi_dim=A, channels=C, resolution=R)
-    o = torch.from_numpy(np.repeat(synth.make_frames_rgb(5, 4, C, R), A, axis=0))
-    pi = torch.eye(A).repeat(4, 1)
-    d, sm = 2, 6
+    n_ep = 8
+    o = torch.from_numpy(np.repeat(synth.make_frames_rgb(5, n_ep, C, R), A, axis=0))
+    pi = torch.eye(A).repeat(n_ep, 1)
     times = []
     with torch.no_grad():
         m.calculate_G_repeated(o[:A], pi[:A], 1, False, 1, 0)
+        t = time.perf_counter()
+        m.calculate_G_repeated(o, pi, 1, False, 2, 0)
+        unit = (time.perf_counter() - t) / 2            # seconds per (stage, sample) of the 24-row batch
+        d = 3
+        sm = int(min(samples, max(4, round(3.2 / max(unit, 1e-3) / d))))
         for rep in range(3):
             t = time.perf_counter()
             m.calculate_G_repeated(o, pi, d, False, sm, rep)
@@ -269,44 +346,43 @@ def cpu_baseline_generic(A, C, R, depth, samples):
     frac = (d * sm) / (depth * samples)
     return {'value': rows * frac / dt, 'unit': 'rollouts/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(), 'repeats': len(times),
             'min': rows * frac / max(times), 'max': rows * frac / min(times),
-            'sample': f'3 timed passes of {rows} rows x depth {d} x {sm} MC samples (median {dt:.1f} s), extrapolated to depth {depth} x {samples} '
-                      f'samples (x{1 / frac:.1f}: every (stage, sample) costs the same); build-defined oracle restatement (oracle/efe_oracle.py, '
-                      f'channels={C}, resolution={R}), torch RNG; parity unpinned'}
+            'sample': f'3 timed passes of {rows} rows x depth {d} x {sm} MC samples (median {dt:.1f} s, {sum(times):.1f} s in all), extrapolated to '
+                      f'depth {depth} x {samples} samples (x{1 / frac:.1f}: every (stage, sample) costs the same); build-defined oracle '
+                      f'restatement (oracle/efe_oracle.py, channels={C}, resolution={R}), torch RNG; parity unpinned'}
 
 
-def bench_generic(a, device, world, rank, dist, steps, warmup, with_cpu):
+def bench_generic(a, device, rk, steps, warmup, with_cpu, min_total_s=2.0):
     """BASELINE configs[4]: Animal-AI-sized observations (3 x 84 x 84, 3 actions), 30 MC samples, depth 7, 32 episodes per GPU
     (256 over 8 GPUs).  Build-defined network, PARITY UNPINNED: no reference semantics exist for this geometry."""
     import daimc_amd
+    world, rank = rk.world, rk.rank
     A, C, R, S, D, E = 3, 3, 84, 30, 7, 32
     rows = E * A
     model = daimc_amd.ActiveInferenceModel(10, A, 0.0, 1.0, 1.0, colour_channels=C, resolution=R, device=device, seed=1, row_offset=rank * rows)
+    for kv in a.opt:
+        k_, v_ = kv.split('=')
+        model.set_option(k_, int(v_))
     g = torch.Generator().manual_seed(300 + rank)
     frames = torch.rand(E, C, R, R, generator=g).to(device)
     o = frames.repeat_interleave(A, dim=0).contiguous()
     pi = torch.eye(A, device=device).repeat(E, 1).contiguous()
     model.reserve(rows, D, S)
+    last = {}
 
     def step(k):
         G, _, _ = model.calculate_G_repeated(o, pi, steps=D, samples=S, stage=k * D)
         P, _ = model.action_posterior(G, A)
-        if world > 1:
-            daimc_amd.gather_action_posteriors(P, world * E)
+        last['P'] = P
+        rk.gather(P, world * E)
         return G
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
     for k in range(warmup):
         step(k)
-    sync()
+    rk.sync()
     macs_row = model.last_call_macs() / rows
-    regions, _ = timed_regions(step, steps, warmup, sync, min_total_s=1.0, max_regions=4)
-    if world > 1:
-        t = torch.tensor(regions, device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        regions = [float(x) for x in t]
+    regions, _ = timed_regions(step, steps, warmup, rk.sync, min_total_s=min_total_s, max_regions=12)
+    per_rank_ms = rk.per_rank(1e3 * statistics.median(regions) / steps)
+    regions = rk.max_over_ranks(regions)
     dt = statistics.median(regions)
     value = world * rows * steps / dt
     tf = value * 2 * macs_row / 1e12
@@ -315,34 +391,41 @@ def bench_generic(a, device, world, rank, dist, steps, warmup, with_cpu):
            'region_ms': [round(1e3 * x, 3) for x in regions], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
            'dtype': 'f32', 'data': 'synthetic', 'parity': 'unpinned: build-defined network, no reference semantics (SURVEY 8a-13)',
            'config': {'workload': f'calculate_G_repeated: {rows} rows ({E} episodes x {A} actions) x depth {D} x {S} MC samples per GPU, '
-                                  f'{C} x {R} x {R} observations (BASELINE configs[4]) + action posterior', 'rows_per_gpu': rows},
+                                  f'{C} x {R} x {R} observations (BASELINE configs[4]) + action posterior'
+                                  + (' + all_gather of posteriors' if rk.on else ''), 'rows_per_gpu': rows},
            'gflop_per_rollout': 2 * macs_row / 1e9, 'achieved_tflops_total': tf,
-           'roofline': {'bound': 'mfma', 'kernel': 'whole step (generic layer-by-layer convolution path)', 'achieved': tf / world,
+           'roofline': {'bound': 'mfma', 'kernel': 'whole step (generic-geometry path)', 'achieved': tf / world,
                         'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s', 'frac': tf / world / PEAK_FP32_MFMA_TF, 'traffic': None}}
+    out.update(rk.info())
+    if rk.on:
+        out['per_rank_ms_per_step'] = [round(x, 3) for x in per_rank_ms]
+        out['all_gather_ms'] = rk.time_gather(last['P'], world * E)
     if not a.no_prof:
-        # per-class HIP-event times of ONE step each (events around every launch inflate a step, so one class per pass)
+        # per-class HIP-event times of ONE un-timed step each (events around every launch inflate a step, so one class per pass)
         Bq = R // 4
         imgs = D * 3 * S * rows                                     # decoder images per step
         macs = {'dec_dense_16384': 256 * 64 * Bq * Bq, 'convT1_generic': Bq * Bq * 9 * 64 * 64, 'dec_a_convT1_convT2': Bq * Bq * 9 * 64 * 64,
                 'dec_b_convT3_final_reduce': 4 * Bq * Bq * 9 * 64 * 32, 'final_layer_generic': R * R * 9 * 32 * C}
-        names = {'dec_dense_16384': 'k_fc4 (Linear 256 -> 64 base^2)', 'convT1_generic': 'k_convt_p<1> (ConvT 64->64 s1)',
-                 'dec_a_convT1_convT2': 'k_convt_p<2> (ConvT 64->64 s2)', 'dec_b_convT3_final_reduce': 'k_convt_p<2> (ConvT 64->32 s2)',
-                 'final_layer_generic': 'k_final_g (ConvT 32->C + sigmoid + reductions)', 'encoder': 'encoder (k_conv_g x4 + dense head)',
-                 'transition_mlp': 'k_trans_fused', 'dec_dense_small': 'decoder head (3 x k_dense)'}
+        names = model.generic_class_names()
         kern, kk = {}, warmup + 100
         for cname in names:
             model.prof_enable(True, classes=[cname])
             step(kk); kk += 1
             ms, n = model.prof_read()[cname]
+            if n == 0:
+                continue
             e = {'kernel': names[cname], 'ms': round(ms, 3), 'launches': int(n)}
-            if cname in macs and ms > 0:
-                e['tflops'] = round(2 * macs[cname] * imgs / (ms * 1e-3) / 1e12, 2)
+            mc = macs.get(cname, 0)
+            if cname == 'dec_b_convT3_final_reduce' and 'final_layer_generic' not in names:
+                mc += macs['final_layer_generic']                   # fused ConvT3 + final layer: one class
+            if mc and ms > 0:
+                e['tflops'] = round(2 * mc * imgs / (ms * 1e-3) / 1e12, 2)
                 e['frac_of_fp32_mfma_peak'] = round(e['tflops'] / PEAK_FP32_MFMA_TF, 4)
             kern[cname] = e
         model.prof_enable(False)
         out['kernels_one_step'] = kern
         dom = kern['dec_b_convT3_final_reduce']
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'k_convt_p<2, true>: ConvTranspose2d(64, 32, s2) of the generic path (largest class of the step)',
+        out['roofline'] = {'bound': 'mfma', 'kernel': dom['kernel'] + ' (largest class of the step)',
                            'achieved': dom.get('tflops', 0.0), 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s',
                            'frac': dom.get('frac_of_fp32_mfma_peak', 0.0), 'traffic': None, 'launches': dom['launches'],
                            'avg_launch_ms': dom['ms'] / max(dom['launches'], 1), 'whole_step_frac': tf / world / PEAK_FP32_MFMA_TF}
@@ -352,52 +435,89 @@ def bench_generic(a, device, world, rank, dist, steps, warmup, with_cpu):
     return out
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start N ranks (one per GPU) of this script through
+    torch.distributed.run on 127.0.0.1 and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus and not a.share_device:
+        print(f'[bench] --gpus {a.gpus} but only {n_dev} HIP device(s) are visible (one rank per GPU; --share-device puts every rank '
+              f'on cuda:0 over gloo to test the launcher on a 1-GPU box)', file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('[bench] launching ' + ' '.join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--rows', type=int, default=0, help='rollout rows per GPU (default: 128 at N = 1 = BASELINE configs[1]; 256 = 64 episodes at N > 1 = configs[3])')
+    ap.add_argument('--rows', type=int, default=0, help='rollout rows per GPU (default 128 = BASELINE configs[1] on every GPU)')
     ap.add_argument('--samples', type=int, default=10)
     ap.add_argument('--depth', type=int, default=5)
     ap.add_argument('--dec-chunk', type=int, default=0)
     ap.add_argument('--opt', action='append', default=[], help='engine option name=value')
     ap.add_argument('--workload', default='rollout', choices=['rollout', 'mcts', 'animalai'],
-                    help="'mcts' = only BASELINE configs[2]: full lock-step MCTS (50 expansions, 10 samples, sim depth 5) over 64 episodes/GPU; "
+                    help="'mcts' = only BASELINE configs[2]/[3]: full lock-step MCTS (50 expansions, 10 samples, sim depth 5) over 64 episodes/GPU; "
                          "'animalai' = only BASELINE configs[4]: 3 x 84 x 84 observations, 30 samples, depth 7, 32 episodes/GPU (parity unpinned)")
     ap.add_argument('--episodes', type=int, default=64)
+    ap.add_argument('--threshold', type=float, default=2.0, help="--workload mcts: early-stop threshold (2.0 = disabled, 0.5 = the reference's default)")
     ap.add_argument('--force-dist', action='store_true', help='initialise torch.distributed (RCCL) even with one rank: exercises the N>1 code path on a 1-GPU box')
+    ap.add_argument('--share-device', action='store_true', help='N > 1 on a box with fewer GPUs: every rank uses cuda:0 and the gather runs over gloo (launcher test only)')
+    ap.add_argument('--min-seconds', type=float, default=10.0, help='measured GPU time of the headline workload (the K-step region is repeated)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-prof', action='store_true')
-    ap.add_argument('--no-extras', action='store_true', help='skip the configs[2] (MCTS) leg of the default N = 1 run')
+    ap.add_argument('--no-extras', action='store_true', help='skip the configs[2]/[3] (MCTS) and configs[4] legs')
     ap.add_argument('--single-region', action='store_true', help='time the K steps once (no repeats)')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = 0 if a.share_device else int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
+    backend = None
     use_dist = world > 1 or a.force_dist
+    if world != a.gpus:
+        sys.exit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29531')
         os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
-    device = torch.device('cuda', local)
-    torch.cuda.set_device(device)
+        backend = 'gloo' if a.share_device else 'nccl'
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)       # one device per rank; "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group('gloo')
+    rk = Ranks(dist, world, rank, device, backend)
+    solo = world == 1 and not use_dist
+    with_cpu = world == 1 and not a.no_cpu
+
+    def emit(out):
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
 
     import daimc_amd
     if a.workload == 'animalai':
-        out = bench_generic(a, device, world, rank, dist, max(1, min(a.steps, 3)), max(1, min(a.warmup, 1)), world == 1 and not a.no_cpu)
-        if rank == 0:
-            print(json.dumps(out))
-        if use_dist:
-            dist.destroy_process_group()
-        return
-    R = a.rows or (128 if world == 1 else 256)
+        return emit(bench_generic(a, device, rk, max(1, min(a.steps, 3)), max(1, min(a.warmup, 1)), with_cpu, min_total_s=a.min_seconds))
+    R = a.rows or 128
     S, D = a.samples, a.depth
     model = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device=device, seed=1, row_offset=rank * R)
     if a.dec_chunk:
@@ -406,67 +526,55 @@ def main():
         k_, v_ = kv.split('=')
         model.set_option(k_, int(v_))
     if a.workload == 'mcts':
-        out = bench_mcts(a, model, device, world, rank, dist, max(1, min(a.steps, 3)), max(1, min(a.warmup, 1)), world == 1 and not a.no_cpu)
-        if rank == 0:
-            print(json.dumps(out))
-        if use_dist:
-            dist.destroy_process_group()
-        return
+        return emit(bench_mcts(a, model, device, rk, max(1, min(a.steps, 3)), max(1, min(a.warmup, 1)), with_cpu, threshold=a.threshold,
+                               min_total_s=a.min_seconds))
     model.reserve(R, D, S)                                       # steady-state steps never hipMalloc
     frames = synth_frames(R // 4, device, seed=100 + rank)
     o = frames.repeat_interleave(4, dim=0).contiguous()          # row 4i+a = (root i, action a), util.py:56-60
     pi = torch.eye(4, device=device).repeat(R // 4, 1).contiguous()
+    last = {}
 
     def step(k):
         G, _, _ = model.calculate_G_repeated(o, pi, steps=D, samples=S, stage=k * D)
         P, _ = model.action_posterior(G)
-        if use_dist:
-            daimc_amd.gather_action_posteriors(P, world * (R // 4))      # the only RCCL traffic: [R/4, 4] floats per rank
+        last['P'] = P
+        rk.gather(P, world * (R // 4))             # the only RCCL traffic: [R/4, 4] floats per rank
         return G
-
-    def sync():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
 
     print(f'[bench] rank {rank}: model ready, warm-up', file=sys.stderr, flush=True)
     for k in range(a.warmup):
         step(k)
-    sync()
+    rk.sync()
     grows0 = model.arena_stats()['grow_count']
-    if not a.no_prof:
-        model.prof_enable(True, classes=[DOM])     # HIP events around the dominant kernel only (one launch per step)
-    regions, kk = timed_regions(step, a.steps, a.warmup, sync, min_total_s=0.0 if a.single_region else 2.5)
+    regions, kk = timed_regions(step, a.steps, a.warmup, rk.sync, min_total_s=0.0 if a.single_region else a.min_seconds)
     G = step(kk); kk += 1
     torch.cuda.synchronize()
     print(f'[bench] rank {rank}: {len(regions)} timed regions of {a.steps} steps, {sum(regions):.3f}s', file=sys.stderr, flush=True)
     assert torch.isfinite(G).all()
     assert model.arena_stats()['grow_count'] == grows0, 'the scratch arena grew inside the timed region'
-    prof = model.prof_read() if not a.no_prof else {}
+    per_rank_ms = rk.per_rank(1e3 * statistics.median(regions) / a.steps)
+    regions = rk.max_over_ranks(regions)             # per region: the slowest rank
+    dt = statistics.median(regions)
+    gather_ms = rk.time_gather(last['P'], world * (R // 4))
     breakdown = {}
-    NB = 3
     if not a.no_prof:
-        # per-class breakdown from extra, un-timed steps, ONE class at a time: event pairs around every launch of a step slow
-        # all of its kernels down by ~10 % (the sum no longer matched ms_per_step)
+        # per-class HIP-event times from extra, UN-TIMED steps, one class at a time: event pairs around every launch of a step
+        # slow all of its kernels down by ~10 % (the sum no longer matched ms_per_step).  The dominant class gets more steps.
         for c in model.PROF_CLASSES:
             if c.endswith('_generic'):            # classes of the generic-geometry path only
                 continue
+            nb = 10 if c == DOM else 3
             model.prof_enable(True, classes=[c])
-            for _ in range(NB):
+            for _ in range(nb):
                 step(kk); kk += 1
             ms, n = model.prof_read()[c]
-            breakdown[c] = (ms / NB, n // NB)
-    model.prof_enable(False)
-    if use_dist:
-        t = torch.tensor(regions, device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)          # per region: the slowest rank
-        regions = [float(x) for x in t]
-    dt = statistics.median(regions)
+            breakdown[c] = (ms / nb, n // nb, ms, n)
+        model.prof_enable(False)
 
     out = None
     if rank == 0:
         value = world * R * a.steps / dt
-        cfg = 'BASELINE configs[1]' if (world == 1 and R == 128) else ('BASELINE configs[3]: 64 episodes per GPU' if R == 256 else 'custom size')
+        cfg = 'BASELINE configs[1]' + (' on every GPU' if world > 1 else '') if R == 128 else 'custom size'
         out = {
             'metric': 'EFE rollouts/sec (64x64 dSprites, 10 MC-samples, depth 5)', 'value': value, 'unit': 'rollouts/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
@@ -479,24 +587,29 @@ def main():
             'achieved_tflops_total': value * 2 * MAC_ROLLOUT / 1e12,
             'frac_of_fp32_mfma_peak_whole_step': value * 2 * MAC_ROLLOUT / 1e12 / world / PEAK_FP32_MFMA_TF,
         }
-        if prof:
-            ms, n = prof[DOM]
-            rows_per_launch = D * 3 * S * R                      # one k_dec_b launch per step (dec_chunk >= rows)
-            launches_per_step = n / max(1, (len(regions) * a.steps + 1))
-            rows_per_launch /= max(launches_per_step, 1)
+        out.update(rk.info())
+        if use_dist:
+            out['per_rank_ms_per_step'] = [round(x, 3) for x in per_rank_ms]
+            out['all_gather_ms'] = gather_ms
+            if a.share_device:
+                out['share_device'] = True
+        if breakdown:
+            _, _, ms, n = breakdown[DOM]
+            rows_per_launch = D * 3 * S * R / max(1, n // 10)     # one k_dec_b launch per step when dec_chunk >= rows
             ach = (2 * MAC_DECB_ROW * rows_per_launch) / (ms / max(n, 1) * 1e-3) / 1e12 if ms > 0 else 0.0
             out['roofline'] = {'bound': 'mfma', 'kernel': 'k_dec_b (ConvTranspose2d 64->32 s2 + ConvTranspose2d 32->1 + sigmoid + per-image reduction, fused)',
                                'achieved': ach, 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TF,
                                'traffic': None, 'launches': int(n), 'avg_launch_ms': ms / max(n, 1),
-                               'flops_per_launch': 2 * MAC_DECB_ROW * rows_per_launch}
+                               'flops_per_launch': 2 * MAC_DECB_ROW * rows_per_launch,
+                               'timing': 'HIP events on the launch stream around the kernel, 10 un-timed steps after the timed regions'}
             bpi, src = committed_traffic('k_dec_b')
-            if bpi is not None:
-                out['roofline']['traffic'] = bpi * rows_per_launch
-                out['roofline']['traffic_source'] = src + ' (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, per image x images per launch)'
+            if bpi is not None:          # not measured in this run: PMC counters need rocprofv3 around the process
+                out['roofline']['traffic_from_profile'] = {'bytes_per_launch': bpi * rows_per_launch, 'file': 'profiles/' + src,
+                                                           'how': 'rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, per image x images per launch'}
             tot = sum(v[0] for v in breakdown.values())
             macs = class_macs_per_step(R, D, S)
             kern = {}
-            for k_, (ms_, n_) in breakdown.items():
+            for k_, (ms_, n_, _, _) in breakdown.items():
                 if n_ == 0:
                     continue
                 e = {'ms': round(ms_, 3), 'launches': int(n_), 'share': round(ms_ / tot, 4) if tot else 0}
@@ -505,19 +618,20 @@ def main():
                     e['frac_of_fp32_mfma_peak'] = round(e['tflops'] / PEAK_FP32_MFMA_TF, 4)
                 kern[k_] = e
             out['kernels_one_step'] = kern
-        if world == 1 and not a.no_cpu:
+        if with_cpu:
             out['cpu_baseline'] = cpu_baseline(D, S)
             out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
-    if world == 1 and not a.no_extras and not a.force_dist:
-        mc = bench_mcts(a, model, device, 1, 0, None, 3, 1, not a.no_cpu)
-        out['extras'] = {'mcts_cfg3': mc}
+    if not a.no_extras:
+        # every rank runs the extras (they are collective at N > 1); rank 0 attaches them
+        key = 'mcts_cfg3' if world == 1 else 'mcts_cfg4_sharded'
+        mc = bench_mcts(a, model, device, rk, 3, 1, with_cpu)
+        mc05 = bench_mcts(a, model, device, rk, 3, 1, False, threshold=0.5, min_total_s=1.0)
         del model
         torch.cuda.empty_cache()
-        out['extras']['animalai_cfg5'] = bench_generic(a, device, 1, 0, None, 2, 1, not a.no_cpu)
-    if rank == 0:
-        print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
+        ai = bench_generic(a, device, rk, 2, 1, with_cpu)
+        if rank == 0:
+            out['extras'] = {key: mc, key + '_threshold_0.5': mc05, 'animalai_cfg5': ai}
+    emit(out)
 
 
 if __name__ == '__main__':

@@ -44,6 +44,14 @@ def load_ops():
     if want != have:
         raise ImportError(f'{OPS_PATH} is stale: built from sources {have}, the sources here are {want}; re-run build()')
     torch.ops.load_library(OPS_PATH)
+    try:        # one engine copy in the process: the ops library must have resolved to the library ctypes loaded (A/B runs with EFE_LIB_PATH)
+        mapped = {line.split()[-1] for line in open('/proc/self/maps') if 'libefe_mi355x' in line or os.path.basename(LIB_PATH) in line}
+        engines = {m for m in mapped if os.path.realpath(m) != os.path.realpath(OPS_PATH)}
+    except OSError:
+        engines = set()
+    if len({os.path.realpath(m) for m in engines}) > 1:
+        raise ImportError(f'two engine libraries are mapped ({sorted(engines)}): libefe_torch_ops.so did not resolve to {LIB_PATH}; '
+                          'rebuild the override with build.py (it sets the SONAME libefe_mi355x.so)')
     _ops = torch.ops.efe
     return _ops
 
@@ -55,7 +63,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f'{LIB_PATH} not built: run `python -c "import __graft_entry__ as g; g.build()"` '
                           '(hipcc --offload-arch=gfx950); there is no CPU fallback')
-    lib = C.CDLL(LIB_PATH)
+    # RTLD_GLOBAL + the library's SONAME (build.py): when libefe_torch_ops.so is loaded later, its DT_NEEDED libefe_mi355x.so resolves
+    # to THIS copy even if EFE_LIB_PATH points somewhere else -- the context and every hot-path op then run the same build
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     lib.efe_abi_version.argtypes = []; lib.efe_abi_version.restype = C.c_int
     if lib.efe_abi_version() != ABI_VERSION:
         raise ImportError(f'{LIB_PATH}: ABI version {lib.efe_abi_version()} != {ABI_VERSION} (stale build: re-run build())')

@@ -15,7 +15,9 @@ HEADERS = ['csrc/kernels.h', 'csrc/philox.h', 'csrc/mfma_pipe.h', '../include/ef
 LIB = os.path.join(HERE, 'libefe_mi355x.so')
 OPS_SOURCES = ['csrc/torch_ops.cpp']
 OPS_LIB = os.path.join(HERE, 'libefe_torch_ops.so')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-pass-failed']
+# the SONAME lets the dynamic linker recognise an engine build loaded from another path (EFE_LIB_PATH) as THE engine library when
+# libefe_torch_ops.so asks for it: one copy in the process, never two
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-pass-failed', '-Wl,-soname,libefe_mi355x.so']
 
 
 def source_digest(files=None):
@@ -50,17 +52,58 @@ def needs_build():
     return _stamp(LIB, 'EFE_BUILD_ID') != source_digest()
 
 
+def _compile_objects(hipcc, srcs, verbose):
+    """one hipcc -c per source, in parallel, cached under build/ by a digest of (source, headers, flags): a kernel edit recompiles
+    one file (10-30 s) instead of the whole library"""
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(HERE, 'build')
+    os.makedirs(obj_dir, exist_ok=True)
+    hdr = source_digest(HEADERS)
+
+    def one(src):
+        h = hashlib.sha256(open(src, 'rb').read() + hdr.encode() + ' '.join(FLAGS).encode()).hexdigest()[:16]
+        obj = os.path.join(obj_dir, os.path.basename(src) + '.' + h + '.o')
+        if not os.path.exists(obj):
+            for old in os.listdir(obj_dir):
+                if old.startswith(os.path.basename(src) + '.'):
+                    os.unlink(os.path.join(obj_dir, old))
+            cmd = [hipcc, *[f for f in FLAGS if f != '-shared' and not f.startswith('-Wl,')], '-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError(f'hipcc failed compiling {src}')
+        return obj
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        return list(ex.map(one, srcs))
+
+
 def build(force=False, verbose=False):
     if force or needs_build():
         hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
         srcs = [os.path.join(HERE, s) for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
-        cmd = [hipcc, *FLAGS, f'-DEFE_BUILD_ID="{source_digest()}"', *srcs, '-o', LIB]
+        if force:
+            import shutil
+            shutil.rmtree(os.path.join(HERE, 'build'), ignore_errors=True)     # --force: every object from source
+        objs = _compile_objects(hipcc, srcs, verbose)
+        stamp = os.path.join(HERE, 'build', 'build_id.cpp')
+        with open(stamp, 'w') as fh:
+            fh.write('extern "C" const char* efe_build_id(void) {\n'
+                     f'    static const char stamp[] = "EFE_BUILD_ID={source_digest()}";      // the marker lets build.py read the stamp from the file without dlopen\n'
+                     '    return stamp + 13;\n}\n')
+        stamp_o = stamp[:-4] + '.o'
+        r = subprocess.run(['g++', '-O1', '-fPIC', '-c', stamp, '-o', stamp_o], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError('g++ failed compiling the build-id stamp')
+        cmd = [hipcc, *FLAGS, stamp_o, *objs, '-o', LIB]
         if verbose:
             print(' '.join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
-            raise RuntimeError('hipcc failed building libefe_mi355x.so')
+            raise RuntimeError('hipcc failed linking libefe_mi355x.so')
     build_torch_ops(force=force, verbose=verbose)
     return LIB
 

@@ -76,7 +76,10 @@ struct efe_ctx {
     size_t high_water = 0;         // largest arena use of any call so far (bytes)
     int64_t arena_grows = 0;       // number of hipMalloc calls the arena has made
     int64_t dec_chunk = 32768, enc_chunk = 32768, dbg_a = 0, dbg_b = 0, poison = -1, trace = 0, dec_chunk_g = 16384;
-    // dec_chunk_g: images per launch group of the generic decoder (1.6 MB of activations each at 84 x 84); poison / trace: development only
+    int64_t dec_budget_g = (int64_t)28 << 30;
+    // generic decoder: images per launch group = min(dec_chunk, dec_chunk_g, dec_budget_g / activation bytes per image), so the scratch
+    // block of a launch group is bounded in BYTES whatever the resolution (0.68 MB of layer activations per image at 84 x 84 on the
+    // fused path, 1.6 MB with the final layer unfused); poison / trace: development only
     int64_t arena_align = 256;
     void* tl_buf = nullptr;   // EFE_TIMELINE experiments: device buffer of 64 int64 stamps (option "tl_buf" = device pointer)
     int64_t last_macs = 0;
@@ -257,11 +260,19 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
     return 0;
 }
 
+// images per launch group of the generic decoder: bounded by the chunk options and by a byte budget for the group's layer activations
+int64_t generic_dec_chunk(const efe_ctx* ctx, int64_t N) {
+    const int64_t B = ctx->base, H2 = 2 * B, H3 = ctx->last_s1 ? 2 * B : 4 * B;
+    const int64_t per_image = (2 * B * B * 64 + H2 * H2 * 64 + H3 * H3 * 32) * (int64_t)sizeof(float);
+    const int64_t by_bytes = std::max<int64_t>(256, ctx->dec_budget_g / per_image);
+    return std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(ctx->dec_chunk, ctx->dec_chunk_g), by_bytes), N);
+}
+
 // generic geometry (generic.hip): dense head -> Linear(256, 64*B*B) -> ConvT(64,64,s1) -> ConvT(64,64,s2) -> ConvT(64,32,s2) -> final conv
 int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, int reward0, int store0, float* val, float* po_store,
                   hipStream_t st) {
     const int B = ctx->base, H2 = 2 * B, H3 = ctx->last_s1 ? 2 * B : 4 * B;
-    const int C = (int)std::min<int64_t>(std::min<int64_t>(ctx->dec_chunk, ctx->dec_chunk_g), N);
+    const int C = (int)generic_dec_chunk(ctx, N);
     float* hA = ctx->allocT<float>((size_t)N * 256);
     float* hB = ctx->allocT<float>((size_t)N * 256);
     float* x4 = ctx->allocT<float>((size_t)C * B * B * 64);
@@ -523,12 +534,20 @@ int check_ready(efe_ctx* ctx, hipStream_t st) {
     return 0;
 }
 
-int finish(efe_ctx* ctx, hipStream_t st) {
+// Every exit of an entry point that passed check_ready() -- success or failure (a bad argument, an arena hipMalloc failure, an
+// unsupported geometry after some kernels were already queued) -- records done_ev behind whatever was enqueued on `st`, so that the
+// next call, on any stream, orders its arena reuse behind it.
+struct CallGuard {
+    efe_ctx* ctx; hipStream_t st;
+    ~CallGuard() {
+        if (hipEventRecord(ctx->done_ev, st) == hipSuccess) { ctx->last_stream = st; ctx->have_last = true; }
+    }
+};
+
+int finish(efe_ctx* ctx, hipStream_t) {
     if (!ctx->pending.empty()) { ctx->err = ctx->pending; ctx->pending.clear(); return 1; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ctx->fail(std::string("kernel launch: ") + hipGetErrorString(e));
-    if (hipEventRecord(ctx->done_ev, st) != hipSuccess) return ctx->fail("hipEventRecord failed");
-    ctx->last_stream = st; ctx->have_last = true;
     return 0;
 }
 int finish(efe_ctx* ctx) {          // calls that use no engine scratch (environment, tree kernels, helpers)
@@ -548,13 +567,8 @@ extern "C" {
 
 int efe_abi_version(void) { return 2; }
 
-#ifndef EFE_BUILD_ID
-#define EFE_BUILD_ID "unstamped"
-#endif
-const char* efe_build_id(void) {
-    static const char stamp[] = "EFE_BUILD_ID=" EFE_BUILD_ID;      // the marker lets build.py read the stamp from the file without dlopen
-    return stamp + 13;
-}
+// efe_build_id(): the digest of the sources this library was compiled from -- a generated translation unit (build.py writes it at
+// link time, so an edit of one kernel file recompiles that file only)
 
 int efe_create(efe_ctx** out, int device) { return efe_create_cfg(out, device, 10, 4, 1, 64); }
 
@@ -639,6 +653,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "tl_buf")) { ctx->tl_buf = (void*)(intptr_t)value; return 0; }
     if (!strcmp(name, "dbg_a")) { ctx->dbg_a = value; return 0; }
     if (!strcmp(name, "dbg_b")) { ctx->dbg_b = value; return 0; }
+    if (!strcmp(name, "dec_budget_g")) { if (value < (1 << 20)) return ctx->fail("dec_budget_g < 1 MiB"); ctx->dec_budget_g = value; return 0; }
     if (!strcmp(name, "dec_chunk_g")) { if (value < 1) return ctx->fail("dec_chunk_g < 1"); ctx->dec_chunk_g = value; return 0; }
     if (!strcmp(name, "poison")) { ctx->poison = value; return 0; }
     if (!strcmp(name, "trace")) { ctx->trace = value; return 0; }
@@ -919,6 +934,7 @@ int efe_transition(efe_ctx* ctx, const float* pi, const float* s0, int M, const 
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
+    CallGuard guard_{ctx, st};
     if (!pi || !s0 || !nz || M < 1) return ctx->fail("efe_transition: bad arguments");
     float* x = ctx->allocT<float>((size_t)M * 16);
     float* tr = ctx->allocT<float>((size_t)M * 32);
@@ -937,6 +953,7 @@ int efe_decoder(efe_ctx* ctx, const float* s, int M, const efe_noise* nz, float*
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
+    CallGuard guard_{ctx, st};
     if (!s || !nz || !po || M < 1) return ctx->fail("efe_decoder: bad arguments");
     float* x = ctx->allocT<float>((size_t)M * 16);
     float* val = ctx->allocT<float>((size_t)M);
@@ -958,6 +975,7 @@ int efe_encoder(efe_ctx* ctx, const float* o, int M, const efe_noise* nz, const 
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
+    CallGuard guard_{ctx, st};
     if (!o || !nz || M < 1) return ctx->fail("efe_encoder: bad arguments");
     float* enc = ctx->allocT<float>((size_t)M * 32);
     if (!enc) return 1;
@@ -980,6 +998,7 @@ int efe_habit(efe_ctx* ctx, const float* s, int M, float* logits, float* q, floa
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
+    CallGuard guard_{ctx, st};
     if (!s || M < 1) return ctx->fail("efe_habit: bad arguments");
     float* x = ctx->allocT<float>((size_t)M * 16);
     float* l32 = ctx->allocT<float>((size_t)M * 32);
@@ -1018,6 +1037,7 @@ int efe_calculate_g(efe_ctx* ctx, const float* s0, const float* pi0, int M, int 
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
+    CallGuard guard_{ctx, st};
     if (!s0 || !pi0 || !nz || !G || M < 1 || samples < 1 || samples > 65535) return ctx->fail("efe_calculate_g: bad arguments");
     float* x = ctx->allocT<float>((size_t)M * 16);
     if (!x) return 1;
@@ -1037,6 +1057,7 @@ int efe_rollout(efe_ctx* ctx, const float* o, const float* pi, int M, int steps,
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
+    CallGuard guard_{ctx, st};
     if (!o || !pi || !nz || !sum_G || M < 1 || steps < 1 || samples < 1 || samples > 65535) return ctx->fail("efe_rollout: bad arguments");
     const uint32_t k0 = (uint32_t)nz->seed, k1 = (uint32_t)(nz->seed >> 32);
     float* enc0 = ctx->allocT<float>((size_t)M * 32);
@@ -1084,6 +1105,7 @@ int efe_trajectory(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, co
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
+    CallGuard guard_{ctx, st};
     if (!s0_traj || !ps1_traj || !ps1_mean_traj || !ps1_logvar_traj || !pi0_traj || !nz || !G || T < 1)
         return ctx->fail("efe_trajectory: bad arguments");
     if (trajectory_impl(ctx, s0_traj, ps1_traj, ps1_mean_traj, ps1_logvar_traj, pi0_traj, T, (uint32_t)nz->seed,
@@ -1097,6 +1119,7 @@ int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int us
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
+    CallGuard guard_{ctx, st};
     if (!starting_s || !nz || !G_mean || !pi0 || E < 1 || depth < 1 || depth > 65535) return ctx->fail("efe_simulate: bad arguments");
     const uint32_t k0 = (uint32_t)nz->seed, k1 = (uint32_t)(nz->seed >> 32);
     const int T = depth;
@@ -1182,7 +1205,7 @@ int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples) {
         enc(R);
         t += al(D * 2 * S * R * 32 * 4) + al(D * 3 * S * R * 16 * 4) + al(2 * R * 16 * 4) + al(D * 3 * S * R * 4) + al(D * S * R * IS * 4)
            + al(D * S * R * 32 * 4) + al(3 * R * 4);
-        {   const size_t N = D * 3 * S * R, C = std::min<size_t>(std::min<size_t>((size_t)dec_chunk, (size_t)ctx->dec_chunk_g), N);
+        {   const size_t N = D * 3 * S * R, C = (size_t)generic_dec_chunk(ctx, (int64_t)N);
             t += 2 * al(N * 256 * 4) + 2 * al(C * B * B * 64 * 4) + al(C * 4 * B * B * 64 * 4) + al(C * (size_t)ctx->res * ctx->res * 32 * 4); }
         enc(D * S * R);
         return (int64_t)(t + ((size_t)1 << 20));

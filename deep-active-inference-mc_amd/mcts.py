@@ -135,6 +135,24 @@ class Node:
         return trimmed
 
 
+def _frames_nchw(model, frames, n, o_shape):
+    """[n, *o_shape] frames -> NCHW [n, C, R, R] as the engine takes them.  One channel: HWC (64, 64, 1) and CHW (1, 64, 64) are the
+    same memory (the reference reshapes, mcts.py:158).  Several channels: (C, R, R) is taken as is, (R, R, C) is permuted --
+    a plain reshape would scramble the channels -- and anything else is an error."""
+    Cc, R = model.colour_channels, model.resolution
+    fr = torch.as_tensor(frames)
+    o_shape = tuple(int(v) for v in o_shape)
+    if Cc == 1:
+        if o_shape not in ((R, R, 1), (1, R, R), (R, R)):
+            raise ValueError(f'o_shape {o_shape} does not match a 1 x {R} x {R} observation')
+        return fr.reshape(n, 1, R, R)
+    if o_shape == (Cc, R, R):
+        return fr.reshape(n, Cc, R, R)
+    if o_shape == (R, R, Cc):
+        return fr.reshape(n, R, R, Cc).permute(0, 3, 1, 2).contiguous()
+    raise ValueError(f'o_shape {o_shape}: a {Cc}-channel model takes ({Cc}, {R}, {R}) (NCHW) or ({R}, {R}, {Cc}) (HWC) frames')
+
+
 def active_inference_mcts(model, frame, params, o_shape=(64, 64, 1)):
     """One planning decision (mcts.py:150-195) -> (path, repeats_done, states_explored, all_paths, all_paths_G)."""
     prev = torch.get_num_threads()
@@ -150,7 +168,7 @@ def _mcts_one(model, frame, params, o_shape):
     if frame is None or (isinstance(frame, (list, tuple)) and len(frame) == 0):
         return [0], 0, states_explored, all_paths, all_paths_G
 
-    qs0_mean, _ = model.model_down.encoder(torch.as_tensor(frame).reshape(1, *o_shape))
+    qs0_mean, _ = model.model_down.encoder(_frames_nchw(model, frame, 1, o_shape))
     root = Node(qs0_mean[0], model, params.C, model.pi_dim, using_prior_for_exploration=params.using_prior_for_exploration)
     root.Qpi = model.model_top.encode_s(qs0_mean)[1][0].to('cpu')
 
@@ -292,7 +310,7 @@ class BatchedMCTS:
         m, E, p, A, p_ = self.model, self.E, self.p, self.pi_dim, self._p
         lib = m._engine.lib
         res = [None] * E
-        qs0_mean, _ = m.model_down.encoder(torch.as_tensor(frames).reshape(E, *o_shape), row_offset=self.ep0)
+        qs0_mean, _ = m.model_down.encoder(_frames_nchw(m, frames, E, o_shape), row_offset=self.ep0)
         self.S[:, 0] = qs0_mean
         q_root = m.model_top.encode_s(qs0_mean)[1]
         self.Qpi[:, 0] = q_root
@@ -303,6 +321,8 @@ class BatchedMCTS:
                 if calc_threshold(q_cpu[e], axis=0) > p.threshold:
                     res[e] = ([int(torch.multinomial(q_cpu[e], 1))], 0, 0, [], [])
                     active_h[e] = False
+        if not bool(active_h.any()):        # every episode was decided by the habit shortcut (mcts.py:166-169): nothing to plan
+            return res
         active = active_h.to(torch.uint8).to(m.device)
         # early-stopped (and habit-decided) episodes stop costing flops: the engine's per-image kernels read `active` on the device
         # and skip their rows (efe_set_row_mask; efe_mcts_stop clears entries as the loop runs, no host round trip involved)
@@ -318,14 +338,17 @@ class BatchedMCTS:
         # threshold cannot be exceeded (max - mean of a distribution over A actions is below 1 - 1/A).
         CHECK = 8
         can_stop = float(p.threshold) < 1.0 - 1.0 / A
+        # noise stages in the reference's call order (the expansion of an iteration takes one stage, then each simulation one),
+        # reserved up front and indexed by the iteration: what a later call draws does not depend on E or on when the loop ended
+        per_it = 1 + p.simulation_repeats
+        st0 = m._take_stage(None, p.repeats * per_it)
         for repeat in range(p.repeats):
             self._call(lib.efe_mcts_stop, p_(active), p_(self.stop_at), repeat, float(p.threshold), p_(self.n_active))
             if can_stop and (repeat % CHECK == 0 or E == 1) and int(self.n_active.item()) == 0:
                 break
             self._call(lib.efe_mcts_select, p_(active), float(p.C), 1 if p.using_prior_for_exploration else 0, self.max_depth,
                        p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))
-            # noise stages in the reference's call order: the expansion takes one stage, then each simulation one
-            st_exp = m._take_stage(None, 1 + p.simulation_repeats)
+            st_exp = st0 + repeat * per_it
             if self.overlap:
                 cur = torch.cuda.current_stream(m.device)
                 self.ev_sel.record(cur)

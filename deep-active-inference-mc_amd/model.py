@@ -571,6 +571,13 @@ class ActiveInferenceModel:
     PROF_CLASSES = ('transition_mlp', 'dec_dense_small', 'dec_dense_16384', 'convT1_generic', 'dec_a_convT1_convT2',
                     'dec_b_convT3_final_reduce', 'final_layer_generic', 'encoder', 'other')
 
+    def generic_class_names(self):
+        """PROF_CLASSES name -> kernel description for the launches of the generic-geometry path (bench.py per-class table)"""
+        return {'dec_dense_16384': 'k_fc4 (Linear 256 -> 64 base^2)', 'convT1_generic': 'k_convt_p<1> (ConvT 64->64 s1)',
+                'dec_a_convT1_convT2': 'k_convt_p<2> (ConvT 64->64 s2)', 'dec_b_convT3_final_reduce': 'k_convt_p<2> (ConvT 64->32 s2)',
+                'final_layer_generic': 'k_final_g (ConvT 32->C + sigmoid + reductions)', 'encoder': 'encoder (k_conv_g x4 + dense head)',
+                'transition_mlp': 'k_trans_fused', 'dec_dense_small': 'decoder head (3 x k_dense)'}
+
     def prof_enable(self, on=True, classes=None):
         """time kernel classes with HIP events on the launch stream; `classes` = iterable of PROF_CLASSES names
         (default: all)"""

@@ -62,7 +62,8 @@ int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const 
 int efe_commit_weights(efe_ctx* ctx);
 
 /* options: "dec_chunk" (decoder rows per launch group), "enc_chunk", "dec_chunk_g" (cap of dec_chunk on the generic-geometry path:
- * 1.6 MB of layer activations per image at 84 x 84). */
+ * 1.6 MB of layer activations per image at 84 x 84), "dec_budget_g" (bytes of layer
+ * activations one launch group of the generic decoder may hold; default 28 GiB). */
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value);
 
 /* scratch arena: efe_reserve makes the arena one block of >= bytes (synchronises once); efe_rollout_scratch_bytes is what

@@ -79,6 +79,8 @@ def test_two_rank_engine_equals_single_process_and_reference(tmp_path):
     port = 29600 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     got = torch.load(tmp_path / 'gathered.pt')
+    # with two or more GPUs the gather must have gone through RCCL (one device per rank), never the gloo fallback
+    assert got['backend'] == ('nccl' if torch.cuda.device_count() >= 2 else 'gloo'), got['backend']
     g = load_golden('mcts_batch_s10')
     P1, V1, G1, out1 = _run_shard(torch.device('cuda', 0), 0, N_EP, g)
     # (a) sharded == unsharded, bit for bit (noise keyed by global rows; no cross-row arithmetic anywhere)
