@@ -317,6 +317,52 @@ def test_batched_mcts_single_episode_equals_golden(golden, models, name):
     np.testing.assert_allclose(dist.sum(1).numpy(), 1.0, rtol=1e-6)
 
 
+def _deep_params(g):
+    import daimc_amd
+    p = daimc_amd.MCTS_Params()
+    p.repeats, p.simulation_depth, p.use_means, p.threshold = int(g['repeats']), int(g['simulation_depth']), False, float(g['threshold'])
+    p.samples = int(g['samples'])
+    p.using_prior_for_exploration, p.use_habit = bool(g['using_prior_for_exploration']), bool(g['use_habit'])
+    return p
+
+
+def _check_deep(g, e, res, visits=None):
+    path, reps, explored, all_paths, all_G = res
+    n = int(g['n_paths'][e])
+    assert reps == int(g['repeats_done'][e]) and explored == int(g['states_explored'][e]) and len(all_paths) == n
+    assert all_paths == [[int(a) for a in row if a >= 0] for row in g['all_paths'][e][:n]]
+    np.testing.assert_allclose(np.array(all_G), g['all_paths_G'][e][:n], atol=gtol(np.array([2800.0])))
+    assert [int(a) for a in path] == [int(a) for a in g['final_path'][e] if a >= 0]
+    if visits is not None:
+        np.testing.assert_array_equal(visits.numpy(), g['root_N'][e] / g['root_N'][e].sum())
+
+
+@pytest.mark.parametrize('name', ['mcts_deep_s10', 'mcts_prior_s10'])
+def test_planners_at_benchmark_depth_vs_reference(golden, models, name):
+    """BASELINE configs[2] pinned at its real depth (mcts_deep_s10: 50 iterations x 10-sample expansions x depth-5 simulations, every
+    iteration run: 205-node trees, paths up to 6 actions, path trimming on long paths) and the prior-exploration bonus combined with
+    10-sample expansions and use_habit (mcts_prior_s10), both captured from the reference planner (oracle/make_golden_deep.py):
+    the single-episode API on each episode alone AND the lock-step planner on all episodes together."""
+    import daimc_amd
+    g = golden(name)
+    m = inject(_model(g, models))
+    p = _deep_params(g)
+    E = int(g['episodes'])
+    frames = torch.from_numpy(g['frames'])
+    m._stage = int(g['stage'])
+    out, visits = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
+    for e in range(E):
+        _check_deep(g, e, out[e], visits[e])
+    # episode 0 through the reference-shaped single-episode API (Node / active_inference_mcts: all its noise rows start at 0) ...
+    m._stage = int(g['stage'])
+    _check_deep(g, 0, daimc_amd.active_inference_mcts(m, frames[0], p, o_shape=(1, 64, 64)))
+    # ... and every episode planned alone by the lock-step planner at its global episode offset
+    for e in range(E):
+        m._stage = int(g['stage'])
+        out1, v1 = daimc_amd.active_inference_mcts_batch(m, frames[e:e + 1], p, o_shape=(1, 64, 64), episode_offset=e)
+        _check_deep(g, e, out1[0], v1[0])
+
+
 def test_batched_mcts_episode_invariance(models):
     """episode e planned inside a batch of 3 == planned alone with episode_offset = e (global noise keys):
     the property that lets episodes shard across GPUs with identical results"""

@@ -173,6 +173,42 @@ def test_oracle_planner_ten_samples_vs_reference(golden, weights_cache, e):
     assert np.array_equal(root_N.numpy(), g['root_N'][e])
 
 
+def _check_planner_fixture(g, e, got):
+    path, reps, explored, all_paths, all_G, root_N = got
+    n = int(g['n_paths'][e])
+    assert reps == int(g['repeats_done'][e]) and explored == int(g['states_explored'][e]) and len(all_paths) == n
+    assert all_paths == _paths(g['all_paths'][e][:n])
+    np.testing.assert_allclose(np.array(all_G), g['all_paths_G'][e][:n], atol=1e-3)
+    assert path == [int(a) for a in g['final_path'][e] if a >= 0]
+    assert np.array_equal(np.asarray(root_N), g['root_N'][e])
+
+
+def test_oracle_planner_at_benchmark_depth_vs_reference(golden, weights_cache):
+    """BASELINE configs[2] at its real depth: 50 iterations x Node.expand(samples=10) x depth-5 simulations, early stop disabled
+    (205 nodes, paths up to 6 actions) -- one of the three episodes captured from the reference planner (the GPU suite runs all three)"""
+    from oracle import mcts_oracle as MO
+    g = golden('mcts_deep_s10')
+    m = _oracle(g, weights_cache)
+    p = MO.Params(repeats=int(g['repeats']), simulation_depth=int(g['simulation_depth']), use_means=False,
+                  threshold=float(g['threshold']), samples=int(g['samples']))
+    e = 1
+    assert int(g['n_nodes'][e]) == 1 + 4 * 51 and int(g['repeats_done'][e]) == 50
+    got = MO.plan(m, torch.from_numpy(g['frames'][e]), p, int(g['stage']), episode=e)
+    _check_planner_fixture(g, e, (got[0], got[1], got[2], got[3], got[4], got[5].numpy()))
+
+
+@pytest.mark.parametrize('e', [0, 1])
+def test_oracle_planner_prior_with_ten_samples_vs_reference(golden, weights_cache, e):
+    """using_prior_for_exploration (mcts.py:44-45) together with Node.expand(samples=10) and use_habit (shortcut evaluated, not taken)"""
+    from oracle import mcts_oracle as MO
+    g = golden('mcts_prior_s10')
+    m = _oracle(g, weights_cache)
+    p = MO.Params(repeats=int(g['repeats']), simulation_depth=int(g['simulation_depth']), use_means=False, threshold=float(g['threshold']),
+                  samples=int(g['samples']), using_prior_for_exploration=True, use_habit=True)
+    got = MO.plan(m, torch.from_numpy(g['frames'][e]), p, int(g['stage']), episode=e)
+    _check_planner_fixture(g, e, (got[0], got[1], got[2], got[3], got[4], got[5].numpy()))
+
+
 def test_resolution32_networks_vs_reference(golden):
     """the reference's own Animal-AI-branch model (pi 3, 3 x 32 x 32, last_strides = 1, torchmodel.py:77-80): its networks run (its
     calculate_G does not: calc_reward_animalai is undefined), so the geometry-generic restatement is pinned at network level"""
