@@ -75,13 +75,14 @@ struct efe_ctx {
     hipEvent_t done_ev = nullptr;
     size_t high_water = 0;         // largest arena use of any call so far (bytes)
     int64_t arena_grows = 0;       // number of hipMalloc calls the arena has made
-    int64_t dec_chunk = 32768, enc_chunk = 32768, dbg_a = 0, dbg_b = 0, poison = -1, trace = 0, dec_chunk_g = 16384;
+    int64_t dec_chunk = 32768, enc_chunk = 32768, poison = -1, trace = 0, dec_chunk_g = 16384;
     int64_t dec_budget_g = (int64_t)28 << 30;
     // generic decoder: images per launch group = min(dec_chunk, dec_chunk_g, dec_budget_g / activation bytes per image), so the scratch
     // block of a launch group is bounded in BYTES whatever the resolution (0.68 MB of layer activations per image at 84 x 84 on the
     // fused path, 1.6 MB with the final layer unfused); poison / trace: development only
     int64_t arena_align = 256;
-    void* tl_buf = nullptr;   // EFE_TIMELINE experiments: device buffer of 64 int64 stamps (option "tl_buf" = device pointer)
+    int64_t reward_intent = 0;     // option "reward_upstream_intent": 1 = the reward target the upstream NHWC code means (kernels.h reward_term), 0 = the shipped port's
+    int64_t fuse_final_g = 1;      // generic path: last two decoder layers in one kernel (k_dec_bg); 0 = separate launches (A/B, parity tests of k_final_g)
     int64_t last_macs = 0;
     const uint8_t* row_mask = nullptr; int row_mask_div = 1;      // efe_set_row_mask
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
@@ -263,7 +264,8 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
 // images per launch group of the generic decoder: bounded by the chunk options and by a byte budget for the group's layer activations
 int64_t generic_dec_chunk(const efe_ctx* ctx, int64_t N) {
     const int64_t B = ctx->base, H2 = 2 * B, H3 = ctx->last_s1 ? 2 * B : 4 * B;
-    const int64_t per_image = (2 * B * B * 64 + H2 * H2 * 64 + H3 * H3 * 32) * (int64_t)sizeof(float);
+    const bool fused = ctx->fuse_final_g && !ctx->last_s1;          // y3 exists only when the final layer is its own launch
+    const int64_t per_image = (2 * B * B * 64 + H2 * H2 * 64 + (fused ? 0 : H3 * H3 * 32)) * (int64_t)sizeof(float);
     const int64_t by_bytes = std::max<int64_t>(256, ctx->dec_budget_g / per_image);
     return std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(ctx->dec_chunk, ctx->dec_chunk_g), by_bytes), N);
 }
@@ -273,13 +275,14 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
                   hipStream_t st) {
     const int B = ctx->base, H2 = 2 * B, H3 = ctx->last_s1 ? 2 * B : 4 * B;
     const int C = (int)generic_dec_chunk(ctx, N);
+    bool fused = ctx->fuse_final_g && !ctx->last_s1;
     float* hA = ctx->allocT<float>((size_t)N * 256);
     float* hB = ctx->allocT<float>((size_t)N * 256);
     float* x4 = ctx->allocT<float>((size_t)C * B * B * 64);
     float* y1 = ctx->allocT<float>((size_t)C * B * B * 64);
     float* y2 = ctx->allocT<float>((size_t)C * H2 * H2 * 64);
-    float* y3 = ctx->allocT<float>((size_t)C * H3 * H3 * 32);
-    if (!hA || !hB || !x4 || !y1 || !y2 || !y3) return 1;
+    float* y3 = fused ? nullptr : ctx->allocT<float>((size_t)C * H3 * H3 * 32);
+    if (!hA || !hB || !x4 || !y1 || !y2 || (!fused && !y3)) return 1;
     ctx->cls = PROF_DEC_FC;
     fc(ctx, ctx->dec_fc[0], dec_in, 16, 0, hA, 256, N, true, true, TAG_DEC + 0, nc, 0, st);
     fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, N, true, true, TAG_DEC + 1, nc, 0, st);
@@ -288,7 +291,7 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
     auto conv = [&](const Layer& L, const float* in, float* out, int n, int hin, int cin, int hout, int cout, int mode) {
         ConvGArgs a{};
         a.in = in; a.out = out; a.Wp = L.Wp; a.bias = L.bias; a.zeros = ctx->zeros; a.n_img = n; a.Hin = hin; a.Win = hin; a.Cin = cin;
-        a.Hout = hout; a.Wout = hout; a.Cout = cout; a.mtiles = L.mtiles; a.mode = mode; a.relu = 1; a.ldo = cout; a.dbg = (int)ctx->dbg_b;
+        a.Hout = hout; a.Wout = hout; a.Cout = cout; a.mtiles = L.mtiles; a.mode = mode; a.relu = 1; a.ldo = cout;
         a.live = live_of(nc, cur_m0);
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_conv_g(a, st);
@@ -304,12 +307,26 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
         ctx->cls = PROF_CT2;
         conv(ctx->g_ct[1], y1, y2, c, B, 64, H2, 64, 2);
         ctx->cls = PROF_CT3;
+        if (fused) {        // ConvT(64,32,s2) + ReLU + ConvT(32,C,s1) + Sigmoid + per-image sums in one kernel: y3 never exists
+            DecBGArgs f{};
+            f.y2 = y2; f.w3 = ctx->g_ct[2].Wp; f.b3 = ctx->g_ct[2].bias; f.w4 = ctx->g_wf; for (int i = 0; i < 4; ++i) f.b4[i] = ctx->g_bf[i];
+            f.rows = c; f.m0 = m0; f.rows_per_group = nc.rows_per_group; f.Hin = H2; f.Win = H2; f.C = ctx->chan; f.gm = nc.gm;
+            f.reward0 = reward0; f.store0 = store0; f.reward_intent = (int)ctx->reward_intent; f.val = val; f.po = po_store; f.live = live_of(nc, m0);
+            hipEvent_t e0 = ctx->prof_begin(st);
+            const int rc = launch_dec_bg(f, st);
+            ctx->prof_end(e0, st);
+            if (rc == 0) continue;
+            // geometry outside the fused kernel's limits: fall back to separate layers for the rest of the call
+            fused = false;
+            y3 = ctx->allocT<float>((size_t)C * H3 * H3 * 32);
+            if (!y3) return 1;
+        }
         conv(ctx->g_ct[2], y2, y3, c, H2, 64, H3, 32, ctx->last_s1 ? 1 : 2);
         ctx->cls = PROF_FINAL;
         FinalGArgs f{};
         f.y3 = y3; f.w = ctx->g_wf; for (int i = 0; i < 4; ++i) f.b[i] = ctx->g_bf[i];
         f.rows = c; f.m0 = m0; f.rows_per_group = nc.rows_per_group; f.H = H3; f.W = H3; f.C = ctx->chan; f.gm = nc.gm;
-        f.reward0 = reward0; f.store0 = store0; f.val = val; f.po = po_store; f.live = live_of(nc, m0);
+        f.reward0 = reward0; f.store0 = store0; f.reward_intent = (int)ctx->reward_intent; f.val = val; f.po = po_store; f.live = live_of(nc, m0);
         hipEvent_t e0 = ctx->prof_begin(st);
         const int frc = launch_final_g(f, st);
         ctx->prof_end(e0, st);
@@ -374,9 +391,9 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
     fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, N, true, true, TAG_DEC + 1, nc, 0, st);
     fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, N, true, true, TAG_DEC + 2, nc, 0, st);
     const int nchunks = (N + C - 1) / C;
-    int* queues = ctx->allocT<int>((size_t)2 * nchunks);    // one image-ticket counter per k_dec_a launch, then one per k_dec_b4 launch
+    int* queues = ctx->allocT<int>((size_t)nchunks);        // one image-ticket counter per k_dec_a launch
     if (!queues) return 1;
-    if (hipMemsetAsync(queues, 0, (size_t)2 * nchunks * sizeof(int), st) != hipSuccess) return ctx->fail("hipMemsetAsync failed");
+    if (hipMemsetAsync(queues, 0, (size_t)nchunks * sizeof(int), st) != hipSuccess) return ctx->fail("hipMemsetAsync failed");
     for (int m0 = 0; m0 < N; m0 += C) {
         const int c = std::min(C, N - m0);
         ctx->cls = PROF_DEC_FC4;
@@ -384,7 +401,7 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         ctx->cls = PROF_CT2;
         DecAArgs da{};
         da.x4 = x4; da.y2 = y2; da.w1 = ctx->dec_ct[0].Wp; da.b1 = ctx->dec_ct[0].bias; da.w2 = ctx->dec_ct[1].Wp;
-        da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.live = live_of(nc, m0); da.queue = queues + m0 / C; da.dbg = (int)ctx->dbg_a; da.tl = (long long*)ctx->tl_buf;
+        da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.live = live_of(nc, m0); da.queue = queues + m0 / C;
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_dec_a(da, st);
         ctx->prof_end(e0, st);
@@ -392,7 +409,7 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         DecBArgs db{};
         db.y2 = y2; db.w3 = ctx->dec_ct[2].Wp; db.b3 = ctx->dec_ct[2].bias; db.w4 = ctx->dec_wf; db.b4 = ctx->dec_bf;
         db.rows = c; db.live = live_of(nc, m0); db.m0 = m0; db.rows_per_group = nc.rows_per_group; db.gm = nc.gm; db.reward0 = reward0; db.store0 = store0;
-        db.val = val; db.po = po_store; db.dbg = (int)ctx->dbg_b; db.queue = queues + nchunks + m0 / C;
+        db.val = val; db.po = po_store; db.reward_intent = (int)ctx->reward_intent;
         e0 = ctx->prof_begin(st);
         launch_dec_b(db, st);
         ctx->prof_end(e0, st);
@@ -506,7 +523,9 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
     }
     TermsArgs ta{};
     ta.val = val; ta.tr = tr_all; ta.enc = enc; ta.D = D; ta.S = S; ta.R = R;
-    ta.reward_scale = ctx->generic ? 1.0f : 10.0f / 4096.0f;
+    // term0 of an image = its pixel sum * scale: 10 * mean over the pixels that count (torchmodel.py:212: all 4096, or the 192 bar pixels of the
+    // upstream-intent variant); the generic geometries use the sum form of the reference's resolution-32 branch (torchmodel.py:214)
+    ta.reward_scale = ctx->generic ? 1.0f : (ctx->reward_intent ? 10.0f / 192.0f : 10.0f / 4096.0f);
     ta.G = io.G; ta.terms = io.terms ? io.terms : terms_tmp; ta.t2parts = io.t2parts;
     launch_terms(ta, st);
     if (io.po1) {
@@ -650,9 +669,8 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return 1;
     EFE_LOCK(ctx);
     if (!strcmp(name, "dec_chunk")) { if (value < 1) return ctx->fail("dec_chunk < 1"); ctx->dec_chunk = value; return 0; }
-    if (!strcmp(name, "tl_buf")) { ctx->tl_buf = (void*)(intptr_t)value; return 0; }
-    if (!strcmp(name, "dbg_a")) { ctx->dbg_a = value; return 0; }
-    if (!strcmp(name, "dbg_b")) { ctx->dbg_b = value; return 0; }
+    if (!strcmp(name, "reward_upstream_intent")) { ctx->reward_intent = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "fuse_final_g")) { ctx->fuse_final_g = value ? 1 : 0; return 0; }
     if (!strcmp(name, "dec_budget_g")) { if (value < (1 << 20)) return ctx->fail("dec_budget_g < 1 MiB"); ctx->dec_budget_g = value; return 0; }
     if (!strcmp(name, "dec_chunk_g")) { if (value < 1) return ctx->fail("dec_chunk_g < 1"); ctx->dec_chunk_g = value; return 0; }
     if (!strcmp(name, "poison")) { ctx->poison = value; return 0; }
@@ -1014,8 +1032,8 @@ int efe_check_reward(efe_ctx* ctx, const float* o, int M, float* out, void* stre
     EFE_LOCK(ctx);
     if (!o || !out || M < 1) return ctx->fail("efe_check_reward: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
-    if (ctx->generic) launch_check_reward_g(o, out, M, ctx->chan, ctx->res, ctx->res, (hipStream_t)stream);
-    else launch_check_reward(o, out, M, (hipStream_t)stream);
+    if (ctx->generic) launch_check_reward_g(o, out, M, ctx->chan, ctx->res, ctx->res, (int)ctx->reward_intent, (hipStream_t)stream);
+    else launch_check_reward(o, out, M, (int)ctx->reward_intent, (hipStream_t)stream);
     return finish(ctx);
 }
 
@@ -1206,7 +1224,8 @@ int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples) {
         t += al(D * 2 * S * R * 32 * 4) + al(D * 3 * S * R * 16 * 4) + al(2 * R * 16 * 4) + al(D * 3 * S * R * 4) + al(D * S * R * IS * 4)
            + al(D * S * R * 32 * 4) + al(3 * R * 4);
         {   const size_t N = D * 3 * S * R, C = (size_t)generic_dec_chunk(ctx, (int64_t)N);
-            t += 2 * al(N * 256 * 4) + 2 * al(C * B * B * 64 * 4) + al(C * 4 * B * B * 64 * 4) + al(C * (size_t)ctx->res * ctx->res * 32 * 4); }
+            const bool fused = ctx->fuse_final_g && !ctx->last_s1;
+            t += 2 * al(N * 256 * 4) + 2 * al(C * B * B * 64 * 4) + al(C * 4 * B * B * 64 * 4) + (fused ? 0 : al(C * (size_t)ctx->res * ctx->res * 32 * 4)); }
         enc(D * S * R);
         return (int64_t)(t + ((size_t)1 << 20));
     }

@@ -8,11 +8,10 @@
 // against the CPU restatement oracle/efe_oracle.py on six geometries -- PARITY UNPINNED there; the reference's own resolution-32
 // variant is pinned at network level against a fixture captured from the reference (tests/test_generic_geometry.py).
 //
-//   k_convt_p  : the decoder's ConvTranspose2d(k3, s1, p1) / ConvTranspose2d(k3, s2, p1, op1) + ReLU: one workgroup per image walking
-//                down full-width strips held as a ring of rows in LDS; sub-pixel form for stride 2, pixels as
-//                the MFMA rows so that stores are whole NHWC lines.  k_convt_l is its one-workgroup-per-strip predecessor (dbg_b 8).
-//   k_final_g  : ConvTranspose2d(32, C, k3, s1, p1) + Sigmoid: tap contraction as a 27-row MFMA, spatial part as a gather from an LDS
-//                ring of T rows, the per-image Bernoulli-entropy / reward sums in a fixed order, and the image store
+//   (generic_dec.hip: k_convt_p, the decoder's LDS-tiled ConvTranspose2d layers, and k_dec_bg, its last two layers fused)
+//   k_final_g  : ConvTranspose2d(32, C, k3, s1, p1) + Sigmoid as its own launch (the reference's resolution-32 variant, whose third layer
+//                has stride 1, and geometries outside k_dec_bg's limits): tap contraction as a 27-row MFMA, spatial part as a gather from
+//                an LDS ring of T rows, the per-image Bernoulli-entropy / reward sums in a fixed order, and the image store
 //   k_conv_g   : the encoder's Conv2d(k3, s2, p0) + ReLU with operands straight from L2 (the round-1 style kernel; also the
 //                fallback of the ConvT layers when a strip does not fit: blockIdx.z = output parity)
 //   k_to_nhwc8 / k_to_nchw : layout changes at the API boundary (observations are NCHW, torchmodel.py:134)
@@ -121,486 +120,8 @@ __global__ void __launch_bounds__(256) k_conv_g(const ConvGArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Decoder ConvTranspose layers, LDS-tiled (modes 1 and 2 of k_conv_g; that kernel read every B operand straight from L2, i.e. each
-// input element up to nine times, and ran at 0.23 - 0.37 of the MFMA peak on BASELINE configs[4]).  One workgroup = one full-width
-// strip of TH input rows of one image (32 * NTW pixels, NTW = 4 / mtiles; TH = 32 NTW / Win): the strip and its halo are copied to
-// LDS once ([row][col][Cin + 4]: the + 4 spreads the 16-byte operand reads over the banks; cells outside the image are zero = the
-// padding), then wave (nt, mt) computes output channels [32 mt, 32 mt + 32) of pixels [32 nt, 32 nt + 32) of the strip, with the PIXELS as
-// the MFMA rows and the channels as its columns -- a lane then holds one channel of 16 pixels, and every store instruction
-// writes whole 128-byte NHWC lines (the channels-as-rows orientation scattered 16-byte pieces over 32 lines per instruction):
-//   MODE 1  ConvT(k3, s1, p1): nine shifted views of the strip, one accumulator tile
-//   MODE 2  ConvT(k3, s2, p1, op1) in sub-pixel form: four views x[ih + dy][iw + dx] feed the four output parities' accumulator
-//           tiles through 4 / 2 / 2 / 1 taps -- 9 MFMAs per 4 operand reads, no zero-insertion work
-// A fragments come from the packed weights with buffer loads (L1-resident; next channel block prefetched).
-// ---------------------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ void __launch_bounds__(256, 2) k_convt_l(const ConvGArgs a) {
-    __shared__ int cl_off[128];                      // per strip pixel: float offset of its (first-parity) output pixel inside the image, -1 = none
-    extern __shared__ float4 cl_x[];                 // [row][col][Cin / 4 + 1] float4: indexed in 16-byte units so that the operand reads are single ds_read_b128
-    constexpr int PADT = MODE == 1 ? 1 : 0;
-    constexpr int NV = MODE == 1 ? 9 : 4;          // shifted operand views
-    constexpr int NA = MODE == 1 ? 1 : 4;          // accumulator tiles
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    const int Cin = a.Cin, KC = Cin >> 3, C4 = Cin >> 2, PS4 = C4 + 1;
-    const int ntw = 4 / a.mtiles;
-    const int TH = (32 * ntw) / a.Win;
-    const int spi = (a.Hin + TH - 1) / TH;
-    const int img = blockIdx.x / spi, r0 = (blockIdx.x - img * spi) * TH;
-    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
-    const int nrow = min(TH, a.Hin - r0);
-    const int nq = nrow * a.Win;
-    const int WSL = a.Win + PADT + 1, NR = nrow + PADT + 1;
-
-    // ---- strip + halo -> LDS
-    {
-        const float* src = a.in + (size_t)img * a.Hin * a.Win * Cin;
-        // thread -> (pixel, 16-byte channel group): C4 divides 256, so a thread keeps its channel group and walks the pixels
-        const int c4 = tid % C4, pstep = 256 / C4, npix = NR * WSL;
-        int pix = tid / C4;
-        int lr = pix / WSL, lx = pix - lr * WSL;
-#pragma unroll 8
-        for (; pix < npix; pix += pstep) {
-            const int gr = r0 - PADT + lr, gx = lx - PADT;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gr >= 0 && gr < a.Hin && gx >= 0 && gx < a.Win && !(a.dbg & 4)) v = *reinterpret_cast<const float4*>(src + ((size_t)gr * a.Win + gx) * Cin + 4 * c4);
-            cl_x[pix * PS4 + c4] = v;
-            lx += pstep;
-            while (lx >= WSL) { lx -= WSL; ++lr; }
-        }
-    }
-    if (tid < 128) {
-        const int rw = tid / a.Win, xw = tid - rw * a.Win;
-        cl_off[tid] = tid < nq ? ((MODE == 2 ? 2 * (r0 + rw) : r0 + rw) * a.Wout + (MODE == 2 ? 2 * xw : xw)) * a.ldo : -1;
-    }
-    __syncthreads();
-
-    const int nt = wave % ntw, mt = wave / ntw;
-    const int q = nt * 32 + j;
-    const bool valid = q < nq;
-    const int qq = valid ? q : 0;
-    const int row = qq / a.Win, x = qq - row * a.Win;
-    if (nt * 32 >= nq) return;                         // wave-uniform: a short last strip
-
-    // view v: MODE 1 -> tap (kh, kw) = (v / 3, v % 3), source (row + 1 - kh, x + 1 - kw) = local (row + 2 - kh, x + 2 - kw)
-    //         MODE 2 -> (dy, dx) = (v >> 1, v & 1), local (row + dy, x + dx)
-    int vb[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int lr = MODE == 1 ? row + 2 - v / 3 : row + (v >> 1);
-        const int lx = MODE == 1 ? x + 2 - v % 3 : x + (v & 1);
-        vb[v] = (lr * WSL + lx) * PS4 + h;
-    }
-    // MFMA list: (view, tap, accumulator)
-    constexpr int NM = 9;
-    constexpr int mv[2][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 0, 0, 0, 1, 1, 2, 2, 3}};
-    constexpr int mtap[2][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {4, 5, 7, 8, 3, 6, 1, 2, 0}};
-    constexpr int macc[2][9] = {{0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 1, 3, 2, 3, 3}};
-    constexpr int MI = MODE - 1;
-
-    f32x16 acc[NA];
-#pragma unroll
-    for (int p = 0; p < NA; ++p)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[p][e] = 0.0f;
-
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wp), 0, 0x7fffffff, 0x00020000);
-    const unsigned wl = (unsigned)lane * 16u;
-    auto load_a = [&](float4 (&av)[NM], int kc) {
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((mtap[MI][m] * a.mtiles + mt) * KC + ((a.dbg & 1) ? 0 : kc)) * 64) * 16u, 0);
-            av[m] = __builtin_bit_cast(float4, v);
-        }
-    };
-    auto step = [&](const float4 (&av)[NM], int kc) {
-        float4 bv[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) bv[v] = cl_x[vb[v] + 2 * kc];
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            const float4 b = bv[mv[MI][m]];
-            f32x16& c = acc[macc[MI][m]];
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, av[m].x, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, av[m].y, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, av[m].z, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, av[m].w, c, 0, 0, 0);
-        }
-    };
-    float4 a0[NM], a1[NM];
-    load_a(a0, 0);
-    for (int kc = 0; kc < KC; kc += 2) {               // KC is even
-        load_a(a1, kc + 1);
-        __builtin_amdgcn_sched_barrier(0);             // keeps each prefetch a full channel block ahead of its use
-        step(a0, kc);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kc + 2 < KC) load_a(a0, kc + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        step(a1, kc + 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // epilogue: C/D layout column = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (pixel of the tile)
-    if ((a.dbg & 2) && acc[0][0] != 12345.678f) return;
-    const int co = mt * 32 + j;
-    if (co >= a.Cout) return;
-    const float bias = a.bias[co];
-    float* yimg = a.out + (size_t)img * a.Hout * a.Wout * a.ldo + co;
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-        const int4 off = *reinterpret_cast<const int4*>(cl_off + nt * 32 + 8 * g4 + 4 * h);
-        const int offs[4] = {off.x, off.y, off.z, off.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (offs[i] < 0) continue;
-#pragma unroll
-            for (int p = 0; p < NA; ++p) {
-                float v = acc[p][4 * g4 + i] + bias;
-                if (a.relu) v = fmaxf(v, 0.0f);
-                yimg[offs[i] + ((p >> 1) * a.Wout + (p & 1)) * a.ldo] = v;
-            }
-        }
-    }
-}
-// ---------------------------------------------------------------------------------------------------------
-// k_convt_p: the same strips, one workgroup per IMAGE walking down its strips.  The strip tile is a ring of TH + PADT + 1 rows in LDS
-// (slot of global row g = (g + PADT) mod ring): consecutive strips share their halo row(s) in place, only the TH new rows of the next
-// strip are fetched -- into registers, during the last two channel blocks of the current strip's contraction (after the last
-// weight-fragment request: vmcnt retires in order, a prefetch issued earlier would sit in front of every fragment wait) -- and
-// written to LDS between two barriers after the strip's stores have been issued.  k_convt_l's workgroups lived fill -> compute ->
-// store with nothing overlapped inside a workgroup and three workgroups per CU (LDS) to hide it: 0.56 / 0.70 of the MFMA rate.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int CP_PF = 10;          // float4 per thread of the next strip's new rows: TH * (Win + 2) * Cin / 4 / 256 <= 10 for Cin <= 64
-template <int MODE, bool SPLIT>
-__global__ void __launch_bounds__(256, SPLIT ? 3 : 2) k_convt_p(const ConvGArgs a) {
-    __shared__ int cl_off[128];                      // per strip pixel: float offset of its (first-parity) output pixel for r0 = 0
-    extern __shared__ float4 cl_x[];                 // [ring row][col][Cin / 4 + 1] float4
-    constexpr int PADT = MODE == 1 ? 1 : 0;
-    constexpr int NV = MODE == 1 ? 9 : 4;
-    constexpr int NA = MODE == 1 ? 1 : 4;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    const int Cin = a.Cin, KC = Cin >> 3, C4 = Cin >> 2, PS4 = C4 + 1;
-    const int ntw = 4 / a.mtiles;
-    const int TH = (32 * ntw) / a.Win;
-    const int spi = (a.Hin + TH - 1) / TH;
-    const int img = blockIdx.x;
-    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
-    const int WSL = a.Win + PADT + 1, NRT = TH + PADT + 1;
-    const float* src = a.in + (size_t)img * a.Hin * a.Win * Cin;
-    const int c4 = tid % C4, pstep = 256 / C4;
-
-    // This thread's walk over the (pixel, 16-byte channel group) elements of a block of rows: pixel += pstep per step, as a
-    // branch-free (row, column) update.  Loads are unconditional, so that the
-    // requests of a block stay in ONE basic block, back to back (with a branch per element hipcc serialised load -> wait -> LDS write).
-    const int dlr = pstep / WSL, dlx = pstep - dlr * WSL;
-    auto advance = [&](int& lr, int& lx) {
-        lr += dlr; lx += dlx;
-        const bool wrap = lx >= WSL;
-        lx = wrap ? lx - WSL : lx; lr = wrap ? lr + 1 : lr;
-    };
-    // (a buffer resource over the image: an element outside it -- halo, rows past the end, lanes past the block -- gets an
-    // out-of-range offset and the hardware returns zeros: no select, one 32-bit offset register per request)
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, a.Hin * a.Win * Cin * 4, 0x00020000);
-    auto fetch = [&](int gr, int lx, bool in_block) -> float4 {
-        const int gx = lx - PADT;
-        const bool ok = in_block && gr >= 0 && gr < a.Hin && gx >= 0 && gx < a.Win && !(a.dbg & 4);
-        const unsigned off = ok ? (unsigned)(((gr * a.Win + gx) * Cin + 4 * c4) * 4) : 0x80000000u;
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
-    };
-    // rows [g0, g0 + nr) of the image (zeros outside it) -> their ring slots
-    auto rows_to_lds = [&](int g0, int nr) {
-        const int npix = nr * WSL;
-        int pix = tid / C4;
-        int lr = pix / WSL, lx = pix - lr * WSL;
-        while (pix < npix) {
-            float4 v[8]; int dst[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                v[i] = fetch(g0 + lr, lx, pix < npix);
-                dst[i] = pix < npix ? (((g0 + lr + PADT) % NRT) * WSL + lx) * PS4 + c4 : -1;
-                pix += pstep; advance(lr, lx);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (dst[i] >= 0) cl_x[dst[i]] = v[i];
-        }
-    };
-    rows_to_lds(-PADT, NRT);                           // strip 0: rows -PADT .. TH
-    if (tid < 128) {
-        const int rw = tid / a.Win, xw = tid - rw * a.Win;
-        cl_off[tid] = rw < TH ? ((MODE == 2 ? 2 * rw : rw) * a.Wout + (MODE == 2 ? 2 * xw : xw)) * a.ldo * 4 : 0x40000000;     // bytes; the sentinel is outside every image
-    }
-    __syncthreads();
-
-    const int nt = wave % ntw, mt = wave / ntw;
-    const int q = nt * 32 + j;
-    const int qq = q < TH * a.Win ? q : 0;
-    const int row = qq / a.Win, x = qq - row * a.Win;
-    const int co = mt * 32 + j;
-    const float bias = co < a.Cout ? a.bias[co] : 0.0f;
-    // a strip pixel outside the image has a first-parity offset >= the image size: dropped whether or not the scalar parity offset is part of the check
-    const int img_floats = a.Hout * a.Wout * a.ldo;
-    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)img * img_floats, 0, img_floats * 4, 0x00020000);
-    const int strip_floats = (MODE == 2 ? 2 : 1) * TH * a.Wout * a.ldo;
-
-    constexpr int NM = 9;
-    constexpr int mv[2][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {0, 0, 0, 0, 1, 1, 2, 2, 3}};
-    constexpr int mtap[2][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {4, 5, 7, 8, 3, 6, 1, 2, 0}};
-    constexpr int macc[2][9] = {{0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 1, 3, 2, 3, 3}};
-    constexpr int MI = MODE - 1;
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wp), 0, 0x7fffffff, 0x00020000);
-    const unsigned wl = (unsigned)lane * 16u;
-
-    for (int s = 0; s < spi; ++s) {
-        const int r0 = s * TH;
-        const int nq = min(TH, a.Hin - r0) * a.Win;
-        const bool more = s + 1 < spi;
-        const bool busy = nt * 32 < nq;                // wave-uniform: a short last strip leaves waves without pixels
-        // operand views of this strip: view v = local row row + dv, column x + dx; ring slot of the tile's first row = r0 mod NRT
-        int vb[NV];
-        {
-            const int s0 = r0 % NRT;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                int lr = s0 + row + (MODE == 1 ? 2 - v / 3 : (v >> 1));
-                if (lr >= NRT) lr -= NRT;
-                const int lx = MODE == 1 ? x + 2 - v % 3 : x + (v & 1);
-                vb[v] = (lr * WSL + lx) * PS4 + h;
-            }
-        }
-        float4 pf[CP_PF];
-        // the next strip's new rows g = r0 + TH + 1 .. r0 + 2 TH: this thread's elements (same walk as rows_to_lds)
-        // the walk's start is laundered per strip: its ten (offset, validity) pairs are loop invariants that hipcc would otherwise
-        // keep in registers across the whole strip loop (256 VGPRs + spills)
-        int pix0 = tid / C4; asm volatile("" : "+v"(pix0));
-        const int lr0s = pix0 / WSL, lx0s = pix0 - lr0s * WSL;
-        auto request_next = [&]() {
-            const int npix = TH * WSL;
-            int pix = pix0;
-            int lr = lr0s, lx = lx0s;
-#pragma unroll
-            for (int i = 0; i < CP_PF; ++i) {
-                pf[i] = fetch(r0 + TH + 1 + lr, lx, pix < npix);
-                pix += pstep; advance(lr, lx);
-            }
-        };
-        if constexpr (SPLIT) {
-            // Stride 2: two passes over the strip, one per output-row parity (3 taps -> parities (0,0) (0,1); 6 taps -> (1,0) (1,1)): 32
-            // accumulator registers live instead of 64, so three waves per SIMD fit (the strip's LDS already allowed three workgroups per
-            // CU).  Stride 1: one pass of nine taps in the same operand-refill form (table row 2).
-            if (busy) {
-                auto run_pass = [&](auto PC) {
-                    constexpr int P = decltype(PC)::value;      // table row: 0 / 1 = the two passes of the stride-2 layers, 2 = the stride-1 layer
-                    constexpr int NMP = P == 0 ? 3 : P == 1 ? 6 : 9, NVP = P == 0 ? 2 : P == 1 ? 4 : 9, NAC = P == 2 ? 1 : 2;
-                    constexpr int pvw[3][9] = {{0, 0, 1, 0, 0, 0, 0, 0, 0}, {0, 0, 1, 2, 2, 3, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};
-                    constexpr int ptp[3][9] = {{4, 5, 3, 0, 0, 0, 0, 0, 0}, {7, 8, 6, 1, 2, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};
-                    constexpr int pac[3][9] = {{0, 1, 1, 0, 0, 0, 0, 0, 0}, {0, 1, 1, 0, 1, 1, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
-                    f32x16 ac[NAC];
-#pragma unroll
-                    for (int p = 0; p < NAC; ++p)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) ac[p][e] = bias;
-                    auto load_a = [&](float4 (&av)[NMP], int kc) {
-#pragma unroll
-                        for (int m = 0; m < NMP; ++m) {
-                            const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + kc) * 64) * 16u, 0);
-                            av[m] = __builtin_bit_cast(float4, v);
-                        }
-                    };
-                    // one contraction step: the strip views of block kc (requested a step earlier) against fragment set av; every
-                    // fragment is re-requested for block kc + 2 right behind the MFMAs that consumed it, every view for block kc + 1
-                    // behind its last reader, so each wait leaves the newer requests in flight (a bulk request per step made hipcc
-                    // wait for all of them in the middle of the step)
-                    constexpr int vlast[3][9] = {{1, 2, 0, 0, 0, 0, 0, 0, 0}, {1, 2, 4, 5, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};      // last MFMA group that reads view v
-                    // (pass 0 keeps two fragment sets, AD = 2 blocks ahead: its three groups are only 768 cycles; pass 1 refills one set, AD = 1)
-                    constexpr int AD = P == 0 ? 2 : 1;
-                    const bool no_a = a.dbg & 128, no_b = a.dbg & 256;      // timing experiments (wrong results): operands not refreshed
-                    auto step = [&](float4 (&av)[NMP], float4 (&bv)[NVP], int kc) {
-#pragma unroll
-                        for (int m = 0; m < NMP; ++m) {
-                            const float4 b = bv[pvw[P][m]];
-                            f32x16& c = ac[pac[P][m]];
-                            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, av[m].x, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, av[m].y, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, av[m].z, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, av[m].w, c, 0, 0, 0);
-                            if (kc + AD < KC && !no_a) {
-                                const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + kc + AD) * 64) * 16u, 0);
-                                av[m] = __builtin_bit_cast(float4, v);
-                            }
-#pragma unroll
-                            for (int v = 0; v < NVP; ++v)
-                                if (vlast[P][v] == m && kc + 1 < KC && !no_b) bv[v] = cl_x[vb[v] + 2 * (kc + 1)];      // view v is free: block kc + 1 in place
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    };
-                    float4 a0[NMP], a1[AD == 2 ? NMP : 1], bv[NVP];
-                    load_a(a0, 0);
-                    if (AD == 2) {
-#pragma unroll
-                        for (int m = 0; m < NMP; ++m) {
-                            const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + 1) * 64) * 16u, 0);
-                            a1[m % (AD == 2 ? NMP : 1)] = __builtin_bit_cast(float4, v);
-                        }
-                    }
-#pragma unroll
-                    for (int v = 0; v < NVP; ++v) bv[v] = cl_x[vb[v]];
-                    for (int kc = 0; kc < KC; kc += 2) {
-                        if (P >= 1 && kc + 2 >= KC && more) request_next();     // behind the strip's last fragment request
-                        __builtin_amdgcn_sched_barrier(0);
-                        step(a0, bv, kc);
-                        if constexpr (AD == 2) step(a1, bv, kc + 1); else step(a0, bv, kc + 1);
-                    }
-                    if (co < a.Cout && !((a.dbg & 2) && ac[0][0] != 12345.678f)) {
-                        const unsigned sbase = (unsigned)(s * strip_floats + co) * 4u;
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int4 off = *reinterpret_cast<const int4*>(cl_off + nt * 32 + 8 * g4 + 4 * h);
-                            const unsigned offs[4] = {(unsigned)off.x, (unsigned)off.y, (unsigned)off.z, (unsigned)off.w};
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const unsigned o = offs[i] + sbase;
-#pragma unroll
-                                for (int pw = 0; pw < NAC; ++pw) {
-                                    float v = ac[pw][4 * g4 + i];
-                                    if (a.relu) v = fmaxf(v, 0.0f);
-                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, o, P == 2 ? 0u : (unsigned)((P * a.Wout + pw) * a.ldo) * 4u, 0);
-                                }
-                            }
-                        }
-                    }
-                };
-                if constexpr (MODE == 2) {
-                    run_pass(std::integral_constant<int, 0>{});
-                    run_pass(std::integral_constant<int, 1>{});
-                } else {
-                    run_pass(std::integral_constant<int, 2>{});
-                }
-            } else if (more) {
-                request_next();
-            }
-        } else {
-        f32x16 acc[NA];
-        if (busy) {
-#pragma unroll
-            for (int p = 0; p < NA; ++p)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[p][e] = bias;          // a lane owns one output channel: the bias is the accumulator's start value
-            auto load_a = [&](float4 (&av)[NM], int kc) {
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((mtap[MI][m] * a.mtiles + mt) * KC + ((a.dbg & 1) ? 0 : kc)) * 64) * 16u, 0);
-                    av[m] = __builtin_bit_cast(float4, v);
-                }
-            };
-            auto load_b = [&](float4 (&bv)[NV], int kc) {
-#pragma unroll
-                for (int v = 0; v < NV; ++v) bv[v] = cl_x[vb[v] + 2 * kc];
-            };
-            auto step = [&](const float4 (&av)[NM], const float4 (&bv)[NV]) {
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const float4 b = bv[mv[MI][m]];
-                    f32x16& c = acc[macc[MI][m]];
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, av[m].x, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, av[m].y, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, av[m].z, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, av[m].w, c, 0, 0, 0);
-                }
-            };
-            // both operands one channel block ahead: fragments a0 / a1 (L1 / L2), strip views b0 / b1 (LDS)
-            float4 a0[NM], a1[NM], b0[NV], b1[NV];
-            load_a(a0, 0); load_b(b0, 0);
-            for (int kc = 0; kc < KC; kc += 2) {           // KC is even
-                load_a(a1, kc + 1); load_b(b1, kc + 1);
-                if (kc + 2 >= KC && more) request_next();  // behind the last fragment request
-                __builtin_amdgcn_sched_barrier(0);
-                step(a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kc + 2 < KC) { load_a(a0, kc + 2); load_b(b0, kc + 2); }
-                __builtin_amdgcn_sched_barrier(0);
-                step(a1, b1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // epilogue: C/D layout column = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (pixel of the tile).
-            // Stores go through a buffer resource that covers exactly this image: a strip pixel outside it (a short last strip, the
-            // table's sentinel) has an out-of-range offset and is dropped by the hardware -- no branches around 64 stores.
-            if (co < a.Cout && !((a.dbg & 2) && acc[0][0] != 12345.678f)) {
-                const unsigned sbase = (unsigned)(s * strip_floats + co) * 4u;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int4 off = *reinterpret_cast<const int4*>(cl_off + nt * 32 + 8 * g4 + 4 * h);
-                    const unsigned offs[4] = {(unsigned)off.x, (unsigned)off.y, (unsigned)off.z, (unsigned)off.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const unsigned o = offs[i] + sbase;            // byte offset of the first-parity pixel's channel co
-#pragma unroll
-                        for (int p = 0; p < NA; ++p) {
-                            float v = acc[p][4 * g4 + i];
-                            if (a.relu) v = fmaxf(v, 0.0f);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, o, (unsigned)(((p >> 1) * a.Wout + (p & 1)) * a.ldo) * 4u, 0);
-                        }
-                    }
-                }
-            }
-        } else if (more) {
-            request_next();
-        }
-        }
-        if (!more) break;
-        __syncthreads();                                   // every wave is done reading the rows that are replaced
-        {
-            const int npix = TH * WSL;
-            int pix = pix0;
-            int lr = lr0s, lx = lx0s;
-            int slot = (r0 + TH + 1 + lr + PADT) % NRT;    // ring slot of this thread's row, advanced without divisions
-#pragma unroll
-            for (int i = 0; i < CP_PF; ++i) {
-                if (pix < npix) cl_x[(slot * WSL + lx) * PS4 + c4] = pf[i];
-                pix += pstep;
-                const int lr0 = lr;
-                advance(lr, lx);
-                slot += lr - lr0;
-                while (slot >= NRT) slot -= NRT;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-static size_t convt_l_lds(const ConvGArgs& a) {
-    const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win, padt = a.mode == 1 ? 1 : 0;
-    return (size_t)(TH + padt + 1) * (a.Win + padt + 1) * (a.Cin + 4) * sizeof(float);
-}
-constexpr size_t CONVT_L_MAX_LDS = 100 * 1024;
-// the LDS-tiled kernels take the decoder's transposed layers when a full-width strip fits: Cin a power of two >= 16, one or two
-// 32-channel output tiles, Win <= 32 * (4 / mtiles)
-static bool convt_l_ok(const ConvGArgs& a) {
-    if (a.mode != 1 && a.mode != 2) return false;
-    if ((a.Cin & 15) || (a.Cin & (a.Cin - 1)) || a.Cin > 256 || a.mtiles < 1 || a.mtiles > 2 || a.Win > 32 * (4 / a.mtiles)) return false;
-    const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win;
-    if ((long)TH * (a.Win + 2) * (a.Cin / 4) > 256L * CP_PF) return false;       // k_convt_p's register prefetch of a strip's new rows
-    return convt_l_lds(a) <= 64 * 1024;
-}
-
 void launch_conv_g(const ConvGArgs& a, hipStream_t st) {
-    if (convt_l_ok(a)) {
-        const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win, spi = (a.Hin + TH - 1) / TH;
-        if (a.dbg & 8) {               // one workgroup per strip (the first LDS-tiled form; kept for A/B)
-            if (a.mode == 1) hipLaunchKernelGGL(k_convt_l<1>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
-            else hipLaunchKernelGGL(k_convt_l<2>, dim3((unsigned)(a.n_img * spi)), dim3(256), convt_l_lds(a), st, a);
-        } else {
-            if (a.mode == 1 && (a.dbg & (16 | 512))) hipLaunchKernelGGL((k_convt_p<1, false>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
-            else if (a.mode == 1) hipLaunchKernelGGL((k_convt_p<1, true>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
-            else if (a.dbg & 16) hipLaunchKernelGGL((k_convt_p<2, false>), dim3((unsigned)a.n_img), dim3(256), convt_l_lds(a), st, a);
-            else hipLaunchKernelGGL((k_convt_p<2, true>), dim3((unsigned)a.n_img), dim3(256), (a.dbg & 32) ? CONVT_L_MAX_LDS : (a.dbg & 64) ? (size_t)70 * 1024 : convt_l_lds(a), st, a);     // dbg 32 / 64: occupancy experiments (1 / 2 workgroups per CU by LDS)
-        }
-        return;
-    }
+    if (convt_p_ok(a)) { launch_convt_p(a, st); return; }       // the decoder's ConvTranspose layers: LDS-tiled (generic_dec.hip)
     const long npix = (long)a.n_img * (a.mode == 2 ? a.Hin * a.Win : a.Hout * a.Wout);
     const unsigned gz = a.mode == 2 ? 4u : 1u;
     if (a.mtiles >= 2) {
@@ -739,14 +260,12 @@ __global__ void __launch_bounds__(256, 2) k_final_g(const FinalGArgs a) {
                         acc[c] += ok ? v : 0.0f;
                     }
             }
-            const bool top = oh < H / 2;
             float p[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 p[c] = 1.0f / (1.0f + expf(-acc[c]));
                 const float p_ = p[c];
-                const float term = mode == 0 ? -(1.0f - p_) * logf(D1 - p_) - p_ * logf(D0 + p_)
-                                             : (top ? p_ * logf(D1) + (1.0f - p_) * logf(D1 - 1.0f) : p_ * logf(D0) + (1.0f - p_) * logf(D1));
+                const float term = mode == 0 ? -(1.0f - p_) * logf(D1 - p_) - p_ * logf(D0 + p_) : reward_term(p_, oh, x, H, W, a.reward_intent);
                 if (c < C) part += term;
             }
             if (po) {
@@ -765,12 +284,7 @@ __global__ void __launch_bounds__(256, 2) k_final_g(const FinalGArgs a) {
 static size_t final_g_lds(int W) { return (size_t)27 * fg_plane(W) * sizeof(float); }
 int init_generic_kernels() {
     if (hipFuncSetAttribute((const void*)k_final_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)final_g_lds(FG_MAXW)) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)k_convt_l<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)k_convt_l<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)k_convt_p<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)k_convt_p<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)k_convt_p<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)k_convt_p<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_L_MAX_LDS) != hipSuccess) return 1;
+    if (init_generic_dec_kernels()) return 1;
     return 0;
 }
 int launch_final_g(const FinalGArgs& a, hipStream_t st) {
@@ -804,7 +318,7 @@ void launch_to_nchw(const float* in, float* out, long M, int HW, int C, hipStrea
 }
 
 // check_reward on an arbitrary NCHW batch, generic geometry (same expression as k_final_g's reward branch)
-__global__ void __launch_bounds__(256) k_check_reward_g(const float* o, float* out, int C, int H, int W) {
+__global__ void __launch_bounds__(256) k_check_reward_g(const float* o, float* out, int C, int H, int W, int intent) {
     __shared__ float sred[4];
     const float* img = o + (size_t)blockIdx.x * C * H * W;
     const float D1 = 1.00001f, D0 = 0.00001f;
@@ -813,7 +327,7 @@ __global__ void __launch_bounds__(256) k_check_reward_g(const float* o, float* o
         const int oh = p / W;
         for (int c = 0; c < C; ++c) {
             const float pr = img[(size_t)c * H * W + p];
-            part += (oh < H / 2) ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f) : pr * logf(D0) + (1.0f - pr) * logf(D1);
+            part += reward_term(pr, oh, p - oh * W, H, W, intent);
         }
     }
 #pragma unroll
@@ -822,8 +336,8 @@ __global__ void __launch_bounds__(256) k_check_reward_g(const float* o, float* o
     __syncthreads();
     if (threadIdx.x == 0) out[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
-void launch_check_reward_g(const float* o, float* out, int M, int C, int H, int W, hipStream_t st) {
-    hipLaunchKernelGGL(k_check_reward_g, dim3(M), dim3(256), 0, st, o, out, C, H, W);
+void launch_check_reward_g(const float* o, float* out, int M, int C, int H, int W, int intent, hipStream_t st) {
+    hipLaunchKernelGGL(k_check_reward_g, dim3(M), dim3(256), 0, st, o, out, C, H, W, intent);
 }
 
 }  // namespace efe

@@ -1,0 +1,572 @@
+// Decoder convolution kernels of the geometry-generic path (BASELINE configs[4]: 3 x 84 x 84 observations): the
+// layers of /root/reference/src/torchmodel.py:120-127 with the layer geometry as run-time arguments, activations NHWC in HBM.
+//
+//   k_convt_p<MODE, NPF> : ConvTranspose2d(k3, s1, p1) (MODE 1) / ConvTranspose2d(k3, s2, p1, op1) (MODE 2, sub-pixel form, SURVEY
+//                          appendix A.1) + ReLU, one workgroup per image walking down full-width strips; pixels are the MFMA rows so
+//                          that every store instruction writes whole 128-byte NHWC lines
+//   k_dec_bg             : the LAST TWO layers fused, ConvTranspose2d(64, 32, s2) + ReLU -> ConvTranspose2d(32, C, s1) + Sigmoid ->
+//                          per-image Bernoulli-entropy / reward sums (+ image store): the design of k_dec_b4 (decoder.hip) with
+//                          run-time geometry.  y3 (903 KB per image at 84 x 84, 58 % of the unfused path's HBM traffic) never exists.
+//
+// The input strip of both kernels is a RING OF PIXELS in LDS: pixel P = row * Win + col of the image lives in slot
+// (P + PADT * Win) mod RPa, 64 channels + one float4 of padding per slot (17 float4: a 16-lane group of a ds_read_b128 that reads
+// 16 consecutive slots at the same channel quad then touches all 16 bank slots once).  No padding columns: consecutive pixels are
+// consecutive slots across row ends, and a lane whose tap falls outside the image reads a ZERO region of 16 slots at the slot
+// with its own residue mod 16 -- so every operand read is conflict-free whatever Win is (the [row][col + pad] tiles of the
+// first version lost 32 - 46 % of their LDS cycles to the skipped slot at every row end: profiles/r2_v6_ai, SQ_LDS_BANK_CONFLICT).
+// The ring size RPa is a multiple of 16, so the wrap keeps the residues too.  Consecutive strips share their halo rows in place:
+// only the TH new rows of the next strip are fetched (one contiguous block of global memory), into registers behind the last
+// weight-fragment request of the current strip (vmcnt retires in order), and written between two barriers.
+#include "mfma_pipe.h"
+#include <type_traits>
+
+namespace efe {
+
+typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int convt_th(int pixels_per_strip, int Win) { return pixels_per_strip / Win; }
+
+// ---------------------------------------------------------------------------------------------------------
+// k_convt_p
+// ---------------------------------------------------------------------------------------------------------
+template <int MODE, int NPF>
+__global__ void __launch_bounds__(256, 3) k_convt_p(const ConvGArgs a) {
+    __shared__ int cl_off[128];                      // per strip pixel: byte offset of its (first-parity) output pixel for r0 = 0
+    extern __shared__ float4 cl_x[];                 // [RPa ring slots + 16 zero slots][Cin / 4 + 1] float4
+    constexpr int PADT = MODE == 1 ? 1 : 0;
+    constexpr int NV = MODE == 1 ? 9 : 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int Cin = a.Cin, KC = Cin >> 3, C4 = Cin >> 2, PS4 = C4 + 1;
+    const int Win = a.Win, Hin = a.Hin;
+    const int ntw = 4 / a.mtiles;
+    const int TH = (32 * ntw) / Win;
+    const int spi = (Hin + TH - 1) / TH;
+    const int img = blockIdx.x;
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    const int SPX = TH * Win;                          // pixels of a strip
+    const int RP = (TH + PADT + 1) * Win, RPa = (RP + 15) & ~15, ZP = RPa;
+    const int npix_img = Hin * Win;
+    const float* src = a.in + (size_t)img * npix_img * Cin;
+    const int sh4 = 31 - __builtin_clz(C4);            // C4 is a power of two
+    const int c4 = tid & (C4 - 1), ppt = tid >> sh4, pstep = 256 >> sh4;
+    // a buffer resource over the image: a pixel outside it (row -1, rows past the end) gets an out-of-range offset and the hardware
+    // returns zeros
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, npix_img * Cin * 4, 0x00020000);
+    auto fetch = [&](int P, bool in_block) -> float4 {
+        const bool ok = in_block && P >= 0 && P < npix_img;
+        const unsigned off = ok ? (unsigned)((P * Cin + 4 * c4) * 4) : 0x80000000u;
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+    };
+    // strip 0: rows -PADT .. TH -> slots 0 .. RP - 1; the zero region
+    for (int pp0 = ppt; pp0 < RP; pp0 += 4 * pstep) {
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fetch(pp0 + i * pstep - PADT * Win, pp0 + i * pstep < RP);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (pp0 + i * pstep < RP) cl_x[(pp0 + i * pstep) * PS4 + c4] = v[i];
+    }
+    for (int i = tid; i < 16 * PS4; i += 256) cl_x[ZP * PS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 128) {
+        const int rw = tid / Win, xw = tid - rw * Win;
+        cl_off[tid] = rw < TH ? ((MODE == 2 ? 2 * rw : rw) * a.Wout + (MODE == 2 ? 2 * xw : xw)) * a.ldo * 4 : 0x40000000;     // bytes; the sentinel is outside every image
+    }
+    __syncthreads();
+
+    const int nt = wave % ntw, mt = wave / ntw;
+    const int q = nt * 32 + j;
+    const bool qv = q < SPX;
+    const int qq = qv ? q : 0;
+    const int row = qq / Win, x = qq - row * Win;
+    const int co = mt * 32 + j;
+    const float bias = co < a.Cout ? a.bias[co] : 0.0f;
+    // a strip pixel outside the image has a first-parity offset >= the image size: dropped whether or not the scalar parity offset is part of the check
+    const int img_floats = a.Hout * a.Wout * a.ldo;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)img * img_floats, 0, img_floats * 4, 0x00020000);
+    const int strip_floats = (MODE == 2 ? 2 : 1) * TH * a.Wout * a.ldo;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wp), 0, 0x7fffffff, 0x00020000);
+    const unsigned wl = (unsigned)lane * 16u;
+
+    int bs = PADT * Win;                               // ring slot of pixel (r0, 0)
+    for (int s = 0; s < spi; ++s) {
+        const int r0 = s * TH;
+        const int nq = min(TH, Hin - r0) * Win;
+        const bool more = s + 1 < spi;
+        const bool busy = nt * 32 < nq;                // wave-uniform: a short last strip leaves waves without pixels
+        // operand views of this strip: view v = pixel (row + dy, x + dx) of the strip; a tap outside the image's columns (or a lane
+        // without a pixel) reads the zero region at its own residue
+        int vb[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int dy = MODE == 1 ? 1 - v / 3 : (v >> 1), dx = MODE == 1 ? 1 - v % 3 : (v & 1);
+            int nat = bs + q + dy * Win + dx;
+            if (MODE == 1 && nat < 0) nat += RPa;
+            if (nat >= RPa) nat -= RPa;
+            const bool ok = qv && x + dx >= 0 && x + dx < Win;
+            vb[v] = (ok ? nat : ZP + (nat & 15)) * PS4 + h;
+        }
+        float4 pf[NPF];
+        // the next strip's new rows r0 + TH + 1 .. r0 + 2 TH are one contiguous block of SPX pixels in global memory; they take the
+        // slots of the TH oldest rows.  (the element index is laundered per strip: its offsets are loop invariants that hipcc would
+        // otherwise keep in registers across the whole strip loop)
+        int pp0 = ppt; asm volatile("" : "+v"(pp0));
+        auto request_next = [&]() {
+            const int P0 = (r0 + TH + 1) * Win;
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) pf[i] = fetch(P0 + pp0 + i * pstep, pp0 + i * pstep < SPX);
+        };
+        if (busy) {
+            // Stride 2: two passes over the strip, one per output-row parity (3 taps -> parities (0,0) (0,1); 6 taps -> (1,0) (1,1)): 32
+            // accumulator registers live instead of 64, so three waves per SIMD fit.  Stride 1: one pass of nine taps (table row 2).
+            auto run_pass = [&](auto PC) {
+                constexpr int P = decltype(PC)::value;      // table row: 0 / 1 = the two passes of the stride-2 layers, 2 = the stride-1 layer
+                constexpr int NMP = P == 0 ? 3 : P == 1 ? 6 : 9, NVP = P == 0 ? 2 : P == 1 ? 4 : 9, NAC = P == 2 ? 1 : 2;
+                constexpr int pvw[3][9] = {{0, 0, 1, 0, 0, 0, 0, 0, 0}, {0, 0, 1, 2, 2, 3, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};
+                constexpr int ptp[3][9] = {{4, 5, 3, 0, 0, 0, 0, 0, 0}, {7, 8, 6, 1, 2, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};
+                constexpr int pac[3][9] = {{0, 1, 1, 0, 0, 0, 0, 0, 0}, {0, 1, 1, 0, 1, 1, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+                f32x16 ac[NAC];
+#pragma unroll
+                for (int p = 0; p < NAC; ++p)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ac[p][e] = bias;       // a lane owns one output channel: the bias is the accumulator's start value
+                auto load_a = [&](float4 (&av)[NMP], int kc) {
+#pragma unroll
+                    for (int m = 0; m < NMP; ++m) {
+                        const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + kc) * 64) * 16u, 0);
+                        av[m] = __builtin_bit_cast(float4, v);
+                    }
+                };
+                // one contraction step: the strip views of block kc (requested a step earlier) against fragment set av; every
+                // fragment is re-requested for block kc + AD right behind the MFMAs that consumed it, every view for block kc + 1
+                // behind its last reader, so each wait leaves the newer requests in flight (a bulk request per step made hipcc
+                // wait for all of them in the middle of the step)
+                constexpr int vlast[3][9] = {{1, 2, 0, 0, 0, 0, 0, 0, 0}, {1, 2, 4, 5, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};      // last MFMA group that reads view v
+                // (pass 0 keeps two fragment sets, AD = 2 blocks ahead: its three groups are only 768 cycles; pass 1 refills one set, AD = 1)
+                constexpr int AD = P == 0 ? 2 : 1;
+                auto step = [&](float4 (&av)[NMP], float4 (&bv)[NVP], int kc) {
+#pragma unroll
+                    for (int m = 0; m < NMP; ++m) {
+                        const float4 b = bv[pvw[P][m]];
+                        f32x16& c = ac[pac[P][m]];
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, av[m].x, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, av[m].y, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, av[m].z, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, av[m].w, c, 0, 0, 0);
+                        if (kc + AD < KC) {
+                            const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + kc + AD) * 64) * 16u, 0);
+                            av[m] = __builtin_bit_cast(float4, v);
+                        }
+#pragma unroll
+                        for (int v = 0; v < NVP; ++v)
+                            if (vlast[P][v] == m && kc + 1 < KC) bv[v] = cl_x[vb[v] + 2 * (kc + 1)];      // view v is free: block kc + 1 in place
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                float4 a0[NMP], a1[AD == 2 ? NMP : 1], bv[NVP];
+                load_a(a0, 0);
+                if (AD == 2) {
+#pragma unroll
+                    for (int m = 0; m < NMP; ++m) {
+                        const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + 1) * 64) * 16u, 0);
+                        a1[m % (AD == 2 ? NMP : 1)] = __builtin_bit_cast(float4, v);
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < NVP; ++v) bv[v] = cl_x[vb[v]];
+                for (int kc = 0; kc < KC; kc += 2) {
+                    if (P >= 1 && kc + 2 >= KC && more) request_next();     // behind the strip's last fragment request
+                    __builtin_amdgcn_sched_barrier(0);
+                    step(a0, bv, kc);
+                    if constexpr (AD == 2) step(a1, bv, kc + 1); else step(a0, bv, kc + 1);
+                }
+                // epilogue: C/D layout column = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (pixel of the tile).
+                // Stores go through a buffer resource that covers exactly this image: a strip pixel outside it (a short last strip, the
+                // table's sentinel) has an out-of-range offset and is dropped by the hardware -- no branches around the stores.
+                if (co < a.Cout) {
+                    const unsigned sbase = (unsigned)(s * strip_floats + co) * 4u;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int4 off = *reinterpret_cast<const int4*>(cl_off + nt * 32 + 8 * g4 + 4 * h);
+                        const unsigned offs[4] = {(unsigned)off.x, (unsigned)off.y, (unsigned)off.z, (unsigned)off.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const unsigned o = offs[i] + sbase;
+#pragma unroll
+                            for (int pw = 0; pw < NAC; ++pw) {
+                                float v = ac[pw][4 * g4 + i];
+                                if (a.relu) v = fmaxf(v, 0.0f);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, o, P == 2 ? 0u : (unsigned)((P * a.Wout + pw) * a.ldo) * 4u, 0);
+                            }
+                        }
+                    }
+                }
+            };
+            if constexpr (MODE == 2) {
+                run_pass(std::integral_constant<int, 0>{});
+                run_pass(std::integral_constant<int, 1>{});
+            } else {
+                run_pass(std::integral_constant<int, 2>{});
+            }
+        } else if (more) {
+            request_next();
+        }
+        if (!more) break;
+        __syncthreads();                                   // every wave is done reading the rows that are replaced
+        {
+            int nb = bs + (TH + 1) * Win;                  // slot of the first new pixel = slot of the oldest row
+            if (nb >= RPa) nb -= RPa;
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) {
+                const int pp = pp0 + i * pstep;
+                int sl = nb + pp;
+                if (sl >= RPa) sl -= RPa;
+                if (pp < SPX) cl_x[sl * PS4 + c4] = pf[i];
+            }
+        }
+        bs += SPX;
+        if (bs >= RPa) bs -= RPa;
+        __syncthreads();
+    }
+}
+
+static size_t convt_p_lds(const ConvGArgs& a) {
+    const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win, padt = a.mode == 1 ? 1 : 0;
+    const int RPa = ((TH + padt + 1) * a.Win + 15) & ~15;
+    return (size_t)(RPa + 16) * (a.Cin / 4 + 1) * sizeof(float4);
+}
+static int convt_p_npf(const ConvGArgs& a) {
+    const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win;
+    return (TH * a.Win * (a.Cin / 4) + 255) / 256;
+}
+constexpr size_t CONVT_P_MAX_LDS = 64 * 1024;
+// the LDS-tiled kernel takes the decoder's transposed layers when a full-width strip fits: Cin a power of two >= 16, one or two
+// 32-channel output tiles, Win <= 32 * (4 / mtiles), the strip's new rows in <= 8 registers per thread
+bool convt_p_ok(const ConvGArgs& a) {
+    if (a.mode != 1 && a.mode != 2) return false;
+    if ((a.Cin & 15) || (a.Cin & (a.Cin - 1)) || a.Cin > 256 || a.mtiles < 1 || a.mtiles > 2 || a.Win > 32 * (4 / a.mtiles) || a.Win < 2) return false;
+    if (convt_p_npf(a) > 8) return false;
+    return convt_p_lds(a) <= CONVT_P_MAX_LDS;
+}
+void launch_convt_p(const ConvGArgs& a, hipStream_t st) {
+    const size_t lds = convt_p_lds(a);
+    const dim3 grid((unsigned)a.n_img), blk(256);
+    const bool small = convt_p_npf(a) <= 4;
+    if (a.mode == 1) {
+        if (small) hipLaunchKernelGGL((k_convt_p<1, 4>), grid, blk, lds, st, a);
+        else hipLaunchKernelGGL((k_convt_p<1, 8>), grid, blk, lds, st, a);
+    } else {
+        if (small) hipLaunchKernelGGL((k_convt_p<2, 4>), grid, blk, lds, st, a);
+        else hipLaunchKernelGGL((k_convt_p<2, 8>), grid, blk, lds, st, a);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_dec_bg: ConvTranspose2d(64, 32, k3, s2, p1, op1) + ReLU -> ConvTranspose2d(32, C, k3, s1, p1) + Sigmoid -> per-image sums,
+// /root/reference/src/torchmodel.py:124-127 with torchutils.py:26-37 and torchmodel.py:210-214,289,292 (C <= 3, any Win <= 64).
+//
+// INPUT-STATIONARY like k_dec_b4: one workgroup (4 waves) per image, strips of TH = 128 / Win input rows (+ 1 halo row, shared with
+// the next strip in place); a wave owns 32 consecutive pixels of the strip (flattened row-major, so a tile may span two rows) and
+// ALL FOUR output parities of them.  The nine taps read four shifted views of the input (pixel, right neighbour, pixel below,
+// below-right), each B fragment feeds 4 / 2 / 2 / 1 independent accumulator chains; channels are the MFMA rows, so the layer-3
+// result of a pixel sits in one lane pair and can be contracted further without leaving the registers.
+//
+// The 32 -> C conv runs on the accumulators as one more MFMA: T[m][pixel] = sum_co Wt[m][co] relu(y3[co][pixel]) with the rows
+// m = (kh, c, kw) -- 27 of the tile's 32 rows for C = 3 -- laid out so that the three kw taps of a (kh, c) group are three
+// consecutive registers of ONE lane half (groups 0..4 in lanes 0-31, groups 5..8 in lanes 32-63).  The horizontal part of the
+// 3 x 3 sum is then formed in registers (own pixel's two column parities + one wave-wide DPP shift left / right):
+//     H[kh][c][row][ox] = sum_kw T[kh, kw, c][row][ox + 1 - kw]
+// and only the 3 C H-planes of a y3 row go through LDS (a ring of 2 TH + 2 rows); the gather adds three values per output
+// element.  A tile boundary that falls inside an image row splits one horizontal sum between two waves: the boundary lanes
+// export their half to a small edge array and the gather adds it for the two output columns concerned.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
+    extern __shared__ float4 sm[];                    // [RPa ring slots + 16 zero slots][17], then H planes, then edge values
+    __shared__ float sred[4];
+    __shared__ float4 sb3[8];
+    constexpr int PS4 = 17, C4 = 16, Cin = 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int Win = a.Win, Hin = a.Hin, TH = a.TH, C = a.C, NG = 3 * C;
+    const int Wout = 2 * Win, Hout = 2 * Hin;
+    const int SPX = TH * Win, RP = (TH + 1) * Win, RPa = (RP + 15) & ~15, ZP = RPa;
+    const int RING = 2 * TH + 2;
+    float* sH = reinterpret_cast<float*>(sm + (size_t)(RPa + 16) * PS4);      // [RING][NG][Wout]
+    float* sE = sH + RING * NG * Wout;                                         // [RING][NG][2 sides][4 tiles]
+    const int img = blockIdx.x;
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+
+    const int mg = a.m0 + img;
+    const int g = mg / a.rows_per_group;
+    const int r = mg - g * a.rows_per_group;
+    int gt, gp, gs;
+    group_decode(a.gm, g, gt, gp, gs);
+    const int mode = (gp == 0 && a.reward0) ? 1 : 0;
+    const int slot = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
+    float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + r) * ((size_t)Hout * Wout * 8) : nullptr;
+
+    const int npix_img = Hin * Win;
+    const float* src = a.y2 + (size_t)img * npix_img * Cin;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, npix_img * Cin * 4, 0x00020000);
+    const int c4 = tid & 15, ppt = tid >> 4;           // this thread's channel quad and first pixel of a 16-pixel step
+    auto fetch = [&](int P, bool in_block) -> float4 {
+        const bool ok = in_block && P < npix_img;
+        const unsigned off = ok ? (unsigned)((P * Cin + 4 * c4) * 4) : 0x80000000u;
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+    };
+    for (int pp0 = ppt; pp0 < RP; pp0 += 64) {        // strip 0: rows 0 .. TH -> slots 0 .. RP - 1
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fetch(pp0 + 16 * i, pp0 + 16 * i < RP);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (pp0 + 16 * i < RP) sm[(pp0 + 16 * i) * PS4 + c4] = v[i];
+    }
+    for (int i = tid; i < 16 * PS4; i += 256) sm[ZP * PS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];
+
+    // A fragments of the tap contraction: row m of the 32 x 32 tile <-> (lane half hm, register u): hm = (m >> 2) & 1,
+    // u = (m & 3) + 4 (m >> 3) (the C/D layout: register e' of lane half h holds row (e' & 3) + 8 (e' >> 2) + 4 h); group t = u / 3,
+    // kw = u % 3, G = hm ? 5 + t : t = kh * C + c; k = channel 8 (e >> 2) + 4 (lane >> 5) + (e & 3) of MFMA e
+    float aw[16];
+    {
+        const int m = j, hm = (m >> 2) & 1, u = (m & 3) + 4 * (m >> 3);
+        const int t = u / 3, kw = u - 3 * t, G = hm ? 5 + t : t;
+        const bool mv = u < 15 && G < NG;
+        const int kh = mv ? G / C : 0, c = mv ? G - kh * C : 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ci = 8 * (e >> 2) + 4 * h + (e & 3);
+            aw[e] = mv ? a.w4[((kh * 3 + kw) * 32 + ci) * 4 + c] : 0.0f;
+        }
+    }
+    // this lane's pixel of a strip
+    const int q = w * 32 + j;
+    const bool qv = q < SPX;
+    const int lrow = (qv ? q : 0) / Win, ix = (qv ? q : 0) - lrow * Win;
+    const bool first_col = ix == 0, last_col = ix == Win - 1;
+
+    const float4* W3 = reinterpret_cast<const float4*>(a.w3);
+    const __amdgpu_buffer_rsrc_t wr = wrsrc(W3);
+    const unsigned ln = (unsigned)lane * 16u;
+    auto wf = [&](int tap, int kc) -> float4 { return wfrag(wr, ln, (size_t)(tap * 8 + kc) * 64); };
+    const float D1 = 1.00001f, D0 = 0.00001f;
+    const float bias4[3] = {a.b4[0], a.b4[1], a.b4[2]};
+    float part = 0.f;
+    const int NS = (Hin + TH - 1) / TH;
+    int bs = 0;                                        // ring slot of pixel (r0, 0)
+    int hb = 0;                                        // H-ring slot of y3 row 2 r0
+    __syncthreads();
+
+    for (int s = 0; s < NS; ++s) {
+        const int r0 = s * TH;
+        const bool more = s + 1 < NS;
+        // the four shifted views: LDS float4 index of (slot, quad h)
+        int pA, pB, pC, pD;
+        {
+            int nA = bs + q; if (nA >= RPa) nA -= RPa;
+            int nB = nA + 1; if (nB >= RPa) nB -= RPa;
+            int nC = nA + Win; if (nC >= RPa) nC -= RPa;
+            int nD = nC + 1; if (nD >= RPa) nD -= RPa;
+            pA = (qv ? nA : ZP + (nA & 15)) * PS4 + h;
+            pB = ((qv && !last_col) ? nB : ZP + (nB & 15)) * PS4 + h;
+            pC = (qv ? nC : ZP + (nC & 15)) * PS4 + h;
+            pD = ((qv && !last_col) ? nD : ZP + (nD & 15)) * PS4 + h;
+        }
+        float4 a0 = wf(4, 0), a1 = wf(5, 0), a2 = wf(7, 0), a3 = wf(8, 0);
+        f32x16 acc[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 bb = sb3[2 * g4 + h];          // register e holds channel (e & 3) + 8 (e >> 2) + 4 h: the bias is the start value
+#pragma unroll
+            for (int p_ = 0; p_ < 4; ++p_) { acc[p_][4 * g4] = bb.x; acc[p_][4 * g4 + 1] = bb.y; acc[p_][4 * g4 + 2] = bb.z; acc[p_][4 * g4 + 3] = bb.w; }
+        }
+        // ---- contraction, software-pipelined one chunk ahead: view A (4 chains: taps (1,1) (1,2) (2,1) (2,2) of parities 0..3), view B
+        // (taps (1,0) (2,0) of parities 1, 3), views C + D fused (taps (0,1) (0,2) of parities 2, 3; tap (0,0) of parity 3)
+        {
+            float4 b = sm[pA];
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const float4 c0 = a0, c1 = a1, c2 = a2, c3 = a3, cb = b;
+                if (kc < 7) {
+                    a0 = wf(4, kc + 1); a1 = wf(5, kc + 1); a2 = wf(7, kc + 1); a3 = wf(8, kc + 1);
+                    b = sm[pA + 2 * (kc + 1)];
+                } else {
+                    a0 = wf(3, 0); a1 = wf(6, 0);
+                    b = sm[pB];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                MFMA4(acc[0], c0, cb) MFMA4(acc[1], c1, cb) MFMA4(acc[2], c2, cb) MFMA4(acc[3], c3, cb)
+            }
+            float4 bd;
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const float4 c0 = a0, c1 = a1, cb = b;
+                if (kc < 7) {
+                    a0 = wf(3, kc + 1); a1 = wf(6, kc + 1);
+                    b = sm[pB + 2 * (kc + 1)];
+                } else {
+                    a0 = wf(1, 0); a1 = wf(2, 0); a2 = wf(0, 0);
+                    b = sm[pC];
+                    bd = sm[pD];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                MFMA4(acc[1], c0, cb) MFMA4(acc[3], c1, cb)
+            }
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const float4 c0 = a0, c1 = a1, c2 = a2, cb = b, cd = bd;
+                if (kc < 7) {
+                    a0 = wf(1, kc + 1); a1 = wf(2, kc + 1); a2 = wf(0, kc + 1);
+                    b = sm[pC + 2 * (kc + 1)];
+                    bd = sm[pD + 2 * (kc + 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                MFMA4(acc[3], c1, cb) MFMA4(acc[2], c0, cb) MFMA4(acc[3], c2, cd)
+            }
+        }
+        // ---- ReLU, tap contraction and horizontal pre-sum, one output-row parity ph at a time (two column parities)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            f32x16 T0, T1;                               // column parity 0 (x = 2 ix) / 1 (x = 2 ix + 1)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[2 * ph][e] = relu_bits(acc[2 * ph][e]); acc[2 * ph + 1][e] = relu_bits(acc[2 * ph + 1][e]);
+                T0[e] = 0.f; T1[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                T0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], acc[2 * ph][e], T0, 0, 0, 0);
+                T1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], acc[2 * ph + 1][e], T1, 0, 0, 0);
+            }
+            // y3 row 2 (r0 + lrow) + ph of this lane -> H-ring slot
+            int hs = hb + 2 * lrow + ph;
+            if (hs >= RING) hs -= RING;
+            float* hp = sH + (size_t)hs * NG * Wout + 2 * ix;
+            float* ep = sE + hs * NG * 8 + w;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int G = h ? 5 + t : t;
+                // out column 2 ix     takes kw = 0 from x = 2 ix + 1, kw = 1 from x = 2 ix, kw = 2 from x = 2 ix - 1 (left neighbour's odd column)
+                // out column 2 ix + 1 takes kw = 0 from x = 2 ix + 2 (right neighbour's even column), kw = 1 from x = 2 ix + 1, kw = 2 from x = 2 ix
+                float l = wave_shr1(T1[3 * t + 2]), rr = wave_shl1(T0[3 * t]);
+                l = (j == 0 || first_col) ? 0.f : l;          // tile boundary (the neighbour is another wave's lane: edge array) or image edge
+                rr = (j == 31 || last_col) ? 0.f : rr;
+                float2 eo;
+                eo.x = (T1[3 * t] + T0[3 * t + 1]) + l;
+                eo.y = (rr + T1[3 * t + 1]) + T0[3 * t + 2];
+                if (qv && G < NG) {
+                    *reinterpret_cast<float2*>(hp + G * Wout) = eo;
+                    if (j == 31) ep[G * 8] = T1[3 * t + 2];          // for output column 2 (ix + 1) of the next tile's first lane
+                    if (j == 0) ep[G * 8 + 4] = T0[3 * t];           // for output column 2 (ix - 1) + 1 of the previous tile's last lane
+                }
+            }
+        }
+        __syncthreads();
+        // ---- request the next strip's new rows (one contiguous block of SPX pixels) behind the MFMA phase
+        float4 pf[8];
+        if (more) {
+            const int P0 = (r0 + TH + 1) * Win;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pf[i] = fetch(P0 + ppt + 16 * i, ppt + 16 * i < SPX);
+        }
+        // ---- gather: output rows 2 r0 - 1 .. 2 r0 + 2 TH - 2 are complete (and the image's last row after the last strip)
+        {
+            const int first = 2 * r0 - 1;
+            const int nrows = more ? 2 * TH : 2 * TH + 1;
+            const int nout = nrows * Wout;
+            for (int f = tid; f < nout; f += 256) {
+                const int orow = (int)__umulhi((unsigned)f, a.magicW);
+                const int ox = f - orow * Wout, oh = first + orow;
+                if (oh < 0 || oh >= Hout) continue;
+                float v[3] = {bias4[0], bias4[1], bias4[2]};
+                const int ixx = ox >> 1;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int tr = oh + 1 - kh;            // y3 source row of tap row kh
+                    if (tr < 0 || tr >= Hout) continue;
+                    int hs = hb + (tr - 2 * r0);
+                    if (hs < 0) hs += RING;
+                    if (hs >= RING) hs -= RING;
+                    const float* hq = sH + ((size_t)hs * NG + kh * C) * Wout + ox;
+                    // the horizontal sum of a pixel at a tile boundary was split between two waves
+                    int lr_ = (tr >> 1) - r0;
+                    if (lr_ < 0) lr_ += TH;
+                    const int qq = lr_ * Win + ixx;
+                    const bool needL = !(ox & 1) && (qq & 31) == 0 && ixx > 0;
+                    const bool needR = (ox & 1) && (qq & 31) == 31 && ixx < Win - 1;
+                    const float* eq = sE + (hs * NG + kh * C) * 8 + (needL ? (qq >> 5) - 1 : 4 + (qq >> 5) + 1);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (c < C) {
+                            v[c] += hq[c * Wout];
+                            if (needL || needR) v[c] += eq[c * 8];
+                        }
+                }
+                float p[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < C) {
+                        const float pr = 1.0f / (1.0f + expf(-v[c]));
+                        p[c] = pr;
+                        if (mode == 0) part += -(1.0f - pr) * logf(D1 - pr) - pr * logf(D0 + pr);
+                        else part += reward_term(pr, oh, ox, Hout, Wout, a.reward_intent);
+                    }
+                if (po) {
+                    float4* pp = reinterpret_cast<float4*>(po + ((size_t)oh * Wout + ox) * 8);
+                    pp[0] = make_float4(p[0], p[1], p[2], 0.f);
+                    pp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+        if (!more) break;
+        // ---- the new rows take the slots of the strip's own TH rows (every wave is past the MFMA phase: barrier above)
+        {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pp = ppt + 16 * i;
+                int sl = bs + RP + pp;                     // pixel (r0 + TH + 1) Win + pp = pixel (r0, 0) + RP + pp, mod RPa
+                if (sl >= RPa) sl -= RPa;
+                if (sl >= RPa) sl -= RPa;
+                if (pp < SPX) sm[sl * PS4 + c4] = pf[i];
+            }
+        }
+        bs += SPX; if (bs >= RPa) bs -= RPa;
+        hb += 2 * TH; if (hb >= RING) hb -= RING;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) sred[w] = part;
+    __syncthreads();
+    if (tid == 0) a.val[mg] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+static size_t dec_bg_lds(int Win, int TH, int C) {
+    const int RPa = ((TH + 1) * Win + 15) & ~15, RING = 2 * TH + 2, NG = 3 * C;
+    return (size_t)(RPa + 16) * 17 * sizeof(float4) + (size_t)RING * NG * (2 * Win) * sizeof(float) + (size_t)RING * NG * 8 * sizeof(float);
+}
+constexpr size_t DEC_BG_MAX_LDS = 96 * 1024;
+int init_generic_dec_kernels() {
+    if (hipFuncSetAttribute((const void*)k_dec_bg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_BG_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_p<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_P_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_p<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_P_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_p<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_P_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_convt_p<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_P_MAX_LDS) != hipSuccess) return 1;
+    return 0;
+}
+// 0 = launched; 1 = geometry outside the kernel's limits (the caller runs the layers separately)
+int launch_dec_bg(DecBGArgs a, hipStream_t st) {
+    if (a.Win < 4 || a.Win > 64 || a.Hin < 2 || a.C < 1 || a.C > 3) return 1;
+    a.TH = 128 / a.Win;
+    if (a.TH < 1 || a.TH * a.Win * 16 > 256 * 8) return 1;
+    const size_t lds = dec_bg_lds(a.Win, a.TH, a.C);
+    if (lds > DEC_BG_MAX_LDS) return 1;
+    a.magicW = (unsigned)((0x100000000ull + (unsigned)(2 * a.Win) - 1) / (unsigned)(2 * a.Win));
+    hipLaunchKernelGGL(k_dec_bg, dim3((unsigned)a.rows), dim3(256), lds, st, a);
+    return 0;
+}
+
+}  // namespace efe

@@ -496,23 +496,24 @@ void launch_posterior(const float* sumG, float* P, float* logP, int n_groups, in
 
 // check_reward (torchmodel.py:210-212, torchutils.py:30-37) on an arbitrary image batch: one workgroup per image.
 // Same per-pixel expression as the fused decoder epilogue (target 1 for rows h < 32, 0 below; mean over pixels * 10).
-__global__ void __launch_bounds__(256) k_check_reward(const float* o, float* out) {
+__global__ void __launch_bounds__(256) k_check_reward(const float* o, float* out, int intent) {
     __shared__ float sred[4];
     const float* img = o + (size_t)blockIdx.x * 4096;
     const float D1 = 1.00001f, D0 = 0.00001f;
     float part = 0.f;
     for (int p = threadIdx.x; p < 4096; p += 256) {
         const float pr = img[p];
-        part += ((p >> 6) < 32) ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f) : pr * logf(D0) + (1.0f - pr) * logf(D1);
+        part += reward_term(pr, p >> 6, p & 63, 64, 64, intent);
     }
 #pragma unroll
     for (int k = 32; k > 0; k >>= 1) part += __shfl_xor(part, k);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = ((sred[0] + sred[1]) + (sred[2] + sred[3])) * (1.0f / 4096.0f) * 10.0f;
+    // mean over the pixels that count (all 4096, or the 192 of the three bar rows) * 10
+    if (threadIdx.x == 0) out[blockIdx.x] = ((sred[0] + sred[1]) + (sred[2] + sred[3])) * (intent ? 1.0f / 192.0f : 1.0f / 4096.0f) * 10.0f;
 }
-void launch_check_reward(const float* o, float* out, int M, hipStream_t st) {
-    hipLaunchKernelGGL(k_check_reward, dim3(M), dim3(256), 0, st, o, out);
+void launch_check_reward(const float* o, float* out, int M, int intent, hipStream_t st) {
+    hipLaunchKernelGGL(k_check_reward, dim3(M), dim3(256), 0, st, o, out, intent);
 }
 
 // reparameterize (torchmodel.py:54-56 / 130-132): out = eps * exp(logvar / 2) + mean, eps from Philox or injected

@@ -367,8 +367,12 @@ class ActiveInferenceModel:
         return {'capacity_bytes': cap.value, 'high_water_bytes': hw.value, 'grow_count': gr.value}
 
     def set_option(self, name, value):
+        """efe_set_option: launch-group sizes (dec_chunk, enc_chunk, dec_chunk_g, dec_budget_g), reward_upstream_intent (0 / 1: the reward
+        target the upstream NHWC code means instead of the shipped port's NCHW broadcast), fuse_final_g (generic path:
+        last two decoder layers in one kernel, default 1), poison / trace / arena_align (development)"""
         e = self._engine
         e.check(e.lib.efe_set_option(e.ctx, name.encode(), int(value)))
+        self._opts = dict(getattr(self, '_opts', {}), **{name: int(value)})
 
     def save_weights(self, folder_chp):
         """torchmodel.py:167-171"""
@@ -573,10 +577,14 @@ class ActiveInferenceModel:
 
     def generic_class_names(self):
         """PROF_CLASSES name -> kernel description for the launches of the generic-geometry path (bench.py per-class table)"""
-        return {'dec_dense_16384': 'k_fc4 (Linear 256 -> 64 base^2)', 'convT1_generic': 'k_convt_p<1> (ConvT 64->64 s1)',
-                'dec_a_convT1_convT2': 'k_convt_p<2> (ConvT 64->64 s2)', 'dec_b_convT3_final_reduce': 'k_convt_p<2> (ConvT 64->32 s2)',
-                'final_layer_generic': 'k_final_g (ConvT 32->C + sigmoid + reductions)', 'encoder': 'encoder (k_conv_g x4 + dense head)',
-                'transition_mlp': 'k_trans_fused', 'dec_dense_small': 'decoder head (3 x k_dense)'}
+        names = {'dec_dense_16384': 'k_fc4 (Linear 256 -> 64 base^2)', 'convT1_generic': 'k_convt_p<1> (ConvT 64->64 s1)',
+                 'dec_a_convT1_convT2': 'k_convt_p<2> (ConvT 64->64 s2)', 'dec_b_convT3_final_reduce': 'k_convt_p<2> (ConvT 64->32 s2)',
+                 'final_layer_generic': 'k_final_g (ConvT 32->C + sigmoid + reductions)', 'encoder': 'encoder (k_conv_g x4 + dense head)',
+                 'transition_mlp': 'k_trans_fused', 'dec_dense_small': 'decoder head (3 x k_dense)'}
+        if getattr(self, '_opts', {}).get('fuse_final_g', 1) and self.resolution != 32:
+            names['dec_b_convT3_final_reduce'] = 'k_dec_bg (ConvT 64->32 s2 + ReLU + ConvT 32->C + sigmoid + per-image sums, fused)'
+            del names['final_layer_generic']
+        return names
 
     def prof_enable(self, on=True, classes=None):
         """time kernel classes with HIP events on the launch stream; `classes` = iterable of PROF_CLASSES names

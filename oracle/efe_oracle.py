@@ -67,6 +67,19 @@ def check_reward_generic(o):
     return torch.sum(log_bernoulli(o, target), dim=[1, 2, 3])
 
 
+def check_reward_upstream_intent(o, generic=False):
+    """The reward the UPSTREAM code means, kept beside the replicated quirk as an engine option
+    (`reward_upstream_intent`): `calc_reward` (torchutils.py:34-37) was written for NHWC observations, where `o[:, 0:3, 0:res, :]` is the
+    top three image rows (the reward bar of game_environment.py:44-54) and `perfect_reward[:, :res/2] = 1` marks their LEFT half.
+    Restated for this repository's NCHW tensors: log_bernoulli over rows 0..2 with target 1 for columns < W/2, every channel;
+    dSprites: mean over those 3*W*C elements * 10 (torchmodel.py:212); generic geometries: their sum (torchmodel.py:214 form)."""
+    W = o.shape[3]
+    target = torch.zeros((1, 1, 1, W), dtype=torch.float32)
+    target[..., :W // 2] = 1.0
+    lb = log_bernoulli(o[:, :, 0:3, :], target)
+    return torch.sum(lb, dim=[1, 2, 3]) if generic else torch.mean(lb, dim=[1, 2, 3]) * 10.0
+
+
 def softmax_multi_with_log(x, single_values=4, eps=1e-20, temperature=10.0):
     """util.py:46-53 (numpy; note logSM is NOT log(SM) -- replicated as is)."""
     x = x.reshape(-1, single_values)
@@ -161,9 +174,12 @@ class OracleModel:
         self.last_stride = 1 if resolution == 32 else 2          # torchmodel.py:77-80
         self.base = resolution // 2 if resolution == 32 else resolution // 4
         self.generic = (channels, resolution) != (1, 64)
+        self.reward_upstream_intent = False         # engine option of the same name: see check_reward_upstream_intent
         self.pi_one_hot = torch.eye(pi_dim)      # torchmodel.py:164-165
 
     def check_reward(self, o):
+        if self.reward_upstream_intent:
+            return check_reward_upstream_intent(o, self.generic)
         return check_reward_generic(o) if self.generic else check_reward(o)
 
     # ---- ModelTop.encode_s (torchmodel.py:27-31); no dropout --------------

@@ -90,6 +90,15 @@ def main():
                                                               depth=5, threshold=2.0, stage0=400, frame_seed=26, prior=False, use_habit=False, meta=meta)
     cases['mcts_prior_s10'], report['mcts_prior_s10'] = capture('mcts_prior_s10', model, inj, ref_mcts, state, episodes=2, samples=10, repeats=12,
                                                                 depth=5, threshold=0.45, stage0=600, frame_seed=27, prior=True, use_habit=True, meta=meta)
+    # ---- the upstream-intent reward: the reference's own calc_reward / check_reward formula applied to the NHWC view
+    # of an image batch -- what the upstream TensorFlow code computes -- as the pin of oracle.efe_oracle.check_reward_upstream_intent
+    from src import torchutils as TU
+    p_img = torch.from_numpy(PX.uniform_fill(5, (3, 1, 64, 64), 60, 0.0, 1.0))
+    p_img[0, 0, :4, :4] = 0.0
+    p_img[0, 0, 4:8, :4] = 1.0
+    r_intent = torch.mean(TU.calc_reward(p_img.permute(0, 2, 3, 1)), dim=[1, 2, 3]) * 10.0
+    np.savez_compressed(os.path.join(GOLD, 'helpers_intent.npz'), p=p_img.numpy(), reward_upstream_intent=r_intent.numpy())
+    cases['helpers_intent'] = ['p', 'reward_upstream_intent']
     mpath = os.path.join(GOLD, 'MANIFEST.json')
     manifest = json.load(open(mpath))
     manifest['cases'].update(cases)

@@ -112,6 +112,30 @@ def test_rollout_and_posterior(pair):
     assert torch.equal(G_hi, G[A:])
 
 
+def test_rollout_at_benchmark_depth_and_samples(pair):
+    """BASELINE configs[4] compared at its OWN depth and sample count -- depth 7, 30 MC samples -- on 24 rows (8 episodes x 3 actions;
+    the bench runs 96): 7 x 90 x 24 = 15120 decoder images through the same launch groups as the benchmark.  (~20 s of oracle time.)"""
+    m, orc = pair
+    from conftest import usable_cores
+    st, D, S, n = 70, 7, 30, 8
+    fr = synth.make_frames_rgb(13, n, C, R)
+    o = np.repeat(fr, A, axis=0)
+    pi = np.tile(np.eye(A, dtype=np.float32), (n, 1))
+    prev = torch.get_num_threads()
+    torch.set_num_threads(usable_cores())
+    try:
+        with torch.no_grad():
+            oG, oT, opo1 = orc.calculate_G_repeated(torch.from_numpy(o), torch.from_numpy(pi), D, False, S, st)
+    finally:
+        torch.set_num_threads(prev)
+    G, T, po1 = m.calculate_G_repeated(o, pi, steps=D, samples=S, stage=st)
+    per_stage = sumtol(oT[0].numpy() / D)
+    np.testing.assert_allclose(c(T[0]), oT[0].numpy(), atol=D * per_stage)
+    np.testing.assert_allclose(c(T[1]), oT[1].numpy(), atol=D * 1e-3)
+    np.testing.assert_allclose(c(G), oG.numpy(), atol=D * 3 * per_stage)
+    np.testing.assert_allclose(c(po1), opo1.numpy(), rtol=1e-5, atol=5e-5)
+
+
 def test_planner_three_actions(pair):
     """single-episode and lock-step planners with pi_dim 3 (the {1,2} opposite pair of mcts.py:119-124) vs the oracle planner"""
     import daimc_amd
@@ -253,3 +277,55 @@ def test_generic_chunking_invariance(pair):
     assert torch.equal(out[0], ref[0]) and torch.equal(out[4], ref[4])
     for k in range(3):
         assert torch.equal(out[1][k], ref[1][k])
+
+
+@pytest.mark.parametrize('A2,C2,R2', [(3, 3, 84), (4, 1, 48), (3, 3, 64), (5, 2, 128), (2, 3, 36)])
+def test_fused_last_layers_equal_separate_launches(A2, C2, R2):
+    """k_dec_bg (ConvT3 + final layer + sigmoid + sums in one kernel, option fuse_final_g = 1, the default) against the same layers
+    as separate launches (k_convt_p + k_final_g through y3 in HBM): identical images up to the summation order of the 3 x 3 taps, equal
+    per-image sums within the fp32 bound -- on every strip shape (Win = 42, 24, 32, 64, 18), including a reward-target row split"""
+    import daimc_amd
+    w = synth.make_weights(91 + R2, 1.15, A2, C2, R2)
+    m = daimc_amd.ActiveInferenceModel(10, A2, 0.0, 1.0, 1.0, colour_channels=C2, resolution=R2, device='cuda:0', seed=6, init_weights=False)
+    m.load_flat_weights(w)
+    m.eps_source, m.u_source = PX.normals, PX.uniforms
+    M, st = 5, 4
+    s0 = PX.uniform_fill(4, (M, 10), 61, -1.2, 1.2)
+    pi0 = np.eye(A2, dtype=np.float32)[np.arange(M) % A2]
+    parts_f, parts_u = [], []
+    Gf, Tf, _, _, pof = m.calculate_G(s0, pi0, samples=2, stage=st, _parts=parts_f)
+    m.set_option('fuse_final_g', 0)
+    try:
+        Gu, Tu, _, _, pou = m.calculate_G(s0, pi0, samples=2, stage=st, _parts=parts_u)
+    finally:
+        m.set_option('fuse_final_g', 1)
+    np.testing.assert_allclose(c(pof), c(pou), rtol=0, atol=4e-6)
+    tol = sumtol(c(Tu[0]))
+    np.testing.assert_allclose(c(Tf[0]), c(Tu[0]), atol=tol)
+    np.testing.assert_allclose(c(parts_f[0][0]), c(parts_u[0][0]), atol=tol)
+    np.testing.assert_allclose(c(Gf), c(Gu), atol=3 * tol)
+    assert torch.equal(Tf[1], Tu[1])
+
+
+def test_reward_upstream_intent_generic(pair):
+    """the upstream-intent reward target (option reward_upstream_intent) on the generic geometry: rows 0..2, left half = 1,
+    summed over channels -- against oracle.efe_oracle.check_reward_upstream_intent, through check_reward and through calculate_G"""
+    m, orc = pair
+    st, M = 31, 4
+    s0 = PX.uniform_fill(4, (M, 10), 63, -1.0, 1.0)
+    pi0 = np.eye(A, dtype=np.float32)[np.arange(M) % A]
+    ref = m.calculate_G(s0, pi0, samples=2, stage=st)
+    m.set_option('reward_upstream_intent', 1)
+    orc.reward_upstream_intent = True
+    try:
+        with torch.no_grad():
+            oG, oT, _, _, opo1 = orc.calculate_G(torch.from_numpy(s0), torch.from_numpy(pi0), 2, st)
+            ocr = orc.check_reward(opo1)
+        G, T, _, _, po1 = m.calculate_G(s0, pi0, samples=2, stage=st)
+        np.testing.assert_allclose(c(T[0]), oT[0].numpy(), atol=sumtol(oT[0].numpy()))
+        np.testing.assert_allclose(c(m.check_reward(opo1.numpy())), ocr.numpy(), rtol=3e-6, atol=1e-4)
+        assert torch.equal(po1, ref[4])
+    finally:
+        m.set_option('reward_upstream_intent', 0)
+        orc.reward_upstream_intent = False
+    assert torch.equal(m.calculate_G(s0, pi0, samples=2, stage=st)[0], ref[0])

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import eps_calcG, eps_rollout, usable_cores
+from conftest import eps_calcG, eps_rollout, usable_cores, load_golden
 from oracle import philox as PX
 from oracle import synth
 from oracle import efe_oracle as EO
@@ -236,26 +236,46 @@ def test_chunking_invariance(models):
     assert torch.equal(G1, G2) and torch.equal(po1, po2)
 
 
-@pytest.mark.parametrize('opt,val', [('dbg_b', 8), ('dbg_b', 16), ('dbg_b', 64), ('dbg_a', 4)])
-def test_kernel_variants_agree(models, opt, val):
-    """the alternative workgroup shapes of the decoder kernels (4-row strips / 8 waves, 4-row strips / 4 waves for
-    k_dec_b; 8-wave k_dec_a) compute the same images bit for bit and the same pixel sums up to the order in which
-    a thread adds its pixels (fp32: a few ulp of a ~2.8e3 sum)."""
+def test_no_experiment_switches_in_the_product_library(models):
+    """the wrong-result timing switches and superseded kernel forms live under tools/ubench/variants/: the shipped library has no
+    option that reaches them"""
     m = models(1234, 1.15, 13)
-    o = synth.make_frames(33, 10)
-    pi = np.eye(4, dtype=np.float32)[np.arange(10) % 4]
-    G1, t1, po1 = m.calculate_G_repeated(o, pi, steps=2, samples=3, stage=5)
-    m.set_option(opt, val)
+    for opt in ('dbg_a', 'dbg_b', 'tl_buf'):
+        with pytest.raises(RuntimeError, match='unknown option'):
+            m.set_option(opt, 1)
+
+
+def test_reward_upstream_intent_option(models, weights_cache):
+    """the reward target the upstream NHWC code means (top three rows, left half = 1) as an engine option beside the
+    replicated NCHW-broadcast quirk (default).  check_reward and the fused decoder epilogue against the oracle restatement
+    (oracle.efe_oracle.check_reward_upstream_intent); switching the option back restores the pinned values bit for bit."""
+    seed, st, M, S = 17, 3, 6, 2
+    w = weights_cache(1234, 1.15)
+    m = models(1234, 1.15, seed)
+    orc = EO.OracleModel(w, EO.PhiloxNoise(seed))
+    s0 = PX.uniform_fill(4, (M, 10), 77, -1.0, 1.0)
+    pi0 = np.eye(4, dtype=np.float32)[np.arange(M) % 4]
+    eps = eps_calcG(seed, M, S, st)
+    G0, T0, _, _, po0 = m.calculate_G(s0, pi0, samples=S, stage=st, eps=eps)
+    m.set_option('reward_upstream_intent', 1)
     try:
-        G2, t2, po2 = m.calculate_G_repeated(o, pi, steps=2, samples=3, stage=5)
+        orc.reward_upstream_intent = True
+        with torch.no_grad():
+            oG, oT, _, _, opo1 = orc.calculate_G(torch.from_numpy(s0), torch.from_numpy(pi0), S, st)
+            ocr = orc.check_reward(opo1)
+        G1, T1, _, _, po1 = m.calculate_G(s0, pi0, samples=S, stage=st, eps=eps)
+        assert torch.equal(po1, po0)                                        # the images do not depend on the reward target
+        np.testing.assert_allclose(c(T1[0]), oT[0].numpy(), atol=1e-4)
+        np.testing.assert_allclose(c(T1[1]), oT[1].numpy(), atol=1e-4)
+        np.testing.assert_allclose(c(G1), oG.numpy(), atol=gtol(orc.last_term2_parts[0].numpy()))
+        np.testing.assert_allclose(c(m.check_reward(opo1.numpy())), ocr.numpy(), rtol=2e-6, atol=1e-6)
+        gi = load_golden('helpers_intent')          # the reference's formula on the NHWC view of a batch (oracle/make_golden_deep.py)
+        np.testing.assert_allclose(c(m.check_reward(gi['p'])), gi['reward_upstream_intent'], rtol=2e-6, atol=1e-6)
+        assert not np.allclose(c(T1[0]), c(T0[0]), atol=1e-2)              # a different quantity than the replicated quirk
     finally:
-        m.set_option(opt, 0)
-    if opt == 'dbg_b':       # the default k_dec_b4 adds the nine taps of the final conv in a different order (kw inside kh) than the k_dec_b forms: a few ulp per pixel
-        np.testing.assert_allclose(c(po2), c(po1), rtol=0, atol=2e-6)
-    else:
-        assert torch.equal(po1, po2)
-    np.testing.assert_allclose(c(G2), c(G1), rtol=0, atol=2e-2)
-    np.testing.assert_allclose(c(t2[0]), c(t1[0]), rtol=1e-5, atol=1e-4)
+        m.set_option('reward_upstream_intent', 0)
+    G2, T2, _, _, _ = m.calculate_G(s0, pi0, samples=S, stage=st, eps=eps)
+    assert torch.equal(G2, G0) and torch.equal(T2[0], T0[0])
 
 
 def test_full_size_properties(models):

@@ -226,3 +226,12 @@ def test_resolution32_networks_vs_reference(golden):
     for a, b in ((ps1, 't_ps1'), (mean, 't_mean'), (lv, 't_lv'), (po, 'd_po'), (es, 'e_s'), (em, 'e_mean'), (elv, 'e_lv'),
                  (hl, 'h_logits'), (hq, 'h_q'), (hlq, 'h_logq')):
         np.testing.assert_allclose(a.numpy(), g[b], rtol=1e-6, atol=1e-6)
+
+
+def test_upstream_intent_reward_vs_reference_formula(golden):
+    """oracle.efe_oracle.check_reward_upstream_intent (the engine option reward_upstream_intent) == the reference's own calc_reward /
+    check_reward formula applied to the NHWC view of the batch (captured by oracle/make_golden_deep.py) -- SURVEY appendix C"""
+    g = golden('helpers_intent')
+    got = EO.check_reward_upstream_intent(torch.from_numpy(g['p']))
+    np.testing.assert_allclose(got.numpy(), g['reward_upstream_intent'], rtol=1e-6)
+    assert not np.allclose(EO.check_reward(torch.from_numpy(g['p'])).numpy(), g['reward_upstream_intent'], rtol=1e-3)

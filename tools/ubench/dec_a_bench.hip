@@ -1,6 +1,6 @@
 // micro-benchmark: k_dec_a (ConvT1 + ConvT2 of the decoder) alone on synthetic data, MFMA efficiency vs the 157.3 TF
 // fp32 peak.  dev tool, not part of the product.   usage: dec_a_bench [rows] [dbg]
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deep-active-inference-mc_amd/csrc tools/ubench/dec_a_bench.hip -o tools/ubench/dec_a_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tools/ubench/variants tools/ubench/dec_a_bench.hip -o tools/ubench/dec_a_bench
 #include "decoder.hip"
 #include <cstdio>
 #include <cstdlib>

@@ -1,6 +1,6 @@
 // micro-benchmark: k_dec_b (ConvT3 + final conv + sigmoid + per-image reduction) alone on synthetic data.
 // dev tool, not part of the product.   usage: dec_b_bench [rows] [dbg]
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deep-active-inference-mc_amd/csrc tools/ubench/dec_b_bench.hip -o tools/ubench/dec_b_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tools/ubench/variants tools/ubench/dec_b_bench.hip -o tools/ubench/dec_b_bench
 #include "decoder.hip"
 #include <cstdio>
 #include <cstdlib>

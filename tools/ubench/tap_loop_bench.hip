@@ -1,6 +1,6 @@
 // micro-benchmark: MFMA issue efficiency of the software-pipelined tap loop (mfma_pipe.h) in isolation, i.e. the
 // CT1 inner loop of k_dec_a without staging / epilogues / stores.  dev tool, not part of the product.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deep-active-inference-mc_amd/csrc tools/ubench/tap_loop_bench.hip -o tools/ubench/tap_loop_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tools/ubench/variants tools/ubench/tap_loop_bench.hip -o tools/ubench/tap_loop_bench
 #include "mfma_pipe.h"
 #include <cstdio>
 #include <vector>

@@ -5,9 +5,8 @@
 // One workgroup (4 waves) owns one decoder image; activations live in LDS between layers:
 //
 //   k_dec_a :  x4[16x16x64] --LDS--> ConvT(64,64,s1)+ReLU --LDS (in place)--> ConvT(64,64,s2)+ReLU --> y2[32x32x64] (HBM)
-//   k_dec_b4:  y2 strips --LDS--> ConvT(64,32,s2)+ReLU (registers) --MFMA--> tap values of the 32->1 conv, horizontal sums in registers
-//              --LDS ring of H planes--> vertical gather + sigmoid + entropy / reward reduction (+ optional image store)
-// (the superseded forms of these kernels and their timing-experiment switches live under tools/ubench/variants/)
+//   k_dec_b :  y2 strips --LDS--> ConvT(64,32,s2)+ReLU (registers) --MFMA--> 9 tap planes of the 32->1 conv
+//              --LDS ring--> 3x3 gather + sigmoid + entropy / reward reduction (+ optional image store)
 //
 // LDS images are [pixel][64 ch] with the 16-byte channel-quad index XOR-swizzled by (pixel & 15), so the
 // ds_read_b128 of an MFMA B fragment (32 pixels x same quad) is bank-conflict free without padding
@@ -21,11 +20,35 @@ namespace efe {
 // k_dec_a: ConvTranspose2d(64,64,3,s1,p1)+ReLU then ConvTranspose2d(64,64,3,s2,p1,op1)+ReLU, one image per WG.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int DA_BIAS = 257 * 16;          // float4 index of the two bias vectors behind the image + zero pixel
-// Four waves of 64 features x 64 pixels each (NTW = 2 32-pixel tiles per wave; 256 VGPRs, 2 waves per SIMD).
-__global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
-    constexpr int NTW = 2;
+#ifdef EFE_TIMELINE
+#ifndef EFE_TL_SKIP
+#define EFE_TL_SKIP 0
+#endif
+#ifndef EFE_TL_BLOCK
+#define EFE_TL_BLOCK 0
+#endif
+#define TL(i) do { if (a.tl && tid == 0 && blockIdx.x == EFE_TL_BLOCK) { if (tlk >= EFE_TL_SKIP && tlk < EFE_TL_SKIP + 60) a.tl[tlk - EFE_TL_SKIP] = clock64(); ++tlk; } } while (0)
+#elif defined(EFE_PHASE_CLK)
+// per-phase cycle sums of wave 0 of every workgroup, written once at kernel end: a.tl[block * 16 + phase]
+#define TL(i) do { const long long t_ = clock64(); phs[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define TL(i) do {} while (0)
+#endif
+#ifdef EFE_X_NOBAR            // timing experiment (wrong results): no workgroup barriers in the image loop
+#define EFE_X_BAR() do {} while (0)
+#else
+#define EFE_X_BAR() __syncthreads()
+#endif
+// NTW = 32-pixel tiles per wave: 2 = four waves of 64 features x 64 pixels (256 VGPRs, 2 waves per SIMD); 1 = eight waves of
+// 64 x 32 (128 VGPRs, 4 waves per SIMD).
+template <int NTW>
+__global__ void __launch_bounds__(512 / NTW, 4 / NTW) k_dec_a(const DecAArgs a) {
     constexpr int NTHR = 512 / NTW;
     constexpr int NPH = 2048 / NTHR;                  // float4s per thread of each image half
+    int tlk = 0; (void)tlk;
+#ifdef EFE_PHASE_CLK
+    long long phs[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) float4 sm[];        // [257 pixels][16 quads]; pixel 256 = zeros
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -42,15 +65,17 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
     int* const slot = reinterpret_cast<int*>(sm + DA_BIAS + 32);
     if (tid == 0) slot[0] = 2 * (int)gridDim.x + atomicAdd(a.queue, 1);
     int nimg = (int)blockIdx.x + (int)gridDim.x;
-    // next image, in flight during compute
-    f32x4 pfa[NPH], pfb[NPH];
+    // next image, in flight during compute.  The 8-wave form keeps only NPB of the second half's NPH pieces in registers (128-VGPR
+    // budget) and fetches the last ones when the image is staged (the other three waves of the SIMD cover that latency).
+    constexpr int NPB = NTW == 1 ? NPH - 2 : NPH;
+    f32x4 pfa[NPH], pfb[NPB];
     f32x4* smv = reinterpret_cast<f32x4*>(sm);
     {
         const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)blockIdx.x * 4096;
 #pragma unroll
         for (int it = 0; it < NPH; ++it) pfa[it] = X[it * NTHR + tid];
 #pragma unroll
-        for (int it = 0; it < NPH; ++it) pfb[it] = X[(it + NPH) * NTHR + tid];
+        for (int it = 0; it < NPB; ++it) pfb[it] = X[(it + NPH) * NTHR + tid];
     }
     if (tid < 16) sm[256 * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     // biases live in LDS: a global bias load inside an epilogue forces s_waitcnt vmcnt(0), i.e. waits for every store
@@ -59,7 +84,9 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
     else if (tid < 32) sm[DA_BIAS + tid] = reinterpret_cast<const float4*>(a.b2)[tid - 16];
 
     for (int img = blockIdx.x; img < a.rows;) {
+        TL(0);
         // stage the 16x16x64 input image (64 KiB) into the swizzled LDS layout
+#ifndef EFE_X_NOSTAGE         // timing experiment (wrong results): no staging of the input image
         // per-image laundering of the thread index: stops hipcc hoisting ~40 loop-invariant staging / prefetch addresses out of
         // the image loop, which pushed the kernel over 256 VGPRs (spill reloads carry s_waitcnt vmcnt(0): they serialised
         // the prefetch loads and waited for every outstanding y2 store)
@@ -75,20 +102,32 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
 #pragma unroll
             for (int it = 0; it < NPH; ++it) smv[sbase + it * NTHR] = pfa[it];
 #pragma unroll
-            for (int it = 0; it < NPH; ++it) smv[sbase + (it + NPH) * NTHR] = pfb[it];
+            for (int it = 0; it < NPB; ++it) smv[sbase + (it + NPH) * NTHR] = pfb[it];
+            if (NPB < NPH) {
+                const f32x4* Xc = reinterpret_cast<const f32x4*>(a.x4) + (size_t)img * 4096;
+                f32x4 late[NPH - NPB + 1];
+#pragma unroll
+                for (int it = NPB; it < NPH; ++it) late[it - NPB] = (Xc + (it + NPH) * NTHR)[tl_];
+#pragma unroll
+                for (int it = NPB; it < NPH; ++it) smv[sbase + (it + NPH) * NTHR] = late[it - NPB];
+            }
         }
-        __syncthreads();
+#endif
+        EFE_X_BAR();
+        TL(1);
         const int nnimg = slot[0];                     // the image after nimg (written one iteration ago)
         int ticket = 0;
         if (tid == 0) ticket = 2 * (int)gridDim.x + atomicAdd(a.queue, 1);     // lands during the layer-1 contraction
         const bool more = nimg < a.rows;
+#ifndef EFE_X_NOSTAGE
         {   // request the next image now (clamped on the last pass: unconditional loads keep pf[] in registers)
-            const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)(more ? nimg : img) * 4096;
+            const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)((more && !(a.dbg & 2)) ? nimg : img) * 4096;
 #pragma unroll
             for (int it = 0; it < NPH; ++it) pfa[it] = (X + it * NTHR)[tl_];
 #pragma unroll
-            for (int it = 0; it < NPH; ++it) pfb[it] = (X + (it + NPH) * NTHR)[tl_];
+            for (int it = 0; it < NPB; ++it) pfb[it] = (X + (it + NPH) * NTHR)[tl_];
         }
+#endif
 
         f32x16 acc[2][NTW];
         // the accumulators start at the bias (register e of tile mt holds channel 32mt + (e&3) + 8(e>>2) + 4h) and ReLU is one
@@ -118,8 +157,11 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
             }
         }, ConvWIdx{});
         }
-        __syncthreads();                // every wave is done reading the input image (and slot[0])
+        TL(2);
+        EFE_X_BAR();                // every wave is done reading the input image (and slot[0])
         if (tid == 0) slot[0] = ticket;
+        TL(3);
+#ifndef EFE_X_NOEPI1          // timing experiment (wrong results): no layer-1 epilogue
         // bias + ReLU, written back IN PLACE as the input image of layer 2 (same swizzled layout)
         if (live)
 #pragma unroll
@@ -136,15 +178,21 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
                     sm[swz(pix, c4)] = v;
                 }
         }
-        __syncthreads();
+#endif
+        EFE_X_BAR();
+        TL(4);
 
         // ---------------- layer 2 (stride 2): 4 output parities, oh = 2*ih - 1 + kh ----------------------------
         float* Y = a.y2 + (size_t)img * (32 * 32 * 64);
+#ifdef EFE_X_NOSTORE
+        float keep = 0.f;
+#endif
 #pragma unroll 1
         for (int par = 0; par < (live ? 4 : 0); ++par) {
             const int ph = par >> 1, pw = par & 1;
             acc_init(16);
             tap_loop_pd<2, NTW, 1>(acc, (1 + ph) * (1 + pw), W2, sm, h, ConvT2Addr<NTW>{ph, pw, prow0, 2, pcol, 16, 16, 256}, ConvWIdx{});
+            TL(5);
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 // y2 layout (float4 units): [parity][8 channel groups][256 input positions][2 quads] -- for one (mt, g4) the 64
@@ -158,30 +206,324 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
                         float4 v;
                         v.x = relu_bits(acc[mt][nt][4 * g4 + 0]); v.y = relu_bits(acc[mt][nt][4 * g4 + 1]);
                         v.z = relu_bits(acc[mt][nt][4 * g4 + 2]); v.w = relu_bits(acc[mt][nt][4 * g4 + 3]);
+#ifdef EFE_X_NOSTORE          // timing experiment (wrong results): no y2 stores
+                        keep += v.x + v.y + v.z + v.w;
+#else
                         yp[(mt * 4 + g4) * 512] = v;
+#endif
                     }
             }
+#ifdef EFE_PHASE_CLK
+            TL(6);
+#endif
         }
-        __syncthreads();                // every wave is done reading layer-1's image before the next one overwrites it
+#ifdef EFE_X_NOSTORE
+        Y[tid] = keep;
+#endif
+        TL(9);
+        EFE_X_BAR();                // every wave is done reading layer-1's image before the next one overwrites it
         img = nimg; nimg = nnimg;
     }
+#ifdef EFE_PHASE_CLK
+    if (a.tl && tid == 0)
+        for (int i = 0; i < 10; ++i) a.tl[blockIdx.x * 16 + i] = phs[i];
+#endif
 }
 
 constexpr size_t DA_LDS_BYTES = (257 * 16 + 33) * sizeof(float4);
 int init_dec_b_kernels();
 // kernels that need more than the default 64 KiB of dynamic LDS: set once per device (called from efe_create)
 int init_decoder_kernels() {
-    if (hipFuncSetAttribute((const void*)k_dec_a, hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)(k_dec_a<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)(k_dec_a<1>), hipFuncAttributeMaxDynamicSharedMemorySize, DA_LDS_BYTES) != hipSuccess) return 1;
     return init_dec_b_kernels();
 }
 
 void launch_dec_a(const DecAArgs& a, hipStream_t st) {
     const size_t lds = DA_LDS_BYTES;
     const int grid = a.rows < 512 ? a.rows : 512;         // persistent: 2 workgroups per CU
-    hipLaunchKernelGGL(k_dec_a, dim3(grid), dim3(256), lds, st, a);       // 0.87 of the fp32 MFMA peak alone (19200 images)
+    // default: four waves of 64 features x 64 pixels (0.872 of the fp32 MFMA peak alone, 19200 images).  dbg bit 2: eight waves of
+    // 64 x 32 (0.881 alone, no gain inside the rollout; kept for A/B)
+    if (a.dbg & 4) hipLaunchKernelGGL((k_dec_a<1>), dim3(grid), dim3(512), lds, st, a);
+    else           hipLaunchKernelGGL((k_dec_a<2>), dim3(grid), dim3(256), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
+#ifdef EFE_FAST_MATH_EPILOGUE
+#define EFE_EXP __expf
+#define EFE_LOG __logf
+#else
+#define EFE_EXP expf
+#define EFE_LOG logf
+#endif
+// k_dec_b: ConvTranspose2d(64,32,3,s2,p1,op1)+ReLU, ConvTranspose2d(32,1,3,s1,p1)+Sigmoid and the per-image
+// reduction, one image per WG, strips of SR input rows (2*SR output rows).
+//
+// The 32->1 conv is applied to the layer-3 accumulators while they are still in registers: for each finished
+// 32(co) x 32(pixel) tile, 16 extra MFMAs contract the channel axis against the 9 taps,
+//     T[tap][q] = sum_co W4[co][tap] * relu(y3[q][co] + b3[co]),
+// using the accumulator register e of every lane directly as the B operand (lane (q,h) holds
+// co = (e&3) + 8*(e>>2) + 4h; with the 4-block 16x16x1 MFMA each 16-lane block is one (pixel half, channel half)).  The 9 planes go to an LDS ring
+// and the 3x3 "gather"  out[oh,ow] = b4 + sum_{kh,kw} T[kh*3+kw][oh+1-kh][ow+1-kw]  is done once the rows
+// above and below exist.  y3 (512 KiB per image) never exists in memory.
+// ---------------------------------------------------------------------------------------------------------
+// SR = input rows per strip.  SR = 4: 8 strips, 64 KiB LDS, 2 workgroups per CU.  SR = 2: 16 strips, 38 KiB LDS, 4 per CU.
+#ifdef EFE_PHASE_CLK
+#define TLB(i) do { const long long t_ = clock64(); phs[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define TLB(i) do {} while (0)
+#endif
+// RW = strip rows (32-pixel tiles) per wave.  RW = 2: SR waves (the original form).  RW = 1: 2*SR waves of <= 128 VGPRs, i.e. four
+// waves per SIMD with two workgroups per CU: a wave in a VALU phase (staging, ReLU, tap-plane writes, gather) issues one
+// instruction per ~19 cycles beside an MFMA stream, and with only two waves per SIMD both were out of MFMA work ~20 % of the time.
+template <int SR, int RW>
+__global__ void __launch_bounds__(128 * SR / RW, 4 / RW) k_dec_b(const DecBArgs a) {
+#ifdef EFE_PHASE_CLK
+    long long phs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
+    constexpr int NW = 2 * SR / RW;                   // waves per workgroup
+    constexpr int NTHR = 64 * NW;
+    constexpr int DB_ZERO = (SR + 1) * 32;            // zero pixel slot behind the (SR+1)-row input strip
+    constexpr int DB_IN_F4 = (DB_ZERO + 1) * 16;      // float4s
+    constexpr int DB_YROWS = 2 * SR + 2;              // tap-plane ring: the strip's 2*SR rows + 2 kept from the previous one
+    constexpr int NPF = (SR + 1) * 512 / NTHR;        // float4s of the input strip per thread
+    constexpr int NS = 32 / SR;                       // strips per image
+    extern __shared__ __attribute__((aligned(16))) float4 sm[];        // input strip, then T ring
+    constexpr int TS = 66;                            // tap-plane row: zero column, 64 columns, zero column
+    float* sT = reinterpret_cast<float*>(sm + DB_IN_F4);               // [ring rows][9 taps][TS]
+    __shared__ float sred[NW];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    // wave -> (row group rp, parity group pg).  pg 0 contracts 5 tap-tiles per row, pg 1 only 4, and waves w and w+4 share a
+    // SIMD: flip pg for the upper four waves so every SIMD gets one heavy and one light wave (otherwise two SIMDs of the CU
+    // carry 25 % more MFMA work than the other two and everyone waits for them at the strip barrier).
+    const int rp = w >> 1;
+#ifndef EFE_X_FLIP
+    const int pg = (NW == 8 ? (w ^ (w >> 2)) : w) & 1;
+#endif
+    const int img = blockIdx.x;
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+
+    const int mg = a.m0 + img;
+    const int g = mg / a.rows_per_group;
+    const int r = mg - g * a.rows_per_group;
+    int gt, gp, gs;
+    group_decode(a.gm, g, gt, gp, gs);
+    const int mode = (gp == 0 && a.reward0) ? 1 : 0;
+    const int slot = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
+    float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + r) * 4096 : nullptr;
+
+    // per-lane constants: the A fragments of the 32->1 conv; the layer-3 bias (accumulator init) is read from LDS per tile
+    __shared__ float4 sb3[8];
+    if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];
+    float w4f[16];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {                   // register e holds channel co = (e&3) + 8*(e>>2) + 4h: four contiguous floats per e>>2
+#ifdef EFE_X_TAP3             // experiment: tap t = 3*(i>>2) + (i&3) in A row i (rows 3, 7, 11, 12-15 are padding): three taps per 16-lane group
+        const int ti_ = lane & 15;
+        const bool tv_ = (ti_ & 3) < 3 && ti_ < 12;
+        const float4 q = tv_ ? reinterpret_cast<const float4*>(a.w4 + (3 * (ti_ >> 2) + (ti_ & 3)) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+#else
+        const float4 q = ((lane & 15) < 9) ? reinterpret_cast<const float4*>(a.w4 + (lane & 15) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+        w4f[4 * g4] = q.x; w4f[4 * g4 + 1] = q.y; w4f[4 * g4 + 2] = q.z; w4f[4 * g4 + 3] = q.w;   // A_b[i = tap = lane&15], b>>1 = h
+    }
+    if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < DB_YROWS * 9 * 2; i += NTHR) sT[(i >> 1) * TS + (i & 1) * (TS - 1)] = 0.f;   // the pad columns (never rewritten)
+
+    const float4* X = reinterpret_cast<const float4*>(a.y2) + (size_t)img * (32 * 32 * 16);
+    const float4* W3 = reinterpret_cast<const float4*>(a.w3);
+    const float D1 = 1.00001f, D0 = 0.00001f;      // fp32 constants of log_bernoulli / entropy_bernoulli
+    float part = 0.f;
+    f32x4 pf[NPF];                                                     // input strip in flight
+    f32x4* smv = reinterpret_cast<f32x4*>(sm);
+    const f32x4* Xv = reinterpret_cast<const f32x4*>(X);
+    // y2 image layout (written by k_dec_a): [parity (iy&1, ix&1)][8 channel groups][16 x 16 positions (iy>>1, ix>>1)][2 quads];
+    // element idx of a staged row = (segment = pw*8 + cg, b = ix>>1, quad half): 512-byte contiguous pieces
+    auto y2_at = [&](int iy, int idx) -> size_t { return (size_t)(((iy & 1) * 16 + ((idx & 511) >> 5)) * 512 + (iy >> 1) * 32 + (idx & 31)); };
+#pragma unroll
+    for (int it = 0; it < NPF; ++it) { const int idx = it * NTHR + tid; pf[it] = Xv[y2_at(idx >> 9, idx)]; }   // strip 0 = rows 0..SR
+
+    TLB(0);
+    for (int s = 0; s < NS; ++s) {
+        // ---- stage input rows SR*s .. SR*s+SR (row 32 does not exist: zeros); the data was requested one strip earlier
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int idx = it * NTHR + tid;                           // (SR+1) rows x 32 px x 16 quads
+            const int rl = idx >> 9, seg = (idx & 511) >> 5, wi = idx & 31;
+            const int ix = 2 * (wi >> 1) + (seg >> 3), c4 = 2 * (seg & 7) + (wi & 1);
+            smv[swz(rl * 32 + ix, c4)] = (SR * s + rl < 32) ? pf[it] : (f32x4)(0.f);
+        }
+        __syncthreads();
+        TLB(1);
+#ifndef EFE_X_PF_LATE
+        {   // request strip s+1 now (it lands during the MFMA phase); rows >= 32 are clamped here and zeroed when staged
+            const int sn = (s < NS - 1) ? s + 1 : NS - 1;
+#pragma unroll
+            for (int it = 0; it < NPF; ++it) {
+                const int idx = it * NTHR + tid;
+                const int grow = min(SR * sn + (idx >> 9), 31);
+                pf[it] = Xv[y2_at(grow, idx)];
+            }
+        }
+#endif
+
+        // ---- MFMA phase: wave (rp, pg) owns local rows 2rp, 2rp+1 and two of the four output parities
+#ifdef EFE_X_FLIP             // experiment: heavy (5 tap-tiles) / light (4) roles alternate every strip
+        const int pg = ((NW == 8 ? (w ^ (w >> 2)) : w) ^ s) & 1;
+#endif
+#pragma unroll 1
+        for (int pi = 0; pi < 2; ++pi) {
+            const int par = pg ? (pi ? 2 : 1) : (pi ? 0 : 3);          // pg0: (1,1),(0,0)   pg1: (0,1),(1,0)
+            const int ph = par >> 1, pw = par & 1;
+            f32x16 acc[RW];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {                            // the accumulators start at the layer-3 bias:
+                const float4 bb = sb3[2 * g4 + h];                      // register e holds channel (e&3) + 8*(e>>2) + 4h
+#pragma unroll
+                for (int nt = 0; nt < RW; ++nt) { acc[nt][4 * g4] = bb.x; acc[nt][4 * g4 + 1] = bb.y; acc[nt][4 * g4 + 2] = bb.z; acc[nt][4 * g4 + 3] = bb.w; }
+            }
+            f32x16 (&acc1)[1][RW] = reinterpret_cast<f32x16 (&)[1][RW]>(acc);
+            tap_loop<1, RW>(acc1, (1 + ph) * (1 + pw), W3, sm, h, ConvT2Addr<RW>{ph, pw, RW * rp, 1, j, 8, 32, DB_ZERO}, ConvWIdx{});
+            TLB(2);
+            // ---- ReLU in registers (a plain VALU instruction costs ~19 cycles of wave time while the co-resident wave streams
+            // MFMAs: the bias add is folded into the accumulator init), then contract channels against the 9 taps of the final conv with the 4-block form
+            // v_mfma_f32_16x16x1_4b_f32: block = lane>>4 = (channel half h)*2 + (pixel half), so the accumulator register e
+            // is again the B operand as it stands; A[i = lane&15] = W4[tap i][co(e, h)].  16 instructions x 32 cycles per
+            // tile (half the cost of the 32x32x2 form, whose 32 tap rows would be 72 % padding); the two tiles' dependent
+            // chains are interleaved.
+            f32x16 T2[RW];
+#pragma unroll
+            for (int nt = 0; nt < RW; ++nt) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)            // ReLU as ONE integer max on the bit pattern (fmaxf on a raw MFMA result
+                    acc[nt][e] = relu_bits(acc[nt][e]);  // costs a second, canonicalising v_max_f32)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) T2[nt][e] = 0.f;
+            }
+#ifdef EFE_X_NO_TMFMA        // timing experiment (wrong results): no tap-plane contraction
+#pragma unroll
+            for (int nt = 0; nt < RW; ++nt) T2[nt] = acc[nt];
+#else
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+#pragma unroll
+                for (int nt = 0; nt < RW; ++nt) T2[nt] = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[nt][e], T2[nt], 0, 0, 0);
+            }
+#endif
+#pragma unroll
+            for (int nt = 0; nt < RW; ++nt) {
+                const f32x16 T = T2[nt];
+                // D layout: T[4b + r] = D_b[row = 4*(lane>>4) + r][col = lane&15]; pixel p = 16*(b&1) + col, and the two
+                // channel halves (b, b+2) of the same pixel sit in the same lane: add them.
+#ifdef EFE_X_NO_TWRITE        // timing experiment (wrong results): no tap-plane LDS writes
+                if (T[0] == 12345.678f) sT[lane] = T[1];
+                continue;
+#endif
+                const int tq = lane >> 4, c = lane & 15;               // this lane holds taps 4*tq + r
+                const int orow = 2 * (SR * s + RW * rp + nt) + ph;
+#ifdef EFE_X_TAP3
+                float* tp3 = sT + ((orow % DB_YROWS) * 9 + 3 * tq) * TS + 1 + pw;
+                if (tq < 3) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 3; ++r4) {
+                        tp3[r4 * TS + 2 * c] = T[r4] + T[8 + r4];
+                        tp3[r4 * TS + 2 * (16 + c)] = T[4 + r4] + T[12 + r4];
+                    }
+                }
+                continue;
+#endif
+                float* tp = sT + ((orow % DB_YROWS) * 9 + 4 * tq) * TS + 1 + pw;
+                if (tq < 2) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        tp[r4 * TS + 2 * c] = T[r4] + T[8 + r4];
+                        tp[r4 * TS + 2 * (16 + c)] = T[4 + r4] + T[12 + r4];
+                    }
+                } else if (tq == 2) {
+                    tp[2 * c] = T[0] + T[8];
+                    tp[2 * (16 + c)] = T[4] + T[12];
+                }
+            }
+            TLB(3);
+        }
+        __syncthreads();
+        TLB(4);
+#ifdef EFE_X_PF_LATE          // experiment: request strip s+1 after the MFMA phase (vmcnt retires in order: issued before the tap loops, the
+        {                     // HBM loads sit in front of every weight-fragment wait of the strip); the gather covers their latency
+            const int sn = (s < NS - 1) ? s + 1 : NS - 1;
+#pragma unroll
+            for (int it = 0; it < NPF; ++it) {
+                const int idx = it * NTHR + tid;
+                const int grow = min(SR * sn + (idx >> 9), 31);
+                pf[it] = Xv[y2_at(grow, idx)];
+            }
+        }
+#endif
+
+        // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete now (row 63 after the last strip).  One output row
+        // per wave and pass (row index wave-uniform: scalar branches only), 9 unconditional LDS reads per pixel -- the zero
+        // pad columns stand in for the out-of-image taps, adding 0.f leaves the fp32 sum unchanged.
+        const int nq = (a.dbg & 2) ? 0 : (s == NS - 1) ? RW + 1 : RW;
+        for (int q = 0; q < nq; ++q) {
+            if (q == RW && w != 0) break;
+            const int oh = 2 * SR * s - 1 + q * NW + w, ow = lane;
+            if (oh < 0) continue;
+            float tv[9];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int tr = oh + 1 - kh;
+                const bool rv = tr >= 0 && tr <= 63;
+                const float* trow = sT + (((rv ? tr : 0) % DB_YROWS) * 9 + kh * 3) * TS + ow + 2;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) tv[kh * 3 + kw] = rv ? trow[kw * TS - kw] : 0.f;
+            }
+            float v = a.b4;
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) v += tv[t9];
+            const float pr = 1.0f / (1.0f + EFE_EXP(-v));
+            if (po) {           // address rebuilt here from a laundered lane index: hoisted out of the strip loop it is a spilled VGPR pair
+                int owl = ow; asm volatile("" : "+v"(owl));
+                (po + oh * 64)[owl] = pr;
+            }
+            if (mode == 0) part += -(1.0f - pr) * EFE_LOG(D1 - pr) - pr * EFE_LOG(D0 + pr);
+            else           // target = 1 for image rows h < 32, 0 below (NCHW broadcast of the port)
+                part += (oh < 32) ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f) : pr * logf(D0) + (1.0f - pr) * logf(D1);
+        }
+        // no barrier here: the next strip's staging only touches the input buffer (all waves are past the MFMA
+        // phase), and its T writes come after the next barrier, i.e. after every thread finished this gather.
+        TLB(5);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) sred[w] = part;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = sred[0] + sred[1];              // fixed order: (s0 + s1) + (s2 + s3) + ...
+#pragma unroll
+        for (int i = 2; i < NW; i += 2) tot += sred[i] + sred[i + 1];
+        a.val[mg] = tot;
+    }
+#ifdef EFE_PHASE_CLK
+    TLB(6);
+    if (a.tl && tid == 0)
+        for (int i = 0; i < 8; ++i) a.tl[(size_t)blockIdx.x * 8 + i] = phs[i];
+#endif
+}
+
+// DPP row shifts of one fp32 register inside 16-lane rows (measured semantics, tools/ubench/dpp_probe.hip): shr1: lane i <- lane i - 1,
+// shl1: lane i <- lane i + 1; lanes without a source are zero (_zero) or keep `old` (_keep); ror1: lane i <- lane (i - 1) & 15, ror15: <- (i + 1) & 15
+__device__ __forceinline__ float dpp_shr1_zero(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true)); }
+__device__ __forceinline__ float dpp_shl1_zero(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, true)); }
+__device__ __forceinline__ float dpp_shr1_keep(float old, float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_shl1_keep(float old, float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, false)); }
+__device__ __forceinline__ float wave_shr1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true)); }   // lane i <- i - 1 over the wave
+__device__ __forceinline__ float wave_shl1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true)); }   // lane i <- i + 1
+__device__ __forceinline__ float dpp_ror1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_ror15(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x12f, 0xf, 0xf, false)); }
+
 // ---------------------------------------------------------------------------------------------------------
 // k_dec_b4: the same layer pair, INPUT-STATIONARY.  One wave owns one input row of the strip (32 positions) and ALL FOUR output
 // parities of it.  The nine (kh, kw) taps of the stride-2 transposed conv read only four shifted views of the input,
@@ -203,7 +545,13 @@ void launch_dec_a(const DecAArgs& a, hipStream_t st) {
 // weights re-read from LDS, channel halves merged with a cross-lane add: 50 KiB LDS) all land on the same 5.96-5.98 ms per 19200
 // images; the per-strip index laundering alone costs 2-3 % at two waves.  The shader clock is at 2.38 GHz in steady state (it
 // ramps from 2.05 GHz over the first four launches after idle): the kernel is not clock- or power-limited.
-__global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
+#ifndef EFE_B4_WAVES
+#define EFE_B4_WAVES 2
+#endif
+#if !defined(EFE_B4_T16) && !defined(EFE_B4_T4X4)
+#define EFE_B4_T4X4 1        // tap contraction of the 32 -> 1 conv: 16-block 4x4x1 MFMA (default, 0.826 alone) or 4-block 16x16x1 (EFE_B4_T16, 0.812)
+#endif
+__global__ void __launch_bounds__(256, EFE_B4_WAVES) k_dec_b4(const DecBArgs a) {
     constexpr int SR = 4, NW = 4, NTHR = 256;
     constexpr int DB_ZERO = (SR + 1) * 32;
     constexpr int DB_IN_F4 = (DB_ZERO + 1) * 16;
@@ -239,6 +587,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
         const float4 q = tv_ ? reinterpret_cast<const float4*>(a.w4 + (3 * (ti_ >> 2) + (ti_ & 3)) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
         w4f[4 * g4] = q.x; w4f[4 * g4 + 1] = q.y; w4f[4 * g4 + 2] = q.z; w4f[4 * g4 + 3] = q.w;
     }
+#ifdef EFE_B4_T4X4
     // 16-block 4x4x1 form of the tap contraction: block = 4 consecutive lanes = 4 pixels of one channel half, A row i = lane & 3 = kw,
     // one instruction per (kh, accumulator register): 3 x 16 A registers, 12 tap rows (9 used) instead of 16
     float w4g[3][16];
@@ -249,6 +598,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
             const float4 q = ((lane & 3) < 3) ? reinterpret_cast<const float4*>(a.w4 + (3 * kh + (lane & 3)) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
             w4g[kh][4 * g4] = q.x; w4g[kh][4 * g4 + 1] = q.y; w4g[kh][4 * g4 + 2] = q.z; w4g[kh][4 * g4 + 3] = q.w;
         }
+#endif
     if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const float4* X = reinterpret_cast<const float4*>(a.y2) + (size_t)img * (32 * 32 * 16);
@@ -337,6 +687,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
             }
         }
         // ---- ReLU, then the 32 -> 1 conv as tap planes: 16 x v_mfma_f32_16x16x1_4b per parity, the four parities' chains interleaved
+#ifdef EFE_B4_T4X4
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             f32x4 Tq[2][3];                                  // [column parity][kh]: registers kw = 0..2 (3 = padding) of this lane's pixel and channel half
@@ -367,6 +718,60 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 *reinterpret_cast<float2*>(hp + kh * 64) = eo;
             }
         }
+#else
+        // one output-row parity ph (two column parities) at a time: 2 x 16 tap-plane registers live instead of 4 x 16
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            f32x16 T0, T1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[2 * ph][e] = relu_bits(acc[2 * ph][e]); acc[2 * ph + 1][e] = relu_bits(acc[2 * ph + 1][e]);
+                T0[e] = 0.f; T1[e] = 0.f;
+            }
+#ifdef EFE_X_NO_TMFMA
+            T0 = acc[2 * ph]; T1 = acc[2 * ph + 1];
+#else
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                T0 = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[2 * ph][e], T0, 0, 0, 0);
+                T1 = __builtin_amdgcn_mfma_f32_16x16x1f32(w4f[e], acc[2 * ph + 1][e], T1, 0, 0, 0);
+            }
+#endif
+#ifdef EFE_X_NO_TWRITE
+            if (T0[0] == 12345.678f) sH[lane] = T0[1] + T1[2];
+#else
+            {
+                // D layout of the 4-block MFMA: T[4 b + r] = D_b[row 4 (lane >> 4) + r][col lane & 15], block b = (channel half) * 2 + (pixel half):
+                // lane (kh = lane >> 4, c = lane & 15) holds taps (kh, kw = r) of input columns c (regs 0-2, 8-10) and 16 + c (regs 4-6, 12-14);
+                // T0 / T1 = column parity 0 (x = 2 c') / 1 (x = 2 c' + 1)
+                const int kh = lane >> 4, c = lane & 15;
+                float X0[2][3], X1[2][3];                                   // [column half][kw], channel halves added
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        X0[hb][kw] = T0[4 * hb + kw] + T0[8 + 4 * hb + kw];
+                        X1[hb][kw] = T1[4 * hb + kw] + T1[8 + 4 * hb + kw];
+                    }
+                // out column 2c'   takes kw = 0 from x = 2c' + 1, kw = 1 from x = 2c', kw = 2 from x = 2c' - 1 (odd column of c' - 1)
+                // out column 2c'+1 takes kw = 0 from x = 2c' + 2 (even column of c' + 1), kw = 1 from x = 2c' + 1, kw = 2 from x = 2c'
+                const float l0 = dpp_shr1_zero(X1[0][2]);                                  // c' - 1 for c' = 0..15 (c' = 0: image edge)
+                const float l1 = dpp_shr1_keep(dpp_ror1(X1[0][2]), X1[1][2]);              // c' = 16: column 15 lives in lane 15 of the first half
+                const float r0 = dpp_shl1_keep(dpp_ror15(X0[1][0]), X0[0][0]);             // c' = 15: column 16 lives in lane 0 of the second half
+                const float r1 = dpp_shl1_zero(X0[1][0]);                                  // c' = 31: image edge
+                float2 e0, e1;
+                e0.x = (X1[0][0] + X0[0][1]) + l0;  e0.y = (r0 + X1[0][1]) + X0[0][2];
+                e1.x = (X1[1][0] + X0[1][1]) + l1;  e1.y = (r1 + X1[1][1]) + X0[1][2];
+                if (kh < 3) {
+                    const int orow = 2 * (SR * s + w) + ph;
+                    float* hp = sH + ((orow % DB_YROWS) * 3 + kh) * 64 + 2 * c;
+                    *reinterpret_cast<float2*>(hp) = e0;
+                    *reinterpret_cast<float2*>(hp + 32) = e1;
+                }
+            }
+#endif
+        }
+#endif
         __syncthreads();
         {   // request strip s+1 behind the MFMA phase (vmcnt retires in order: an HBM load in front of the weight-fragment loads stalls them)
             const int sn = (s < NS - 1) ? s + 1 : NS - 1;
@@ -380,7 +785,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
 
         // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete (row 63 after the last strip)
         constexpr int RWG = 2 * SR / NW;
-        const int nq = (s == NS - 1) ? RWG + 1 : RWG;
+        const int nq = (a.dbg & 2) ? 0 : (s == NS - 1) ? RWG + 1 : RWG;
         for (int q = 0; q < nq; ++q) {
             if (q == RWG && w != 0) break;
             const int oh = 2 * SR * s - 1 + q * NW + w, ow = lane;
@@ -391,16 +796,21 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
             for (int kh = 0; kh < 3; ++kh) {
                 const int tr = oh + 1 - kh;
                 const bool rv = tr >= 0 && tr <= 63;
+#ifdef EFE_B4_T4X4
                 const float* hq = sH + ((((rv ? tr : 0) % DB_YROWS) * 2) * 3 + kh) * 64 + ow;
                 v += rv ? hq[0] + hq[3 * 64] : 0.f;          // the two channel halves
+#else
+                v += rv ? sH[(((rv ? tr : 0) % DB_YROWS) * 3 + kh) * 64 + ow] : 0.f;
+#endif
             }
-            const float pr = 1.0f / (1.0f + expf(-v));
+            const float pr = 1.0f / (1.0f + EFE_EXP(-v));
             if (po) {
                 int owl = ow; asm volatile("" : "+v"(owl));
                 (po + oh * 64)[owl] = pr;
             }
-            if (mode == 0) part += -(1.0f - pr) * logf(D1 - pr) - pr * logf(D0 + pr);
-            else part += reward_term(pr, oh, ow, 64, 64, a.reward_intent);
+            if (mode == 0) part += -(1.0f - pr) * EFE_LOG(D1 - pr) - pr * EFE_LOG(D0 + pr);
+            else
+                part += (oh < 32) ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f) : pr * logf(D0) + (1.0f - pr) * logf(D1);
         }
     }
 #pragma unroll
@@ -410,14 +820,32 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     if (tid == 0) a.val[mg] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
-constexpr size_t DB_LDS4H = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 2 * 3 * 64 * sizeof(float);  // input strip + H planes per channel half
+constexpr size_t DB_LDS4 = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 66 * sizeof(float);
+#ifdef EFE_B4_T4X4
+constexpr size_t DB_LDS4H = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 2 * 3 * 64 * sizeof(float);  // k_dec_b4: H planes per channel half
+#else
+constexpr size_t DB_LDS4H = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 3 * 64 * sizeof(float);      // k_dec_b4: H planes instead of tap planes
+#endif
 int init_dec_b_kernels() {
     if (hipFuncSetAttribute((const void*)(k_dec_b4), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4H) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)(k_dec_b<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)(k_dec_b<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4) != hipSuccess) return 1;
     return 0;
 }
 
 void launch_dec_b(const DecBArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_dec_b4, dim3(a.rows), dim3(256), DB_LDS4H, st, a);
+    const size_t lds4 = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 9 * 66 * sizeof(float);
+    const size_t lds2 = ((3 * 32 + 1) * 16) * sizeof(float4) + 6 * 9 * 66 * sizeof(float);
+    if (!(a.dbg & (8 | 16 | 64))) {     // default: input-stationary form, one wave = one strip row x four parities, H planes (0.81 of the fp32 MFMA peak alone)
+        hipLaunchKernelGGL(k_dec_b4, dim3(a.rows), dim3(256), DB_LDS4H, st, a);
+    } else if (a.dbg & 64) {           // round-1 default: 2-row strips, four one-row waves per workgroup, 38 KiB LDS: four workgroups (four independent
+                                // barrier domains) and 16 waves per CU.  Measured 0.795 of the fp32 MFMA peak (k_dec_b alone, 19200 images)
+        hipLaunchKernelGGL((k_dec_b<2, 1>), dim3(a.rows), dim3(256), lds2, st, a);
+    } else if (a.dbg & 8) {     // 4-row strips, eight one-row waves, two workgroups per CU: 0.767
+        hipLaunchKernelGGL((k_dec_b<4, 1>), dim3(a.rows), dim3(512), lds4, st, a);
+    } else {                    // 4-row strips, four two-row waves (8 waves per CU): 0.738
+        hipLaunchKernelGGL((k_dec_b<4, 2>), dim3(a.rows), dim3(256), lds4, st, a);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -51,18 +51,6 @@ __device__ __forceinline__ bool row_live(const RowMask& k, int m) {
     return !k.mask || k.mask[((k.m0 + m) % k.rows_per_group) / k.div] != 0;
 }
 
-// One pixel's term of the reward log-likelihood log_bernoulli(x = pr, p = target) (/root/reference/src/torchutils.py:30-37):
-//   intent 0: what the shipped port computes -- on NCHW input the target broadcasts to 1 for image rows oh < H / 2 and 0 below, and
-//             every pixel counts (pinned by the oracle);
-//   intent 1: what the upstream NHWC code means -- only the top three rows (the reward bar) count, with target 1
-//             on their left half and 0 on the right half.
-__device__ __forceinline__ float reward_term(float pr, int oh, int ow, int H, int W, int intent) {
-    const float D1 = 1.00001f, D0 = 0.00001f;
-    const bool one = intent ? (ow < W / 2) : (oh < H / 2);
-    const float t = one ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f) : pr * logf(D0) + (1.0f - pr) * logf(D1);
-    return (intent && oh >= 3) ? 0.0f : t;
-}
-
 struct GemmArgs {
     const float* Wp;      // packed weights [tap][mtile][kc][64 lanes][4]
     const float* bias;    // [mtiles*32]
@@ -93,6 +81,8 @@ struct DecAArgs {
     int rows;
     RowMask live;
     int* queue;           // zero-initialised ticket counter of this launch: images beyond the first two per workgroup are claimed dynamically
+    int dbg;              // experiments only (0 in production): 2 = skip next-image prefetch, 4 = eight-wave workgroups
+    long long* tl;        // timeline experiments only (EFE_TIMELINE builds): s_memtime stamps of workgroup 0 / wave 0
 };
 // fused decoder, stage B: y2 -> ConvT(64,32,s2)+ReLU -> ConvT(32,1,s1)+Sigmoid -> per-image reduction (+ image store)
 struct DecBArgs {
@@ -108,7 +98,9 @@ struct DecBArgs {
     int store0;           // groups with pidx == 0 store their image at slot t*S + sample
     float* val;           // [batch] per-image pixel sum (entropy sum, or log-likelihood sum)
     float* po;            // [slots][rows_per_group][4096] stored images
-    int reward_intent;    // 0 = the shipped port's NCHW-broadcast reward target, 1 = the upstream-intent variant (reward_term below)
+    int* queue;           // k_dec_b4: zero-initialised ticket counter of this launch (images beyond the first per workgroup are claimed dynamically)
+    int dbg;              // experiments only: 2 = skip gather/epilogue math, 8 = 4-row strips / 8 waves, 16 = 4-row strips / 4 waves
+    long long* tl;        // EFE_PHASE_CLK builds only: per-workgroup phase cycle sums [rows][8]
 };
 // fused encoder trunk: o [rows][64][64] -> conv1..conv4 (+ReLU) -> out [rows][576] in NHWC (p*64 + c) order
 struct EncArgs {
@@ -210,31 +202,15 @@ struct ConvGArgs {
     int relu;
     int ldo;                          // floats per output pixel
     RowMask live;                     // LDS-tiled ConvT kernels only (the decoder's layers)
+    int dbg;                          // development switches (engine option dbg_b): 1 one weight slab, 2 no stores, 4 no strip loads -- wrong results, timing only
 };
 void launch_conv_g(const ConvGArgs& a, hipStream_t st);
-bool convt_p_ok(const ConvGArgs& a);                            // generic_dec.hip: the LDS-tiled ConvTranspose kernel takes this layer
-void launch_convt_p(const ConvGArgs& a, hipStream_t st);
-// fused last two decoder layers of the generic path (generic_dec.hip): y2 [rows][Hin * Win][64] NHWC -> per-image sums (+ stored images)
-struct DecBGArgs {
-    const float* y2;
-    const float* w3; const float* b3;   // packed [9][1][8][64][4], bias [32]
-    const float* w4; float b4[4];       // [9 taps][32 ci][4 c], bias
-    int rows, m0, rows_per_group, Hin, Win, C;
-    int TH; unsigned magicW;            // set by launch_dec_bg: input rows per strip, ceil(2^32 / Wout)
-    GroupMap gm;
-    int reward0, store0, reward_intent;
-    RowMask live;
-    float* val;                         // [batch] per-image sums
-    float* po;                          // [slots][rows_per_group][Hout * Wout][8] stored images (NHWC, channels padded to 8)
-};
-int launch_dec_bg(DecBGArgs a, hipStream_t st);                 // non-zero: geometry outside the kernel's limits
-int init_generic_dec_kernels();
 struct FinalGArgs {
     const float* y3;                  // [rows][H*W][32]
     const float* w; float b[4];       // [9 taps][32 ci][4 c], bias
     int rows, m0, rows_per_group, H, W, C;
     GroupMap gm;
-    int reward0, store0, reward_intent;
+    int reward0, store0;
     RowMask live;
     float* val;                       // [batch] per-image sums
     float* po;                        // [slots][rows_per_group][H*W][8] stored images (NHWC, channels padded to 8)
@@ -243,7 +219,7 @@ int launch_final_g(const FinalGArgs& a, hipStream_t st);       // non-zero: geom
 int init_generic_kernels();
 void launch_to_nhwc8(const float* in, float* out, long M, int HW, int C, hipStream_t st);
 void launch_to_nchw(const float* in, float* out, long M, int HW, int C, hipStream_t st);
-void launch_check_reward_g(const float* o, float* out, int M, int C, int H, int W, int intent, hipStream_t st);
+void launch_check_reward_g(const float* o, float* out, int M, int C, int H, int W, hipStream_t st);
 
 void launch_pack_x(const float* pi, const float* s, float* x, int R, int pi_dim, int s_dim, hipStream_t st);
 void launch_pad16(const float* s, float* x, int R, int s_dim, hipStream_t st);
@@ -261,7 +237,7 @@ void launch_mean_rows(const float* G, float* out, int E, int T, hipStream_t st);
 void launch_fill_tr(const float* mean, const float* logvar, float* tr, int R, hipStream_t st);
 void launch_posterior(const float* sumG, float* P, float* logP, int n_groups, int n, float temperature, hipStream_t st);
 
-void launch_check_reward(const float* o, float* out, int M, int intent, hipStream_t st);
+void launch_check_reward(const float* o, float* out, int M, hipStream_t st);
 void launch_reparam(const float* mean, const float* logvar, const float* eps_inj, float* out, int M, int n, uint32_t k0, uint32_t k1,
                     uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, hipStream_t st);
 void launch_env_step(float* state, float* last_r, const int* actions, int* round_changed, int E, int repeats,

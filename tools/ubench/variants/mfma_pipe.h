@@ -40,18 +40,6 @@ __device__ __forceinline__ float relu_bits(float x) {
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
-// DPP row shifts of one fp32 register inside 16-lane rows (measured semantics, tools/ubench/dpp_probe.hip): shr1: lane i <- lane i - 1,
-// shl1: lane i <- lane i + 1; lanes without a source are zero (_zero) or keep `old` (_keep); ror1: lane i <- lane (i - 1) & 15, ror15: <- (i + 1) & 15
-__device__ __forceinline__ float dpp_shr1_zero(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true)); }
-__device__ __forceinline__ float dpp_shl1_zero(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, true)); }
-__device__ __forceinline__ float dpp_shr1_keep(float old, float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, false)); }
-__device__ __forceinline__ float dpp_shl1_keep(float old, float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), 0x101, 0xf, 0xf, false)); }
-__device__ __forceinline__ float wave_shr1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true)); }   // lane i <- i - 1 over the wave
-__device__ __forceinline__ float wave_shl1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, true)); }   // lane i <- i + 1
-__device__ __forceinline__ float dpp_ror1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false)); }
-__device__ __forceinline__ float dpp_ror15(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x12f, 0xf, 0xf, false)); }
-
-
 __device__ __forceinline__ int swz(int pix, int c4) { return pix * 16 + (c4 ^ (pix & 15)); }   // float4 index
 
 // Software-pipelined contraction over `ntaps` taps x 64 input channels (8 chunks of 8): the A fragments (weights,
@@ -125,10 +113,16 @@ struct TapPipe {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) av[mt] = aq[kc % PD][mt];
                 // chunk kc + PD of this tap, or chunk kc + PD - KC of the next one, replaces the slot just consumed
+#ifndef EFE_DBG_NO_A          // timing experiment: skip the weight-fragment loads (wrong results)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     aq[kc % PD][mt] = (kc + PD < KC) ? wfrag(wr, ln, widx.template at<MT>(wt, mt, kc + PD))
                                                      : wfrag(wr, ln, widx.template at<MT>(nwt, mt, kc + PD - KC));
+#endif
+#ifdef EFE_DBG_NO_B           // timing experiment: skip the LDS activation-fragment reads (wrong results)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bn[nt] = bv[nt];
+#else
                 if (kc < KC - 1) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[bs[nt] + ((2 * (kc + 1) + h) ^ sw[nt])];
@@ -136,11 +130,31 @@ struct TapPipe {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) bn[nt] = sm[nbs[nt] + (h ^ nsw[nt])];
                 }
+#endif
+#ifndef EFE_SCHED_SPREAD
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch loads AHEAD of this chunk's MFMAs (hipcc sinks them otherwise)
+#endif
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) { MFMA4(acc[mt][nt], av[mt], bv[nt]) }
+#ifdef EFE_SCHED_SPREAD
+                // one prefetch instruction behind each of the first MFMAs instead of a cluster in front of them
+#pragma unroll
+                for (int q = 0; q < MT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, EFE_SCHED_SPREAD, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, EFE_SCHED_SPREAD, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT * 4 - MT - NT, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
             }
