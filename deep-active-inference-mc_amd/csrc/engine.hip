@@ -523,9 +523,9 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
     }
     TermsArgs ta{};
     ta.val = val; ta.tr = tr_all; ta.enc = enc; ta.D = D; ta.S = S; ta.R = R;
-    // term0 of an image = its pixel sum * scale: 10 * mean over the pixels that count (torchmodel.py:212: all 4096, or the 192 bar pixels of the
+    // term0 of an image = 10 * mean over the pixels that count (torchmodel.py:212: all 4096, or the 192 bar pixels of the
     // upstream-intent variant); the generic geometries use the sum form of the reference's resolution-32 branch (torchmodel.py:214)
-    ta.reward_scale = ctx->generic ? 1.0f : (ctx->reward_intent ? 10.0f / 192.0f : 10.0f / 4096.0f);
+    ta.reward_div = ctx->generic ? 0.0f : (ctx->reward_intent ? 192.0f : 4096.0f);
     ta.G = io.G; ta.terms = io.terms ? io.terms : terms_tmp; ta.t2parts = io.t2parts;
     launch_terms(ta, st);
     if (io.po1) {

@@ -147,7 +147,8 @@ struct TermsArgs {
     const float* tr;       // [D][2S][R][32]
     const float* enc;      // [D][S][R][32]
     int D, S, R;
-    float reward_scale;    // term0 per image = pixel sum * reward_scale: 10 / 4096 (mean over pixels * 10, torchmodel.py:212) for dSprites, 1 for the sum form
+    float reward_div;      // term0 per image = pixel sum / reward_div * 10 (mean over the counted pixels * 10, torchmodel.py:212: 4096, or the 192 bar
+                           // pixels of the upstream-intent target); 0 = the sum form of the generic geometries
     float* G;              // [R] summed over stages
     float* terms;          // [3][R] summed over stages
     float* t2parts;        // nullable [2][R]: term2_1, term2_2 (last stage; diagnostics)

@@ -260,8 +260,8 @@ __global__ void __launch_bounds__(256) k_terms(const TermsArgs a) {
         const float* en = a.enc + (((size_t)t * S + i) * R + r) * 32 + 10;
         float h = 0.f;
         for (int k = 0; k < 10; ++k) h += 0.5f * (C + tr[k]) + 0.5f * (C + en[k]);
-        p1s[idx * 4 + 0] = a.reward_scale == 1.0f ? val[(size_t)i * R + r]
-                                                  : val[(size_t)i * R + r] * (1.0f / 4096.0f) * 10.0f;   // mean over pixels * 10 (torchmodel.py:212)
+        p1s[idx * 4 + 0] = a.reward_div == 0.0f ? val[(size_t)i * R + r]
+                                                : val[(size_t)i * R + r] / a.reward_div * 10.0f;          // mean over the counted pixels * 10 (torchmodel.py:212)
         p1s[idx * 4 + 1] = -h;
         p1s[idx * 4 + 2] = val[(size_t)(S + i) * R + r];
         p1s[idx * 4 + 3] = val[(size_t)(2 * S + i) * R + r];
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(256) k_check_reward(const float* o, float* out
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = part;
     __syncthreads();
     // mean over the pixels that count (all 4096, or the 192 of the three bar rows) * 10
-    if (threadIdx.x == 0) out[blockIdx.x] = ((sred[0] + sred[1]) + (sred[2] + sred[3])) * (intent ? 1.0f / 192.0f : 1.0f / 4096.0f) * 10.0f;
+    if (threadIdx.x == 0) out[blockIdx.x] = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / (intent ? 192.0f : 4096.0f) * 10.0f;
 }
 void launch_check_reward(const float* o, float* out, int M, int intent, hipStream_t st) {
     hipLaunchKernelGGL(k_check_reward, dim3(M), dim3(256), 0, st, o, out, intent);
