@@ -281,6 +281,14 @@ void launch_convt_p(const ConvGArgs& a, hipStream_t st) {
 // element.  A tile boundary that falls inside an image row splits one horizontal sum between two waves: the boundary lanes
 // export their half to a small edge array and the gather adds it for the two output columns concerned.
 // ---------------------------------------------------------------------------------------------------------
+// sigmoid and the two logarithms of a pixel with the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each): the
+// libm forms are ~50 VALU instructions per output element, and this geometry has C = 3 outputs per pixel (on the dSprites kernels the
+// accurate forms stay: parity pinned, one output per pixel).  Error: |x| 2^-24 relative on e^-x, i.e. < 5e-7 absolute on the sigmoid
+// for |x| < 30, and < 2 ulp on the logarithms -- inside the fp32 tolerances of tests/test_generic_geometry.py, which compare against
+// the libm-evaluated oracle.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+template <int C>
 __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     extern __shared__ float4 sm[];                    // [RPa ring slots + 16 zero slots][17], then H planes, then edge values
     __shared__ float sred[4];
@@ -289,7 +297,8 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int Win = a.Win, Hin = a.Hin, TH = a.TH, C = a.C, NG = 3 * C;
+    constexpr int NG = 3 * C;
+    const int Win = a.Win, Hin = a.Hin, TH = a.TH;
     const int Wout = 2 * Win, Hout = 2 * Hin;
     const int SPX = TH * Win, RP = (TH + 1) * Win, RPa = (RP + 15) & ~15, ZP = RPa;
     const int RING = 2 * TH + 2;
@@ -353,7 +362,6 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     const unsigned ln = (unsigned)lane * 16u;
     auto wf = [&](int tap, int kc) -> float4 { return wfrag(wr, ln, (size_t)(tap * 8 + kc) * 64); };
     const float D1 = 1.00001f, D0 = 0.00001f;
-    const float bias4[3] = {a.b4[0], a.b4[1], a.b4[2]};
     float part = 0.f;
     const int NS = (Hin + TH - 1) / TH;
     int bs = 0;                                        // ring slot of pixel (r0, 0)
@@ -457,7 +465,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
                 float2 eo;
                 eo.x = (T1[3 * t] + T0[3 * t + 1]) + l;
                 eo.y = (rr + T1[3 * t + 1]) + T0[3 * t + 2];
-                if (qv && G < NG) {
+                if (qv && G < NG) {         // (qv is false only for the last lanes of the last tile when Win does not divide 128)
                     *reinterpret_cast<float2*>(hp + G * Wout) = eo;
                     if (j == 31) ep[G * 8] = T1[3 * t + 2];          // for output column 2 (ix + 1) of the next tile's first lane
                     if (j == 0) ep[G * 8 + 4] = T0[3 * t];           // for output column 2 (ix - 1) + 1 of the previous tile's last lane
@@ -481,39 +489,40 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
                 const int orow = (int)__umulhi((unsigned)f, a.magicW);
                 const int ox = f - orow * Wout, oh = first + orow;
                 if (oh < 0 || oh >= Hout) continue;
-                float v[3] = {bias4[0], bias4[1], bias4[2]};
+                float v[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[c] = a.b4[c];
                 const int ixx = ox >> 1;
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     const int tr = oh + 1 - kh;            // y3 source row of tap row kh
-                    if (tr < 0 || tr >= Hout) continue;
-                    int hs = hb + (tr - 2 * r0);
+                    const bool rv = tr >= 0 && tr < Hout;
+                    int hs = hb + ((rv ? tr : oh) - 2 * r0);   // (an out-of-image source row reads a valid slot and adds zero)
                     if (hs < 0) hs += RING;
                     if (hs >= RING) hs -= RING;
                     const float* hq = sH + ((size_t)hs * NG + kh * C) * Wout + ox;
-                    // the horizontal sum of a pixel at a tile boundary was split between two waves
+                    // the horizontal sum of a pixel at a tile boundary was split between two waves: the other half is in the edge array
                     int lr_ = (tr >> 1) - r0;
                     if (lr_ < 0) lr_ += TH;
                     const int qq = lr_ * Win + ixx;
                     const bool needL = !(ox & 1) && (qq & 31) == 0 && ixx > 0;
                     const bool needR = (ox & 1) && (qq & 31) == 31 && ixx < Win - 1;
-                    const float* eq = sE + (hs * NG + kh * C) * 8 + (needL ? (qq >> 5) - 1 : 4 + (qq >> 5) + 1);
+                    const float* eq = sE + (hs * NG + kh * C) * 8 + (needL ? (qq >> 5) - 1 : needR ? 4 + (qq >> 5) + 1 : 0);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        if (c < C) {
-                            v[c] += hq[c * Wout];
-                            if (needL || needR) v[c] += eq[c * 8];
-                        }
+                    for (int c = 0; c < C; ++c) {
+                        const float hv = hq[c * Wout], ev = eq[c * 8];
+                        v[c] += rv ? hv : 0.0f;
+                        v[c] += (rv && (needL || needR)) ? ev : 0.0f;
+                    }
                 }
                 float p[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    if (c < C) {
-                        const float pr = 1.0f / (1.0f + expf(-v[c]));
-                        p[c] = pr;
-                        if (mode == 0) part += -(1.0f - pr) * logf(D1 - pr) - pr * logf(D0 + pr);
-                        else part += reward_term(pr, oh, ox, Hout, Wout, a.reward_intent);
-                    }
+                for (int c = 0; c < C; ++c) {
+                    const float pr = fast_sigmoid(v[c]);
+                    p[c] = pr;
+                    if (mode == 0) part += -(1.0f - pr) * __logf(D1 - pr) - pr * __logf(D0 + pr);
+                    else part += reward_term(pr, oh, ox, Hout, Wout, a.reward_intent);
+                }
                 if (po) {
                     float4* pp = reinterpret_cast<float4*>(po + ((size_t)oh * Wout + ox) * 8);
                     pp[0] = make_float4(p[0], p[1], p[2], 0.f);
@@ -550,7 +559,9 @@ static size_t dec_bg_lds(int Win, int TH, int C) {
 }
 constexpr size_t DEC_BG_MAX_LDS = 96 * 1024;
 int init_generic_dec_kernels() {
-    if (hipFuncSetAttribute((const void*)k_dec_bg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_BG_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_dec_bg<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_BG_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_dec_bg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_BG_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_dec_bg<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_BG_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_convt_p<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_P_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_convt_p<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_P_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_convt_p<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_P_MAX_LDS) != hipSuccess) return 1;
@@ -565,7 +576,10 @@ int launch_dec_bg(DecBGArgs a, hipStream_t st) {
     const size_t lds = dec_bg_lds(a.Win, a.TH, a.C);
     if (lds > DEC_BG_MAX_LDS) return 1;
     a.magicW = (unsigned)((0x100000000ull + (unsigned)(2 * a.Win) - 1) / (unsigned)(2 * a.Win));
-    hipLaunchKernelGGL(k_dec_bg, dim3((unsigned)a.rows), dim3(256), lds, st, a);
+    const dim3 grid((unsigned)a.rows), blk(256);
+    if (a.C == 1) hipLaunchKernelGGL(k_dec_bg<1>, grid, blk, lds, st, a);
+    else if (a.C == 2) hipLaunchKernelGGL(k_dec_bg<2>, grid, blk, lds, st, a);
+    else hipLaunchKernelGGL(k_dec_bg<3>, grid, blk, lds, st, a);
     return 0;
 }
 
