@@ -203,11 +203,19 @@ void launch_dec_a(const DecAArgs& a, hipStream_t st) {
 // weights re-read from LDS, channel halves merged with a cross-lane add: 50 KiB LDS) all land on the same 5.96-5.98 ms per 19200
 // images; the per-strip index laundering alone costs 2-3 % at two waves.  The shader clock is at 2.38 GHz in steady state (it
 // ramps from 2.05 GHz over the first four launches after idle): the kernel is not clock- or power-limited.
+// DEFER: the gather of a strip (sigmoid + entropy / reward terms of its 2 SR output rows: ~130 VALU instructions per wave) is not done
+// between the strip's two barriers -- where it is pure non-MFMA wave time -- but DURING THE NEXT STRIP'S CONTRACTION, in pieces
+// placed between the MFMA groups of the unrolled channel-block steps (a wave's VALU instructions issue in the shadow of its own
+// 64-cycle MFMAs).  The H-plane ring holds 4 SR + 2 rows (27.6 KiB) so that the next strip's planes do not overwrite rows still
+// being gathered; the next strip's input is requested behind the contraction's last weight-fragment request (the tap phase covers
+// its latency instead of the gather); the images of the deferred rows are stored after the strip barrier.  Per-thread summation
+// order is unchanged, so the result is bit-identical to the immediate form.
+template <bool DEFER>
 __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     constexpr int SR = 4, NW = 4, NTHR = 256;
     constexpr int DB_ZERO = (SR + 1) * 32;
     constexpr int DB_IN_F4 = (DB_ZERO + 1) * 16;
-    constexpr int DB_YROWS = 2 * SR + 2;
+    constexpr int DB_YROWS = DEFER ? 4 * SR + 2 : 2 * SR + 2;
     constexpr int NPF = (SR + 1) * 512 / NTHR;        // 10 float4s of the input strip per thread
     constexpr int NS = 32 / SR;
     extern __shared__ __attribute__((aligned(16))) float4 sm[];
@@ -231,24 +239,17 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + r) * 4096 : nullptr;
 
     if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];
-    float w4f[16];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {                   // A row i = lane & 15 holds tap (kh, kw) = (i >> 2, i & 3); rows with (i & 3) == 3 and rows 12..15 are padding
-        const int ti_ = lane & 15;
-        const bool tv_ = (ti_ & 3) < 3 && ti_ < 12;
-        const float4 q = tv_ ? reinterpret_cast<const float4*>(a.w4 + (3 * (ti_ >> 2) + (ti_ & 3)) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
-        w4f[4 * g4] = q.x; w4f[4 * g4 + 1] = q.y; w4f[4 * g4 + 2] = q.z; w4f[4 * g4 + 3] = q.w;
-    }
     // 16-block 4x4x1 form of the tap contraction: block = 4 consecutive lanes = 4 pixels of one channel half, A row i = lane & 3 = kw,
-    // one instruction per (kh, accumulator register): 3 x 16 A registers, 12 tap rows (9 used) instead of 16
-    float w4g[3][16];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 q = ((lane & 3) < 3) ? reinterpret_cast<const float4*>(a.w4 + (3 * kh + (lane & 3)) * 32)[2 * g4 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
-            w4g[kh][4 * g4] = q.x; w4g[kh][4 * g4 + 1] = q.y; w4g[kh][4 * g4 + 2] = q.z; w4g[kh][4 * g4 + 3] = q.w;
-        }
+    // one instruction per (kh, accumulator register): 3 x 16 A values per lane, 12 tap rows (9 used) instead of 16.  The 48 values depend
+    // on (lane & 3, h) only: they live in an LDS table of 8 patterns and are re-read (12 broadcast ds_read_b128) in front of every
+    // strip's tap phase instead of occupying 48 VGPRs through the contraction.
+    __shared__ float4 sW4[8 * 12];
+    if (tid < 96) {
+        const int pat = tid / 12, i4 = tid - pat * 12;           // pattern = h * 4 + kw, float4 i4 = (kh, g4)
+        const int kw = pat & 3, hh = pat >> 2, kh = i4 >> 2, g4 = i4 & 3;
+        sW4[tid] = kw < 3 ? reinterpret_cast<const float4*>(a.w4 + (3 * kh + kw) * 32)[2 * g4 + hh] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4* w4p = sW4 + (h * 4 + (lane & 3)) * 12;
     if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const float4* X = reinterpret_cast<const float4*>(a.y2) + (size_t)img * (32 * 32 * 16);
@@ -273,8 +274,53 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     //   shift A: p0 (1,1)=4  p1 (1,2)=5  p2 (2,1)=7  p3 (2,2)=8 | shift B: p1 (1,0)=3  p3 (2,0)=6 | shift C: p2 (0,1)=1  p3 (0,2)=2 | shift D: p3 (0,0)=0
     auto wf = [&](int tap, int kc) -> float4 { return wfrag(wr, ln, (size_t)(tap * 8 + kc) * 64); };
 
+    // ---- gather of output row oh (lane = column): out = b4 + H[0][oh + 1] + H[1][oh] + H[2][oh - 1] (source row r contributes to
+    // oh = r - 1 + kh), the two channel halves added here; split into pieces for the deferred form
+    constexpr int RWG = 2 * SR / NW;
+    float gh[RWG][6], gpr[RWG];
+    auto g_load = [&](int oh, int q) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int tr = oh + 1 - kh;
+            const bool rv = tr >= 0 && tr <= 63;
+            const float* hq = sH + ((((rv ? tr : 0) % DB_YROWS) * 2) * 3 + kh) * 64 + lane;
+            gh[q][2 * kh] = hq[0]; gh[q][2 * kh + 1] = hq[3 * 64];
+        }
+    };
+    auto g_sig = [&](int oh, int q) {
+        float v = a.b4;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int tr = oh + 1 - kh;
+            v += (tr >= 0 && tr <= 63) ? gh[q][2 * kh] + gh[q][2 * kh + 1] : 0.f;
+        }
+        gpr[q] = 1.0f / (1.0f + expf(-v));
+    };
+    auto g_term = [&](int oh, int q) {          // branch-free: both forms are evaluated (the reward form is four FMAs), rows above the image add zero
+        const float pr = gpr[q];
+        const float te = -(1.0f - pr) * logf(D1 - pr) - pr * logf(D0 + pr);
+        const float tw = reward_term(pr, oh, lane, 64, 64, a.reward_intent);
+        const float t = mode == 0 ? te : tw;
+        part += oh >= 0 ? t : 0.0f;
+    };
+    auto g_store = [&](int oh, int q) {
+        if (po && oh >= 0) {
+            int owl = lane; asm volatile("" : "+v"(owl));
+            (po + oh * 64)[owl] = gpr[q];
+        }
+    };
+    auto prefetch = [&](int sn, int tl) {
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int idx = it * NTHR + tl;
+            const int grow = min(SR * sn + (idx >> 9), 31);
+            pf[it] = Xv[y2_at(grow, idx)];
+        }
+    };
+
     for (int s = 0; s < NS; ++s) {
-        const int tl = tid;        // (laundering the index per strip frees ~20 VGPRs -- 168, three waves per SIMD, 4 spills -- for no gain: 0.814 vs 0.812)
+        const int tl = tid;
+        const int oh0 = 2 * SR * (s - 1) - 1 + w, oh1 = oh0 + NW;         // DEFER: this wave's two output rows of the previous strip        // (laundering the index per strip frees ~20 VGPRs -- 168, three waves per SIMD, 4 spills -- for no gain: 0.814 vs 0.812)
 #pragma unroll
         for (int it = 0; it < NPF; ++it) {
             const int idx = it * NTHR + tl;
@@ -308,6 +354,12 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[0], c0, cb) MFMA4(acc[1], c1, cb) MFMA4(acc[2], c2, cb) MFMA4(acc[3], c3, cb)
+                if constexpr (DEFER) {       // the previous strip's gather, a piece per channel-block step
+                    if (kc == 0) { g_load(oh0, 0); g_load(oh1, 1); }
+                    if (kc == 2) g_sig(oh0, 0);
+                    if (kc == 4) g_term(oh0, 0);
+                    if (kc == 6) g_sig(oh1, 1);
+                }
             }
             float4 bd;
 #pragma unroll
@@ -323,6 +375,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[1], c0, cb) MFMA4(acc[3], c1, cb)
+                if constexpr (DEFER) { if (kc == 1) g_term(oh1, 1); }
             }
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
@@ -332,11 +385,18 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                     b = sm[spC * 16 + ((2 * (kc + 1) + h) ^ (spC & 15))];
                     bd = sm[spD * 16 + ((2 * (kc + 1) + h) ^ (spD & 15))];
                 }
+                if constexpr (DEFER) { if (kc == 6) prefetch((s < NS - 1) ? s + 1 : NS - 1, tl); }       // behind the strip's last weight-fragment request
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[3], c1, cb) MFMA4(acc[2], c0, cb) MFMA4(acc[3], c2, cd)
             }
         }
         // ---- ReLU, then the 32 -> 1 conv as tap planes: 16 x v_mfma_f32_16x16x1_4b per parity, the four parities' chains interleaved
+        float w4g[3][16];
+#pragma unroll
+        for (int i4 = 0; i4 < 12; ++i4) {
+            const float4 q = w4p[i4];
+            w4g[i4 >> 2][4 * (i4 & 3)] = q.x; w4g[i4 >> 2][4 * (i4 & 3) + 1] = q.y; w4g[i4 >> 2][4 * (i4 & 3) + 2] = q.z; w4g[i4 >> 2][4 * (i4 & 3) + 3] = q.w;
+        }
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             f32x4 Tq[2][3];                                  // [column parity][kh]: registers kw = 0..2 (3 = padding) of this lane's pixel and channel half
@@ -368,39 +428,26 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
             }
         }
         __syncthreads();
-        {   // request strip s+1 behind the MFMA phase (vmcnt retires in order: an HBM load in front of the weight-fragment loads stalls them)
-            const int sn = (s < NS - 1) ? s + 1 : NS - 1;
+        if constexpr (DEFER) {
+            g_store(oh0, 0); g_store(oh1, 1);              // the deferred rows' pixels (stores behind the prefetch loads)
+            if (s == NS - 1) {                              // the last strip has no successor: its rows (and row 63) now
 #pragma unroll
-            for (int it = 0; it < NPF; ++it) {
-                const int idx = it * NTHR + tl;
-                const int grow = min(SR * sn + (idx >> 9), 31);
-                pf[it] = Xv[y2_at(grow, idx)];
+                for (int q = 0; q <= RWG; ++q) {
+                    if (q == RWG && w != 0) break;
+                    const int oh = 2 * SR * s - 1 + q * NW + w;
+                    g_load(oh, 0); g_sig(oh, 0); g_term(oh, 0); g_store(oh, 0);
+                }
             }
-        }
-
-        // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete (row 63 after the last strip)
-        constexpr int RWG = 2 * SR / NW;
-        const int nq = (s == NS - 1) ? RWG + 1 : RWG;
-        for (int q = 0; q < nq; ++q) {
-            if (q == RWG && w != 0) break;
-            const int oh = 2 * SR * s - 1 + q * NW + w, ow = lane;
-            if (oh < 0) continue;
-            // out[oh][ow] = b4 + H[0][oh + 1][ow] + H[1][oh][ow] + H[2][oh - 1][ow]   (source row r contributes to oh = r - 1 + kh)
-            float v = a.b4;
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int tr = oh + 1 - kh;
-                const bool rv = tr >= 0 && tr <= 63;
-                const float* hq = sH + ((((rv ? tr : 0) % DB_YROWS) * 2) * 3 + kh) * 64 + ow;
-                v += rv ? hq[0] + hq[3 * 64] : 0.f;          // the two channel halves
+        } else {
+            prefetch((s < NS - 1) ? s + 1 : NS - 1, tl);   // behind the MFMA phase (vmcnt retires in order: an HBM load in front of the weight-fragment loads stalls them)
+            // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete (row 63 after the last strip)
+            const int nq = (s == NS - 1) ? RWG + 1 : RWG;
+            for (int q = 0; q < nq; ++q) {
+                if (q == RWG && w != 0) break;
+                const int oh = 2 * SR * s - 1 + q * NW + w;
+                if (oh < 0) continue;
+                g_load(oh, 0); g_sig(oh, 0); g_term(oh, 0); g_store(oh, 0);
             }
-            const float pr = 1.0f / (1.0f + expf(-v));
-            if (po) {
-                int owl = ow; asm volatile("" : "+v"(owl));
-                (po + oh * 64)[owl] = pr;
-            }
-            if (mode == 0) part += -(1.0f - pr) * logf(D1 - pr) - pr * logf(D0 + pr);
-            else part += reward_term(pr, oh, ow, 64, 64, a.reward_intent);
         }
     }
 #pragma unroll
@@ -410,14 +457,17 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     if (tid == 0) a.val[mg] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
-constexpr size_t DB_LDS4H = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 2 * 3 * 64 * sizeof(float);  // input strip + H planes per channel half
+constexpr size_t DB_LDS4H = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 2 * 3 * 64 * sizeof(float);  // input strip + H planes per channel half (2 SR + 2 rows)
+constexpr size_t DB_LDS4D = ((5 * 32 + 1) * 16) * sizeof(float4) + 18 * 2 * 3 * 64 * sizeof(float);  // deferred gather: 4 SR + 2 rows
 int init_dec_b_kernels() {
-    if (hipFuncSetAttribute((const void*)(k_dec_b4), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4H) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)(k_dec_b4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4H) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)(k_dec_b4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4D) != hipSuccess) return 1;
     return 0;
 }
 
 void launch_dec_b(const DecBArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_dec_b4, dim3(a.rows), dim3(256), DB_LDS4H, st, a);
+    if (a.defer) hipLaunchKernelGGL(k_dec_b4<true>, dim3(a.rows), dim3(256), DB_LDS4D, st, a);
+    else hipLaunchKernelGGL(k_dec_b4<false>, dim3(a.rows), dim3(256), DB_LDS4H, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
