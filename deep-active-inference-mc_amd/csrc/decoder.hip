@@ -278,12 +278,17 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     // oh = r - 1 + kh), the two channel halves added here; split into pieces for the deferred form
     constexpr int RWG = 2 * SR / NW;
     float gh[RWG][6], gpr[RWG];
-    auto g_load = [&](int oh, int q) {
+    // (ring slot of y3 row tr = slot hb0 of row r0y + (tr - r0y), wrapped: no division; a row outside the image reads any valid slot)
+    auto g_load = [&](int oh, int q, int r0y, int hb0) {
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int tr = oh + 1 - kh;
             const bool rv = tr >= 0 && tr <= 63;
-            const float* hq = sH + ((((rv ? tr : 0) % DB_YROWS) * 2) * 3 + kh) * 64 + lane;
+            int hs = hb0 + (tr - r0y);
+            hs = hs < 0 ? hs + DB_YROWS : hs;
+            hs = hs >= DB_YROWS ? hs - DB_YROWS : hs;
+            hs = rv ? hs : 0;
+            const float* hq = sH + ((hs * 2) * 3 + kh) * 64 + lane;
             gh[q][2 * kh] = hq[0]; gh[q][2 * kh + 1] = hq[3 * 64];
         }
     };
@@ -318,6 +323,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
         }
     };
 
+    int hb = 0, hbp = 0;                                   // H-ring slots of y3 rows 2 SR s (this strip's first) and 2 SR (s - 1)
     for (int s = 0; s < NS; ++s) {
         const int tl = tid;
         const int oh0 = 2 * SR * (s - 1) - 1 + w, oh1 = oh0 + NW;         // DEFER: this wave's two output rows of the previous strip        // (laundering the index per strip frees ~20 VGPRs -- 168, three waves per SIMD, 4 spills -- for no gain: 0.814 vs 0.812)
@@ -355,7 +361,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[0], c0, cb) MFMA4(acc[1], c1, cb) MFMA4(acc[2], c2, cb) MFMA4(acc[3], c3, cb)
                 if constexpr (DEFER) {       // the previous strip's gather, a piece per channel-block step
-                    if (kc == 0) { g_load(oh0, 0); g_load(oh1, 1); }
+                    if (kc == 0) { g_load(oh0, 0, 2 * SR * (s - 1), hbp); g_load(oh1, 1, 2 * SR * (s - 1), hbp); }
                     if (kc == 2) g_sig(oh0, 0);
                     if (kc == 4) g_term(oh0, 0);
                     if (kc == 6) g_sig(oh1, 1);
@@ -414,8 +420,9 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                     Tq[1][kh] = __builtin_amdgcn_mfma_f32_4x4x1f32(w4g[kh][e], acc[2 * ph + 1][e], Tq[1][kh], 0, 0, 0);
                 }
             // horizontal presum per channel half (the halves are added by the gather): lane = (pixel c' = lane & 31, half h)
-            const int orow = 2 * (SR * s + w) + ph;
-            float* hp = sH + (((orow % DB_YROWS) * 2 + h) * 3) * 64 + 2 * j;
+            int hsw = hb + 2 * w + ph;                       // ring slot of this wave's y3 row 2 (SR s + w) + ph
+            hsw = hsw >= DB_YROWS ? hsw - DB_YROWS : hsw;
+            float* hp = sH + ((hsw * 2 + h) * 3) * 64 + 2 * j;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 float l = wave_shr1(Tq[1][kh][2]), r = wave_shl1(Tq[0][kh][0]);
@@ -435,7 +442,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 for (int q = 0; q <= RWG; ++q) {
                     if (q == RWG && w != 0) break;
                     const int oh = 2 * SR * s - 1 + q * NW + w;
-                    g_load(oh, 0); g_sig(oh, 0); g_term(oh, 0); g_store(oh, 0);
+                    g_load(oh, 0, 2 * SR * s, hb); g_sig(oh, 0); g_term(oh, 0); g_store(oh, 0);
                 }
             }
         } else {
@@ -446,9 +453,12 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 if (q == RWG && w != 0) break;
                 const int oh = 2 * SR * s - 1 + q * NW + w;
                 if (oh < 0) continue;
-                g_load(oh, 0); g_sig(oh, 0); g_term(oh, 0); g_store(oh, 0);
+                g_load(oh, 0, 2 * SR * s, hb); g_sig(oh, 0); g_term(oh, 0); g_store(oh, 0);
             }
         }
+        hbp = hb;
+        hb += 2 * SR;
+        hb = hb >= DB_YROWS ? hb - DB_YROWS : hb;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);

@@ -366,6 +366,75 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     const int NS = (Hin + TH - 1) / TH;
     int bs = 0;                                        // ring slot of pixel (r0, 0)
     int hb = 0;                                        // H-ring slot of y3 row 2 r0
+    // ---- gather of the output elements of a strip (thread = output pixel f of rows 2 r0 - 1 .. , 256 per pass; C channels), in pieces:
+    //   g_sum  : v[c] = b4[c] + sum_kh H[kh][c] (+ the other wave's half at a tile boundary)   -- LDS reads + adds
+    //   g_sig  : sigmoid                 g_term : entropy / reward term into the thread's partial sum                g_store : image store
+    // A strip with a successor only does g_sum between its barriers (the H rows it reads are rewritten by the next strip's tap phase,
+    // which starts behind the next barrier); the transcendental pieces run inside the NEXT strip's contraction, between MFMA groups
+    // (a wave's VALU instructions issue in the shadow of its own 64-cycle MFMAs), the stores behind that strip's barrier.
+    float gv[2][C]; int goh[2], gox[2]; bool gok[2];
+    auto g_sum = [&](int it, int f0, int r0g, int nrows) {      // it = state slot, f0 = first element of this pass
+        const int f = f0 + tid;
+        const int orow = (int)__umulhi((unsigned)f, a.magicW);
+        const int ox = f - orow * Wout, oh = 2 * r0g - 1 + orow;
+        goh[it] = oh; gox[it] = ox;
+        gok[it] = f < nrows * Wout && oh >= 0 && oh < Hout;
+        const int ohc = min(max(oh, 0), Hout - 1);          // (a thread without an output element reads valid slots and is discarded)
+#pragma unroll
+        for (int c = 0; c < C; ++c) gv[it][c] = a.b4[c];
+        const int ixx = ox >> 1;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int tr = ohc + 1 - kh;            // y3 source row of tap row kh
+            const bool rv = tr >= 0 && tr < Hout;
+            int hs = hb + ((rv ? tr : ohc) - 2 * r0g);   // (an out-of-image source row reads a valid slot and adds zero)
+            if (hs < 0) hs += RING;
+            if (hs >= RING) hs -= RING;
+            const float* hq = sH + ((size_t)hs * NG + kh * C) * Wout + ox;
+            // the horizontal sum of a pixel at a tile boundary was split between two waves: the other half is in the edge array
+            int lr_ = (tr >> 1) - r0g;
+            if (lr_ < 0) lr_ += TH;
+            const int qq = lr_ * Win + ixx;
+            const bool needL = !(ox & 1) && (qq & 31) == 0 && ixx > 0;
+            const bool needR = (ox & 1) && (qq & 31) == 31 && ixx < Win - 1;
+            const float* eq = sE + (hs * NG + kh * C) * 8 + (needL ? (qq >> 5) - 1 : needR ? 4 + (qq >> 5) + 1 : 0);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float hv = hq[c * Wout], ev = eq[c * 8];
+                gv[it][c] += rv ? hv : 0.0f;
+                gv[it][c] += (rv && (needL || needR)) ? ev : 0.0f;
+            }
+        }
+    };
+    // (the empty asm statements pin a piece where it is written: its results have no reader until after the strip barrier, and LLVM
+    // otherwise sinks the whole computation there -- back into the non-MFMA phase)
+    auto g_sig = [&](int it) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) { gv[it][c] = fast_sigmoid(gv[it][c]); asm volatile("" : "+v"(gv[it][c])); }
+    };
+    auto g_term = [&](int it) {             // branch-free: both forms are evaluated (the reward form is a few FMAs), discarded threads add zero
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float pr = gv[it][c];
+            const float te = -(1.0f - pr) * __logf(D1 - pr) - pr * __logf(D0 + pr);
+            const float tw = reward_term(pr, goh[it], gox[it], Hout, Wout, a.reward_intent);
+            t += mode == 0 ? te : tw;
+        }
+        part += gok[it] ? t : 0.0f;
+        asm volatile("" : "+v"(part));
+    };
+    auto g_store = [&](int it) {
+        if (po && gok[it]) {
+            float4* pp = reinterpret_cast<float4*>(po + ((size_t)goh[it] * Wout + gox[it]) * 8);
+            pp[0] = make_float4(gv[it][0], C > 1 ? gv[it][C > 1 ? 1 : 0] : 0.f, C > 2 ? gv[it][C > 2 ? 2 : 0] : 0.f, 0.f);
+            pp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    gok[0] = gok[1] = false; goh[0] = goh[1] = 0; gox[0] = gox[1] = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) gv[0][c] = gv[1][c] = 0.f;
+    float4 pf[8];
     __syncthreads();
 
     for (int s = 0; s < NS; ++s) {
@@ -407,6 +476,11 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[0], c0, cb) MFMA4(acc[1], c1, cb) MFMA4(acc[2], c2, cb) MFMA4(acc[3], c3, cb)
+                // the previous strip's gather (sums taken before the barrier), a piece per channel-block step
+                if (kc == 0) g_sig(0);
+                if (kc == 2) g_term(0);
+                if (kc == 4) g_sig(1);
+                if (kc == 6) g_term(1);
             }
             float4 bd;
 #pragma unroll
@@ -430,6 +504,11 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
                     a0 = wf(1, kc + 1); a1 = wf(2, kc + 1); a2 = wf(0, kc + 1);
                     b = sm[pC + 2 * (kc + 1)];
                     bd = sm[pD + 2 * (kc + 1)];
+                }
+                if (kc == 6 && more) {       // the next strip's new rows (one contiguous block of SPX pixels), behind the strip's last weight-fragment request
+                    const int P0 = (r0 + TH + 1) * Win;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pf[i] = fetch(P0 + ppt + 16 * i, ppt + 16 * i < SPX);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[3], c1, cb) MFMA4(acc[2], c0, cb) MFMA4(acc[3], c2, cd)
@@ -473,64 +552,15 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
             }
         }
         __syncthreads();
-        // ---- request the next strip's new rows (one contiguous block of SPX pixels) behind the MFMA phase
-        float4 pf[8];
-        if (more) {
-            const int P0 = (r0 + TH + 1) * Win;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) pf[i] = fetch(P0 + ppt + 16 * i, ppt + 16 * i < SPX);
+        g_store(0); g_store(1);                            // the previous strip's pixels
+        if (!more) {
+            // the last strip has no successor: its rows (and the image's last row) are gathered in full now
+            const int nrows = 2 * TH + 1;
+            for (int f0 = 0; f0 < nrows * Wout; f0 += 256) { g_sum(0, f0, r0, nrows); g_sig(0); g_term(0); g_store(0); }
+            break;
         }
-        // ---- gather: output rows 2 r0 - 1 .. 2 r0 + 2 TH - 2 are complete (and the image's last row after the last strip)
-        {
-            const int first = 2 * r0 - 1;
-            const int nrows = more ? 2 * TH : 2 * TH + 1;
-            const int nout = nrows * Wout;
-            for (int f = tid; f < nout; f += 256) {
-                const int orow = (int)__umulhi((unsigned)f, a.magicW);
-                const int ox = f - orow * Wout, oh = first + orow;
-                if (oh < 0 || oh >= Hout) continue;
-                float v[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) v[c] = a.b4[c];
-                const int ixx = ox >> 1;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int tr = oh + 1 - kh;            // y3 source row of tap row kh
-                    const bool rv = tr >= 0 && tr < Hout;
-                    int hs = hb + ((rv ? tr : oh) - 2 * r0);   // (an out-of-image source row reads a valid slot and adds zero)
-                    if (hs < 0) hs += RING;
-                    if (hs >= RING) hs -= RING;
-                    const float* hq = sH + ((size_t)hs * NG + kh * C) * Wout + ox;
-                    // the horizontal sum of a pixel at a tile boundary was split between two waves: the other half is in the edge array
-                    int lr_ = (tr >> 1) - r0;
-                    if (lr_ < 0) lr_ += TH;
-                    const int qq = lr_ * Win + ixx;
-                    const bool needL = !(ox & 1) && (qq & 31) == 0 && ixx > 0;
-                    const bool needR = (ox & 1) && (qq & 31) == 31 && ixx < Win - 1;
-                    const float* eq = sE + (hs * NG + kh * C) * 8 + (needL ? (qq >> 5) - 1 : needR ? 4 + (qq >> 5) + 1 : 0);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        const float hv = hq[c * Wout], ev = eq[c * 8];
-                        v[c] += rv ? hv : 0.0f;
-                        v[c] += (rv && (needL || needR)) ? ev : 0.0f;
-                    }
-                }
-                float p[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float pr = fast_sigmoid(v[c]);
-                    p[c] = pr;
-                    if (mode == 0) part += -(1.0f - pr) * __logf(D1 - pr) - pr * __logf(D0 + pr);
-                    else part += reward_term(pr, oh, ox, Hout, Wout, a.reward_intent);
-                }
-                if (po) {
-                    float4* pp = reinterpret_cast<float4*>(po + ((size_t)oh * Wout + ox) * 8);
-                    pp[0] = make_float4(p[0], p[1], p[2], 0.f);
-                    pp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-        }
-        if (!more) break;
+        // ---- output rows 2 r0 - 1 .. 2 r0 + 2 TH - 2 are complete: take their sums now, the rest inside the next strip
+        g_sum(0, 0, r0, 2 * TH); g_sum(1, 256, r0, 2 * TH);
         // ---- the new rows take the slots of the strip's own TH rows (every wave is past the MFMA phase: barrier above)
         {
 #pragma unroll
