@@ -303,15 +303,23 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
                            'achieved': dec * fl / 1e12 / world, 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s',
                            'frac': dec * fl / 1e12 / world / PEAK_FP32_MFMA_TF, 'traffic': None}
         if not a.no_prof:
-            model.prof_enable(True, classes=[DOM])
+            # the planner's simulations run on a replica context (second stream): time the class on both contexts
+            ctxs = [model] + ([model._replica] if getattr(model, '_replica', None) is not None else [])
+            for c_ in ctxs:
+                c_.prof_enable(True, classes=[DOM])
             step(0)
-            ms_dom, n_dom = model.prof_read()[DOM]
-            model.prof_enable(False)
-            n_img = 51 * 3 * a.samples * 4 * E + 50 * 3 * 5 * E     # decoder images of one decision batch
+            ms_dom = n_dom = 0
+            for c_ in ctxs:
+                ms_, n_ = c_.prof_read()[DOM]
+                ms_dom += ms_; n_dom += n_
+                c_.prof_enable(False)
+            n_img = 51 * 3 * a.samples * 4 * E + 50 * 3 * 5 * E     # decoder images of one decision batch (expansions + simulations)
             ach_dom = 2 * MAC_DECB_ROW * n_img / (ms_dom * 1e-3) / 1e12 if ms_dom > 0 else 0.0
             out['roofline']['dominant'] = {'kernel': 'k_dec_b', 'achieved': ach_dom, 'frac': ach_dom / PEAK_FP32_MFMA_TF,
                                            'launches': int(n_dom), 'avg_launch_ms': ms_dom / max(n_dom, 1),
-                                           'note': 'HIP events of this rank, one un-timed decision batch (includes the replica stream\'s launches)'}
+                                           'note': 'HIP events of this rank on both engine contexts (expansions on the main stream, simulations on '
+                                                   'the replica stream: the two overlap, so a launch shares the GPU with the other stream\'s kernels), '
+                                                   'one un-timed decision batch'}
     if with_cpu:
         out['cpu_baseline'] = cpu_baseline_mcts(a.samples)
         out['speedup_vs_cpu_baseline'] = dec / out['cpu_baseline']['value']
