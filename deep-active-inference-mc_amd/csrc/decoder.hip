@@ -337,12 +337,13 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
         float4 a0 = wf(4, 0), a1 = wf(5, 0), a2 = wf(7, 0), a3 = wf(8, 0);      // the strip's first weight fragments: in flight across the barrier
         __syncthreads();
 
-        f32x16 acc[4];
+        // the accumulators start at the layer-3 bias (register e holds channel (e & 3) + 8 (e >> 2) + 4 h): the bias vector is the C operand
+        // of each chain's FIRST MFMA -- 16 short-lived registers instead of 64 moves into the four accumulator tiles
+        f32x16 acc[4], bias16;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const float4 bb = sb3[2 * g4 + h];
-#pragma unroll
-            for (int p_ = 0; p_ < 4; ++p_) { acc[p_][4 * g4] = bb.x; acc[p_][4 * g4 + 1] = bb.y; acc[p_][4 * g4 + 2] = bb.z; acc[p_][4 * g4 + 3] = bb.w; }
+            bias16[4 * g4] = bb.x; bias16[4 * g4 + 1] = bb.y; bias16[4 * g4 + 2] = bb.z; bias16[4 * g4 + 3] = bb.w;
         }
         // ---- contraction, software-pipelined one chunk ahead: shift A (4 chains), shift B (2), shifts C + D fused (2 + 1, so the
         // single-chain shift never runs alone).  The first weight fragments were requested before the staging barrier.
@@ -359,7 +360,8 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                     b = sm[spB * 16 + (h ^ (spB & 15))];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                MFMA4(acc[0], c0, cb) MFMA4(acc[1], c1, cb) MFMA4(acc[2], c2, cb) MFMA4(acc[3], c3, cb)
+                if (kc == 0) { MFMA4I(acc[0], bias16, c0, cb) MFMA4I(acc[1], bias16, c1, cb) MFMA4I(acc[2], bias16, c2, cb) MFMA4I(acc[3], bias16, c3, cb) }
+                else { MFMA4(acc[0], c0, cb) MFMA4(acc[1], c1, cb) MFMA4(acc[2], c2, cb) MFMA4(acc[3], c3, cb) }
                 if constexpr (DEFER) {       // the previous strip's gather, a piece per channel-block step
                     if (kc == 0) { g_load(oh0, 0, 2 * SR * (s - 1), hbp); g_load(oh1, 1, 2 * SR * (s - 1), hbp); }
                     if (kc == 2) g_sig(oh0, 0);

@@ -73,9 +73,27 @@ __global__ void __launch_bounds__(256, 3) k_convt_p(const ConvGArgs a) {
         const int rw = tid / Win, xw = tid - rw * Win;
         cl_off[tid] = rw < TH ? ((MODE == 2 ? 2 * rw : rw) * a.Wout + (MODE == 2 ? 2 * xw : xw)) * a.ldo * 4 : 0x40000000;     // bytes; the sentinel is outside every image
     }
+    const int nt = wave % ntw, mt = wave / ntw;
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wp), 0, 0x7fffffff, 0x00020000);
+    const unsigned wl = (unsigned)lane * 16u;
+    // The first weight fragments of a pass are requested BEFORE the previous pass's store epilogue (and, for a strip's first pass,
+    // before the barriers in front of it): requested at the top of a pass they exposed an L2 round trip per pass -- two per strip on
+    // the stride-2 layers.  fa = fragment set of channel block 0 of the upcoming pass, fb = block 1 (pass 0 keeps two sets).
+    constexpr int ptp_[3][9] = {{4, 5, 3, 0, 0, 0, 0, 0, 0}, {7, 8, 6, 1, 2, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};
+    float4 fa[9], fb[3];
+    auto preload = [&](int P) {        // P = table row of the upcoming pass
+        const int n = P == 0 ? 3 : P == 1 ? 6 : 9;
+#pragma unroll
+        for (int m = 0; m < 9; ++m)
+            if (m < n) fa[m] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp_[P][m] * a.mtiles + mt) * KC) * 64) * 16u, 0));
+        if (P == 0) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) fb[m] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp_[0][m] * a.mtiles + mt) * KC + 1) * 64) * 16u, 0));
+        }
+    };
+    preload(MODE == 2 ? 0 : 2);
     __syncthreads();
 
-    const int nt = wave % ntw, mt = wave / ntw;
     const int q = nt * 32 + j;
     const bool qv = q < SPX;
     const int qq = qv ? q : 0;
@@ -86,8 +104,6 @@ __global__ void __launch_bounds__(256, 3) k_convt_p(const ConvGArgs a) {
     const int img_floats = a.Hout * a.Wout * a.ldo;
     const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)img * img_floats, 0, img_floats * 4, 0x00020000);
     const int strip_floats = (MODE == 2 ? 2 : 1) * TH * a.Wout * a.ldo;
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wp), 0, 0x7fffffff, 0x00020000);
-    const unsigned wl = (unsigned)lane * 16u;
 
     int bs = PADT * Win;                               // ring slot of pixel (r0, 0)
     for (int s = 0; s < spi; ++s) {
@@ -131,13 +147,6 @@ __global__ void __launch_bounds__(256, 3) k_convt_p(const ConvGArgs a) {
                 for (int p = 0; p < NAC; ++p)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) ac[p][e] = bias;       // a lane owns one output channel: the bias is the accumulator's start value
-                auto load_a = [&](float4 (&av)[NMP], int kc) {
-#pragma unroll
-                    for (int m = 0; m < NMP; ++m) {
-                        const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + kc) * 64) * 16u, 0);
-                        av[m] = __builtin_bit_cast(float4, v);
-                    }
-                };
                 // one contraction step: the strip views of block kc (requested a step earlier) against fragment set av; every
                 // fragment is re-requested for block kc + AD right behind the MFMAs that consumed it, every view for block kc + 1
                 // behind its last reader, so each wait leaves the newer requests in flight (a bulk request per step made hipcc
@@ -165,13 +174,11 @@ __global__ void __launch_bounds__(256, 3) k_convt_p(const ConvGArgs a) {
                     }
                 };
                 float4 a0[NMP], a1[AD == 2 ? NMP : 1], bv[NVP];
-                load_a(a0, 0);
+#pragma unroll
+                for (int m = 0; m < NMP; ++m) a0[m] = fa[m];                  // requested before the previous pass's epilogue / the strip barriers
                 if (AD == 2) {
 #pragma unroll
-                    for (int m = 0; m < NMP; ++m) {
-                        const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)(((ptp[P][m] * a.mtiles + mt) * KC + 1) * 64) * 16u, 0);
-                        a1[m % (AD == 2 ? NMP : 1)] = __builtin_bit_cast(float4, v);
-                    }
+                    for (int m = 0; m < NMP; ++m) a1[m % (AD == 2 ? NMP : 1)] = fb[m % 3];
                 }
 #pragma unroll
                 for (int v = 0; v < NVP; ++v) bv[v] = cl_x[vb[v]];
@@ -181,6 +188,7 @@ __global__ void __launch_bounds__(256, 3) k_convt_p(const ConvGArgs a) {
                     step(a0, bv, kc);
                     if constexpr (AD == 2) step(a1, bv, kc + 1); else step(a0, bv, kc + 1);
                 }
+                preload(P == 0 ? 1 : P == 1 ? 0 : 2);                          // the next pass's first fragments, ahead of this pass's stores
                 // epilogue: C/D layout column = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (pixel of the tile).
                 // Stores go through a buffer resource that covers exactly this image: a strip pixel outside it (a short last strip, the
                 // table's sentinel) has an out-of-range offset and is dropped by the hardware -- no branches around the stores.
@@ -435,6 +443,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
 #pragma unroll
     for (int c = 0; c < C; ++c) gv[0][c] = gv[1][c] = 0.f;
     float4 pf[8];
+    float4 a0 = wf(4, 0), a1 = wf(5, 0), a2 = wf(7, 0), a3 = wf(8, 0);      // a strip's first weight fragments are in flight across the barrier in front of it
     __syncthreads();
 
     for (int s = 0; s < NS; ++s) {
@@ -452,7 +461,6 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
             pC = (qv ? nC : ZP + (nC & 15)) * PS4 + h;
             pD = ((qv && !last_col) ? nD : ZP + (nD & 15)) * PS4 + h;
         }
-        float4 a0 = wf(4, 0), a1 = wf(5, 0), a2 = wf(7, 0), a3 = wf(8, 0);
         f32x16 acc[4];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -574,6 +582,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
         }
         bs += SPX; if (bs >= RPa) bs -= RPa;
         hb += 2 * TH; if (hb >= RING) hb -= RING;
+        a0 = wf(4, 0); a1 = wf(5, 0); a2 = wf(7, 0); a3 = wf(8, 0);
         __syncthreads();
     }
 #pragma unroll

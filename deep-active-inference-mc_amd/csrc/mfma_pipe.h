@@ -22,6 +22,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vector: p
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, (BV).z, ACC, 0, 0, 0);   \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, (BV).w, ACC, 0, 0, 0);
 
+// the same with the chain's start value INIT (e.g. the bias vector) as the C operand of the first instruction
+#define MFMA4I(ACC, INIT, AV, BV)                                               \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, (BV).x, INIT, 0, 0, 0);  \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, (BV).y, ACC, 0, 0, 0);   \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, (BV).z, ACC, 0, 0, 0);   \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, (BV).w, ACC, 0, 0, 0);
+
 // Weight (A) fragments are fetched with buffer loads: SGPR resource (base) + SGPR byte offset (tap / tile / chunk, all
 // uniform) + ONE per-lane VGPR offset (lane * 16).  With flat global loads hipcc folds the lane into a 64-bit per-lane
 // pointer and materialises a VGPR pair per distinct offset -- dozens of pairs, hoisted out of the loops and spilled.
