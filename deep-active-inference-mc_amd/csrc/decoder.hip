@@ -203,19 +203,18 @@ void launch_dec_a(const DecAArgs& a, hipStream_t st) {
 // weights re-read from LDS, channel halves merged with a cross-lane add: 50 KiB LDS) all land on the same 5.96-5.98 ms per 19200
 // images; the per-strip index laundering alone costs 2-3 % at two waves.  The shader clock is at 2.38 GHz in steady state (it
 // ramps from 2.05 GHz over the first four launches after idle): the kernel is not clock- or power-limited.
-// DEFER: the gather of a strip (sigmoid + entropy / reward terms of its 2 SR output rows: ~130 VALU instructions per wave) is not done
+// Deferred gather: the gather of a strip (sigmoid + entropy / reward terms of its 2 SR output rows: ~130 VALU instructions per wave) is not done
 // between the strip's two barriers -- where it is pure non-MFMA wave time -- but DURING THE NEXT STRIP'S CONTRACTION, in pieces
 // placed between the MFMA groups of the unrolled channel-block steps (a wave's VALU instructions issue in the shadow of its own
 // 64-cycle MFMAs).  The H-plane ring holds 4 SR + 2 rows (27.6 KiB) so that the next strip's planes do not overwrite rows still
 // being gathered; the next strip's input is requested behind the contraction's last weight-fragment request (the tap phase covers
 // its latency instead of the gather); the images of the deferred rows are stored after the strip barrier.  Per-thread summation
-// order is unchanged, so the result is bit-identical to the immediate form.
-template <bool DEFER>
+// order is the same as when every strip is gathered between its own barriers (0.812 of the fp32 MFMA peak in that form, 0.843 in this one).
 __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     constexpr int SR = 4, NW = 4, NTHR = 256;
     constexpr int DB_ZERO = (SR + 1) * 32;
     constexpr int DB_IN_F4 = (DB_ZERO + 1) * 16;
-    constexpr int DB_YROWS = DEFER ? 4 * SR + 2 : 2 * SR + 2;
+    constexpr int DB_YROWS = 4 * SR + 2;
     constexpr int NPF = (SR + 1) * 512 / NTHR;        // 10 float4s of the input strip per thread
     constexpr int NS = 32 / SR;
     extern __shared__ __attribute__((aligned(16))) float4 sm[];
@@ -326,7 +325,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     int hb = 0, hbp = 0;                                   // H-ring slots of y3 rows 2 SR s (this strip's first) and 2 SR (s - 1)
     for (int s = 0; s < NS; ++s) {
         const int tl = tid;
-        const int oh0 = 2 * SR * (s - 1) - 1 + w, oh1 = oh0 + NW;         // DEFER: this wave's two output rows of the previous strip        // (laundering the index per strip frees ~20 VGPRs -- 168, three waves per SIMD, 4 spills -- for no gain: 0.814 vs 0.812)
+        const int oh0 = 2 * SR * (s - 1) - 1 + w, oh1 = oh0 + NW;         // this wave's two output rows of the previous strip        // (laundering the index per strip frees ~20 VGPRs -- 168, three waves per SIMD, 4 spills -- for no gain: 0.814 vs 0.812)
 #pragma unroll
         for (int it = 0; it < NPF; ++it) {
             const int idx = it * NTHR + tl;
@@ -362,12 +361,11 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (kc == 0) { MFMA4I(acc[0], bias16, c0, cb) MFMA4I(acc[1], bias16, c1, cb) MFMA4I(acc[2], bias16, c2, cb) MFMA4I(acc[3], bias16, c3, cb) }
                 else { MFMA4(acc[0], c0, cb) MFMA4(acc[1], c1, cb) MFMA4(acc[2], c2, cb) MFMA4(acc[3], c3, cb) }
-                if constexpr (DEFER) {       // the previous strip's gather, a piece per channel-block step
-                    if (kc == 0) { g_load(oh0, 0, 2 * SR * (s - 1), hbp); g_load(oh1, 1, 2 * SR * (s - 1), hbp); }
-                    if (kc == 2) g_sig(oh0, 0);
-                    if (kc == 4) g_term(oh0, 0);
-                    if (kc == 6) g_sig(oh1, 1);
-                }
+                // the previous strip's gather, a piece per channel-block step
+                if (kc == 0) { g_load(oh0, 0, 2 * SR * (s - 1), hbp); g_load(oh1, 1, 2 * SR * (s - 1), hbp); }
+                if (kc == 2) g_sig(oh0, 0);
+                if (kc == 4) g_term(oh0, 0);
+                if (kc == 6) g_sig(oh1, 1);
             }
             float4 bd;
 #pragma unroll
@@ -383,7 +381,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[1], c0, cb) MFMA4(acc[3], c1, cb)
-                if constexpr (DEFER) { if (kc == 1) g_term(oh1, 1); }
+                if (kc == 1) g_term(oh1, 1);
             }
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
@@ -393,7 +391,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                     b = sm[spC * 16 + ((2 * (kc + 1) + h) ^ (spC & 15))];
                     bd = sm[spD * 16 + ((2 * (kc + 1) + h) ^ (spD & 15))];
                 }
-                if constexpr (DEFER) { if (kc == 6) prefetch((s < NS - 1) ? s + 1 : NS - 1, tl); }       // behind the strip's last weight-fragment request
+                if (kc == 6) prefetch((s < NS - 1) ? s + 1 : NS - 1, tl);       // the next strip's input, behind this strip's last weight-fragment request
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[3], c1, cb) MFMA4(acc[2], c0, cb) MFMA4(acc[3], c2, cd)
             }
@@ -437,24 +435,12 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
             }
         }
         __syncthreads();
-        if constexpr (DEFER) {
-            g_store(oh0, 0); g_store(oh1, 1);              // the deferred rows' pixels (stores behind the prefetch loads)
-            if (s == NS - 1) {                              // the last strip has no successor: its rows (and row 63) now
+        g_store(oh0, 0); g_store(oh1, 1);                  // the deferred rows' pixels (stores behind the prefetch loads)
+        if (s == NS - 1) {                                  // the last strip has no successor: its rows (and row 63) now
 #pragma unroll
-                for (int q = 0; q <= RWG; ++q) {
-                    if (q == RWG && w != 0) break;
-                    const int oh = 2 * SR * s - 1 + q * NW + w;
-                    g_load(oh, 0, 2 * SR * s, hb); g_sig(oh, 0); g_term(oh, 0); g_store(oh, 0);
-                }
-            }
-        } else {
-            prefetch((s < NS - 1) ? s + 1 : NS - 1, tl);   // behind the MFMA phase (vmcnt retires in order: an HBM load in front of the weight-fragment loads stalls them)
-            // ---- gather: output rows 2*SR*s-1 .. 2*SR*s+2*SR-2 are complete (row 63 after the last strip)
-            const int nq = (s == NS - 1) ? RWG + 1 : RWG;
-            for (int q = 0; q < nq; ++q) {
+            for (int q = 0; q <= RWG; ++q) {
                 if (q == RWG && w != 0) break;
                 const int oh = 2 * SR * s - 1 + q * NW + w;
-                if (oh < 0) continue;
                 g_load(oh, 0, 2 * SR * s, hb); g_sig(oh, 0); g_term(oh, 0); g_store(oh, 0);
             }
         }
@@ -469,17 +455,14 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     if (tid == 0) a.val[mg] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
-constexpr size_t DB_LDS4H = ((5 * 32 + 1) * 16) * sizeof(float4) + 10 * 2 * 3 * 64 * sizeof(float);  // input strip + H planes per channel half (2 SR + 2 rows)
-constexpr size_t DB_LDS4D = ((5 * 32 + 1) * 16) * sizeof(float4) + 18 * 2 * 3 * 64 * sizeof(float);  // deferred gather: 4 SR + 2 rows
+constexpr size_t DB_LDS4D = ((5 * 32 + 1) * 16) * sizeof(float4) + 18 * 2 * 3 * 64 * sizeof(float);  // input strip + H planes per channel half (4 SR + 2 rows)
 int init_dec_b_kernels() {
-    if (hipFuncSetAttribute((const void*)(k_dec_b4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4H) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)(k_dec_b4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4D) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_dec_b4, hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4D) != hipSuccess) return 1;
     return 0;
 }
 
 void launch_dec_b(const DecBArgs& a, hipStream_t st) {
-    if (a.defer) hipLaunchKernelGGL(k_dec_b4<true>, dim3(a.rows), dim3(256), DB_LDS4D, st, a);
-    else hipLaunchKernelGGL(k_dec_b4<false>, dim3(a.rows), dim3(256), DB_LDS4H, st, a);
+    hipLaunchKernelGGL(k_dec_b4, dim3(a.rows), dim3(256), DB_LDS4D, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

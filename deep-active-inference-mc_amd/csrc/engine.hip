@@ -82,7 +82,6 @@ struct efe_ctx {
     // fused path, 1.6 MB with the final layer unfused); poison / trace: development only
     int64_t arena_align = 256;
     int64_t reward_intent = 0;     // option "reward_upstream_intent": 1 = the reward target the upstream NHWC code means (kernels.h reward_term), 0 = the shipped port's
-    int64_t decb_defer = 1;        // k_dec_b4: gather of a strip deferred into the next strip's contraction (0 = immediate form; results bit-identical)
     int64_t fuse_final_g = 1;      // generic path: last two decoder layers in one kernel (k_dec_bg); 0 = separate launches (A/B, parity tests of k_final_g)
     int64_t last_macs = 0;
     const uint8_t* row_mask = nullptr; int row_mask_div = 1;      // efe_set_row_mask
@@ -410,7 +409,7 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         DecBArgs db{};
         db.y2 = y2; db.w3 = ctx->dec_ct[2].Wp; db.b3 = ctx->dec_ct[2].bias; db.w4 = ctx->dec_wf; db.b4 = ctx->dec_bf;
         db.rows = c; db.live = live_of(nc, m0); db.m0 = m0; db.rows_per_group = nc.rows_per_group; db.gm = nc.gm; db.reward0 = reward0; db.store0 = store0;
-        db.val = val; db.po = po_store; db.reward_intent = (int)ctx->reward_intent; db.defer = (int)ctx->decb_defer;
+        db.val = val; db.po = po_store; db.reward_intent = (int)ctx->reward_intent;
         e0 = ctx->prof_begin(st);
         launch_dec_b(db, st);
         ctx->prof_end(e0, st);
@@ -671,7 +670,6 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     EFE_LOCK(ctx);
     if (!strcmp(name, "dec_chunk")) { if (value < 1) return ctx->fail("dec_chunk < 1"); ctx->dec_chunk = value; return 0; }
     if (!strcmp(name, "reward_upstream_intent")) { ctx->reward_intent = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "decb_defer")) { ctx->decb_defer = value ? 1 : 0; return 0; }
     if (!strcmp(name, "fuse_final_g")) { ctx->fuse_final_g = value ? 1 : 0; return 0; }
     if (!strcmp(name, "dec_budget_g")) { if (value < (1 << 20)) return ctx->fail("dec_budget_g < 1 MiB"); ctx->dec_budget_g = value; return 0; }
     if (!strcmp(name, "dec_chunk_g")) { if (value < 1) return ctx->fail("dec_chunk_g < 1"); ctx->dec_chunk_g = value; return 0; }

@@ -109,7 +109,6 @@ struct DecBArgs {
     float* val;           // [batch] per-image pixel sum (entropy sum, or log-likelihood sum)
     float* po;            // [slots][rows_per_group][4096] stored images
     int reward_intent;    // 0 = the shipped port's NCHW-broadcast reward target, 1 = the upstream-intent variant (reward_term below)
-    int defer;            // 1 = the gather of a strip runs inside the next strip's contraction (k_dec_b4<true>)
 };
 // fused encoder trunk: o [rows][64][64] -> conv1..conv4 (+ReLU) -> out [rows][576] in NHWC (p*64 + c) order
 struct EncArgs {
