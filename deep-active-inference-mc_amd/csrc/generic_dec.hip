@@ -439,6 +439,52 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
             pp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    // The same sums for a strip with a successor (2 TH rows = at most two passes), with everything that does not depend on the strip taken
+    // out of the loop: output element f = p * 256 + tid is always (row orow, column ox) of the strip's 2 TH output rows, its tap row kh
+    // always reads y3 row 2 r0 + (orow - kh), and whether (and where) a tile boundary splits its horizontal sum depends on
+    // (orow - kh) >> 1 and ox only.  Per strip only the ring slot and the image-edge tests remain.
+    int fox[2], forow[2], feo[2][3];
+#pragma unroll
+    for (int p_ = 0; p_ < 2; ++p_) {
+        const int f = p_ * 256 + tid;
+        forow[p_] = (int)__umulhi((unsigned)f, a.magicW);
+        fox[p_] = f - forow[p_] * Wout;
+        const int ixx = fox[p_] >> 1;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            int lr_ = (forow[p_] - kh) >> 1;              // input row of the source y3 row, relative to the strip (-1 = the previous strip's last row)
+            if (lr_ < 0) lr_ += TH;
+            const int qq = lr_ * Win + ixx;
+            const bool needL = !(fox[p_] & 1) && (qq & 31) == 0 && ixx > 0;
+            const bool needR = (fox[p_] & 1) && (qq & 31) == 31 && ixx < Win - 1;
+            feo[p_][kh] = needL ? (qq >> 5) - 1 : needR ? 4 + (qq >> 5) + 1 : -1;
+        }
+    }
+    auto g_sum_fast = [&](int p_, int r0g) {
+        const int oh = 2 * r0g - 1 + forow[p_], ox = fox[p_];
+        goh[p_] = oh; gox[p_] = ox;
+        gok[p_] = p_ * 256 + tid < 2 * TH * Wout && oh >= 0 && oh < Hout;
+#pragma unroll
+        for (int c = 0; c < C; ++c) gv[p_][c] = a.b4[c];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int d = forow[p_] - kh;                  // y3 source row = 2 r0 + d
+            const int tr = 2 * r0g + d;
+            const bool rv = tr >= 0 && tr < Hout && forow[p_] < 2 * TH;
+            int hs = hb + (rv ? d : 0);
+            hs = hs < 0 ? hs + RING : hs;
+            hs = hs >= RING ? hs - RING : hs;
+            const float* hq = sH + ((size_t)hs * NG + kh * C) * Wout + ox;
+            const bool ed = rv && feo[p_][kh] >= 0;
+            const float* eq = sE + (hs * NG + kh * C) * 8 + (ed ? feo[p_][kh] : 0);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float hv = hq[c * Wout], ev = eq[c * 8];
+                gv[p_][c] += rv ? hv : 0.0f;
+                gv[p_][c] += ed ? ev : 0.0f;
+            }
+        }
+    };
     gok[0] = gok[1] = false; goh[0] = goh[1] = 0; gox[0] = gox[1] = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) gv[0][c] = gv[1][c] = 0.f;
@@ -568,7 +614,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
             break;
         }
         // ---- output rows 2 r0 - 1 .. 2 r0 + 2 TH - 2 are complete: take their sums now, the rest inside the next strip
-        g_sum(0, 0, r0, 2 * TH); g_sum(1, 256, r0, 2 * TH);
+        g_sum_fast(0, r0); g_sum_fast(1, r0);
         // ---- the new rows take the slots of the strip's own TH rows (every wave is past the MFMA phase: barrier above)
         {
 #pragma unroll
