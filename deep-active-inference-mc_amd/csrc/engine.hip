@@ -57,6 +57,7 @@ struct efe_ctx {
     size_t img_store = 4096;        // floats per stored D1 image: C*H*W NCHW (dSprites, C = 1) or H*W*8 NHWC8 (generic)
     Layer g_fc4, g_ct[3], g_enc[4];
     float* g_wf = nullptr; float g_bf[4] = {0.f, 0.f, 0.f, 0.f};
+    float* g_enc1p = nullptr;       // first encoder conv for k_conv_e: [9 taps][64 lanes][2] = W[co][h][tap], W[co][2 + h][tap]
     int64_t mac_dec = 43256320, mac_enc = 3868960, mac_trans = 541696, mac_habit = 18176;
     MlpW mid16{}, top16{};         // the same transition / habit weights packed for the fused 16x16x4 kernels (fused.hip)
     int64_t mid_unfused = 0;       // option: 1 = layer-by-layer k_dense transition (A/B experiments)
@@ -82,6 +83,7 @@ struct efe_ctx {
     // fused path, 1.6 MB with the final layer unfused); poison / trace: development only
     int64_t arena_align = 256;
     int64_t reward_intent = 0;     // option "reward_upstream_intent": 1 = the reward target the upstream NHWC code means (kernels.h reward_term), 0 = the shipped port's
+    int64_t enc_tiled = 1;         // generic path: LDS-tiled encoder layers 1 and 2 (k_conv_e); 0 = k_conv_g for every layer (A/B, parity of the fallback)
     int64_t fuse_final_g = 1;      // generic path: last two decoder layers in one kernel (k_dec_bg); 0 = separate launches (A/B, parity tests of k_final_g)
     int64_t last_macs = 0;
     const uint8_t* row_mask = nullptr; int row_mask_div = 1;      // efe_set_row_mask
@@ -360,8 +362,19 @@ int run_encoder_g(efe_ctx* ctx, const float* o8, int N, const NoiseCfg& nc, floa
     for (int m0 = 0; m0 < N; m0 += C) {
         const int c = std::min(C, N - m0);
         ctx->cls = PROF_ENC;
-        conv(ctx->g_enc[0], o8 + (size_t)m0 * hw[0] * hw[0] * 8, c1, c, hw[0], 8, hw[1], 32);
-        conv(ctx->g_enc[1], c1, c2, c, hw[1], 32, hw[2], 32);
+        // layers 1 and 2 LDS-tiled (generic_enc.hip); k_conv_g where a geometry is outside that kernel's limits
+        auto conv_e = [&](int layer, const float* in, float* out, const float* Wp, const float* bias, int hin, int hout) -> int {
+            ConvEArgs e{};
+            e.in = in; e.out = out; e.Wp = Wp; e.bias = bias; e.n_img = c; e.Hin = hin; e.Win = hin; e.Hout = hout; e.Wout = hout;
+            e.live = live_of(nc, m0);
+            hipEvent_t e0 = ctx->prof_begin(st);
+            const int rc = ctx->enc_tiled ? launch_conv_e(e, layer, st) : 1;
+            ctx->prof_end(rc ? nullptr : e0, st);
+            return rc;
+        };
+        const float* o8c = o8 + (size_t)m0 * hw[0] * hw[0] * 8;
+        if (conv_e(1, o8c, c1, ctx->g_enc1p, ctx->g_enc[0].bias, hw[0], hw[1])) conv(ctx->g_enc[0], o8c, c1, c, hw[0], 8, hw[1], 32);
+        if (conv_e(2, c1, c2, ctx->g_enc[1].Wp, ctx->g_enc[1].bias, hw[1], hw[2])) conv(ctx->g_enc[1], c1, c2, c, hw[1], 32, hw[2], 32);
         conv(ctx->g_enc[2], c2, c3, c, hw[2], 32, hw[3], 64);
         conv(ctx->g_enc[3], c3, c4, c, hw[3], 64, hw[4], 64);
         fc(ctx, ctx->enc_fc[0], c4, flat, 0, hA, 256, c, true, true, TAG_ENC + 0, nc, m0, st);
@@ -670,6 +683,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     EFE_LOCK(ctx);
     if (!strcmp(name, "dec_chunk")) { if (value < 1) return ctx->fail("dec_chunk < 1"); ctx->dec_chunk = value; return 0; }
     if (!strcmp(name, "reward_upstream_intent")) { ctx->reward_intent = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "enc_tiled")) { ctx->enc_tiled = value ? 1 : 0; return 0; }
     if (!strcmp(name, "fuse_final_g")) { ctx->fuse_final_g = value ? 1 : 0; return 0; }
     if (!strcmp(name, "dec_budget_g")) { if (value < (1 << 20)) return ctx->fail("dec_budget_g < 1 MiB"); ctx->dec_budget_g = value; return 0; }
     if (!strcmp(name, "dec_chunk_g")) { if (value < 1) return ctx->fail("dec_chunk_g < 1"); ctx->dec_chunk_g = value; return 0; }
@@ -731,6 +745,19 @@ int efe_commit_weights(efe_ctx* ctx) {
             const float* W = w->data.data(); const int Cin = cci[i];
             if (upload_packed(ctx, ctx->g_enc[i], 9, cco[i], Cin,
                               [&](int t, int co, int ci) { return W[((size_t)co * Cin + ci) * 9 + t]; }, b->data.data(), nullptr)) return 1;
+        }
+        {   // layer 1 for the LDS-tiled kernel (generic_enc.hip): lane (co = lane & 31, h = lane >> 5) holds its two K operands of a tap
+            const HostTensor* w = need(ctx, "down.qs_net.0.weight", {32, C, 3, 3});
+            if (!w) return 1;
+            std::vector<float> p1(9 * 64 * 2, 0.f);
+            for (int t = 0; t < 9; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 2; ++i) {
+                        const int co = lane & 31, ci = 2 * i + (lane >> 5);
+                        if (ci < C) p1[(t * 64 + lane) * 2 + i] = w->data[((size_t)co * C + ci) * 9 + t];
+                    }
+            HIPCHK(hipMalloc((void**)&ctx->g_enc1p, p1.size() * 4)); ctx->wbufs.push_back(ctx->g_enc1p);
+            HIPCHK(hipMemcpy(ctx->g_enc1p, p1.data(), p1.size() * 4, hipMemcpyHostToDevice));
         }
         {   // Flatten is channel-major c*F + p; conv4's output is NHWC p*64 + c
             std::vector<int> colp((size_t)F * 64);

@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) k_final_g(const FinalGArgs a) {
 static size_t final_g_lds(int W) { return (size_t)27 * fg_plane(W) * sizeof(float); }
 int init_generic_kernels() {
     if (hipFuncSetAttribute((const void*)k_final_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)final_g_lds(FG_MAXW)) != hipSuccess) return 1;
-    if (init_generic_dec_kernels()) return 1;
+    if (init_generic_dec_kernels() || init_generic_enc_kernels()) return 1;
     return 0;
 }
 int launch_final_g(const FinalGArgs& a, hipStream_t st) {

@@ -228,6 +228,17 @@ struct DecBGArgs {
     float* val;                         // [batch] per-image sums
     float* po;                          // [slots][rows_per_group][Hout * Wout][8] stored images (NHWC, channels padded to 8)
 };
+// LDS-tiled encoder Conv2d(k3, s2, p0) + ReLU of the generic path, layers 1 and 2 (generic_enc.hip)
+struct ConvEArgs {
+    const float* in;                    // layer 1: NHWC8 image [n][Hin * Win][8]; layer 2: [n][Hin * Win][32]
+    float* out;                         // [n][Hout * Wout][32]
+    const float* Wp; const float* bias; // layer 2: packed [9][1][4][64][4]; layer 1: [9 taps][64 lanes][2] = W[co][h][tap], W[co][2 + h][tap]
+    int n_img, Hin, Win, Hout, Wout;
+    int TY; unsigned magicWin, magicWout;       // set by launch_conv_e
+    RowMask live;
+};
+int launch_conv_e(ConvEArgs a, int layer, hipStream_t st);     // non-zero: outside the kernel's limits (use k_conv_g)
+int init_generic_enc_kernels();
 int launch_dec_bg(DecBGArgs a, hipStream_t st);                 // non-zero: geometry outside the kernel's limits
 int init_generic_dec_kernels();
 struct FinalGArgs {
