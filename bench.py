@@ -186,19 +186,24 @@ def committed_traffic(kernel='k_dec_b'):
     return None, None
 
 
-def timed_regions(step, steps, k0, sync, min_total_s=10.0, max_regions=60):
-    """time EXACTLY `steps` steps between sync() pairs; repeat the region until min_total_s of measured time.
-    -> (list of region seconds (max over ranks is taken by the caller), next step index)"""
-    out, k = [], k0
+def timed_regions(step, steps, k0, rk, min_total_s=10.0, max_regions=60):
+    """time EXACTLY `steps` steps between sync() pairs (barrier + device synchronise on both sides); repeat the region until
+    min_total_s of measured time.  The stop decision uses the MAX-over-ranks time of every region (one scalar all_reduce outside
+    the timed section), so that every rank runs the same number of regions -- a rank-local decision would leave one rank in a
+    barrier that the others never enter.
+    -> (region seconds, max over ranks), (this rank's region seconds), next step index"""
+    out, local, k = [], [], k0
     while True:
-        sync()
+        rk.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             step(k); k += 1
-        sync()
-        out.append(time.perf_counter() - t0)
+        rk.sync()
+        dt = time.perf_counter() - t0
+        local.append(dt)
+        out.append(rk.max_over_ranks([dt])[0])
         if sum(out) >= min_total_s or len(out) >= max_regions:
-            return out, k
+            return out, local, k
 
 
 class Ranks:
@@ -274,9 +279,8 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
 
     for k in range(warmup):
         step(k)
-    regions, _ = timed_regions(step, steps, 0, rk.sync, min_total_s=min_total_s, max_regions=12)
-    per_rank_ms = rk.per_rank(1e3 * statistics.median(regions) / steps)
-    regions = rk.max_over_ranks(regions)
+    regions, local, _ = timed_regions(step, steps, 0, rk, min_total_s=min_total_s, max_regions=12)
+    per_rank_ms = rk.per_rank(1e3 * statistics.median(local) / steps)
     dt = statistics.median(regions)
     dec = world * E * steps / dt
     iters = [o[1] for o in last['out']]
@@ -388,9 +392,8 @@ def bench_generic(a, device, rk, steps, warmup, with_cpu, min_total_s=2.0):
         step(k)
     rk.sync()
     macs_row = model.last_call_macs() / rows
-    regions, _ = timed_regions(step, steps, warmup, rk.sync, min_total_s=min_total_s, max_regions=12)
-    per_rank_ms = rk.per_rank(1e3 * statistics.median(regions) / steps)
-    regions = rk.max_over_ranks(regions)
+    regions, local, _ = timed_regions(step, steps, warmup, rk, min_total_s=min_total_s, max_regions=12)
+    per_rank_ms = rk.per_rank(1e3 * statistics.median(local) / steps)
     dt = statistics.median(regions)
     value = world * rows * steps / dt
     tf = value * 2 * macs_row / 1e12
@@ -554,15 +557,14 @@ def main():
         step(k)
     rk.sync()
     grows0 = model.arena_stats()['grow_count']
-    regions, kk = timed_regions(step, a.steps, a.warmup, rk.sync, min_total_s=0.0 if a.single_region else a.min_seconds)
+    regions, local, kk = timed_regions(step, a.steps, a.warmup, rk, min_total_s=0.0 if a.single_region else a.min_seconds)
     G = step(kk); kk += 1
     torch.cuda.synchronize()
     print(f'[bench] rank {rank}: {len(regions)} timed regions of {a.steps} steps, {sum(regions):.3f}s', file=sys.stderr, flush=True)
     assert torch.isfinite(G).all()
     assert model.arena_stats()['grow_count'] == grows0, 'the scratch arena grew inside the timed region'
-    per_rank_ms = rk.per_rank(1e3 * statistics.median(regions) / a.steps)
-    regions = rk.max_over_ranks(regions)             # per region: the slowest rank
-    dt = statistics.median(regions)
+    per_rank_ms = rk.per_rank(1e3 * statistics.median(local) / a.steps)
+    dt = statistics.median(regions)                  # per region: the slowest rank (max over ranks)
     gather_ms = rk.time_gather(last['P'], world * (R // 4))
     breakdown = {}
     if not a.no_prof:
