@@ -61,9 +61,16 @@ const char* efe_build_id(void);
 int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const int64_t* shape, int ndim);
 int efe_commit_weights(efe_ctx* ctx);
 
-/* options: "dec_chunk" (decoder rows per launch group), "enc_chunk", "dec_chunk_g" (cap of dec_chunk on the generic-geometry path:
- * 1.6 MB of layer activations per image at 84 x 84), "dec_budget_g" (bytes of layer
- * activations one launch group of the generic decoder may hold; default 28 GiB). */
+/* options
+ *   launch groups : "dec_chunk" (decoder rows per launch group), "enc_chunk", "dec_chunk_g" / "dec_budget_g" (generic-geometry decoder: cap in
+ *                   images / in bytes of layer activations per launch group; 0.68 MB per image at 84 x 84, default budget 28 GiB)
+ *   semantics     : "reward_upstream_intent" (0 / 1, default 0).  0 = the reward the shipped port computes (torchutils.py:34-37 on NCHW input: target
+ *                   1 for image rows h < H/2, every pixel counts; pinned by the oracle).  1 = what the upstream NHWC code means:
+ *                   only the top three rows count, target 1 on their left half; dSprites: mean over those 192 pixels * 10, other geometries: sum.
+ *   A / B         : "fuse_final_g" (generic path: last two decoder layers in one kernel, default 1), "enc_tiled" (generic path: LDS-tiled encoder
+ *                   layers 1 and 2, default 1, bit-identical to 0), "mid_unfused" (layer-by-layer transition MLP).  None of them removes work:
+ *                   every setting computes the same quantities (fp32 summation order may differ where stated).
+ *   development   : "poison" (pre-fill scratch with a byte), "trace" (synchronise and log every profiled launch), "arena_align" */
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value);
 
 /* scratch arena: efe_reserve makes the arena one block of >= bytes (synchronises once); efe_rollout_scratch_bytes is what
