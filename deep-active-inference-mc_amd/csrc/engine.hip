@@ -54,7 +54,7 @@ struct efe_ctx {
     bool generic = false;
     bool last_s1 = false;           // resolution 32: the reference's own variant (torchmodel.py:77-80, last_strides = 1): decoder base res/2, third ConvT stride 1
     int base = 16, enc_hw[5] = {64, 31, 15, 7, 3};
-    size_t img_store = 4096;        // floats per stored D1 image: C*H*W NCHW (dSprites, C = 1) or H*W*8 NHWC8 (generic)
+    size_t img_store = 4096;        // floats per stored D1 image: C*H*W NCHW (dSprites, C = 1) or H*W*4 NHWC4 (generic)
     Layer g_fc4, g_ct[3], g_enc[4];
     float* g_wf = nullptr; float g_bf[4] = {0.f, 0.f, 0.f, 0.f};
     float* g_enc1p = nullptr;       // first encoder conv for k_conv_e: [9 taps][64 lanes][2] = W[co][h][tap], W[co][2 + h][tap]
@@ -339,7 +339,7 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
     return 0;
 }
 
-// generic geometry: o is NHWC8 [N][res*res][8]; four Conv2d(k3,s2,p0)+ReLU, then the dense head
+// generic geometry: o is NHWC4 [N][res*res][4]; four Conv2d(k3,s2,p0)+ReLU, then the dense head
 int run_encoder_g(efe_ctx* ctx, const float* o8, int N, const NoiseCfg& nc, float* enc, hipStream_t st) {
     const int* hw = ctx->enc_hw;
     const int C = (int)std::min<int64_t>(std::min<int64_t>(ctx->enc_chunk, 8192), N);
@@ -351,6 +351,7 @@ int run_encoder_g(efe_ctx* ctx, const float* o8, int N, const NoiseCfg& nc, floa
     float* hB = ctx->allocT<float>((size_t)C * 256);
     if (!c1 || !c2 || !c3 || !c4 || !hA || !hB) return 1;
     const int flat = hw[4] * hw[4] * 64;
+    float* o8w = nullptr;
     auto conv = [&](const Layer& L, const float* in, float* out, int n, int hin, int cin, int hout, int cout) {
         ConvGArgs a{};
         a.in = in; a.out = out; a.Wp = L.Wp; a.bias = L.bias; a.zeros = ctx->zeros; a.n_img = n; a.Hin = hin; a.Win = hin; a.Cin = cin;
@@ -372,8 +373,14 @@ int run_encoder_g(efe_ctx* ctx, const float* o8, int N, const NoiseCfg& nc, floa
             ctx->prof_end(rc ? nullptr : e0, st);
             return rc;
         };
-        const float* o8c = o8 + (size_t)m0 * hw[0] * hw[0] * 8;
-        if (conv_e(1, o8c, c1, ctx->g_enc1p, ctx->g_enc[0].bias, hw[0], hw[1])) conv(ctx->g_enc[0], o8c, c1, c, hw[0], 8, hw[1], 32);
+        const float* o4c = o8 + (size_t)m0 * hw[0] * hw[0] * GEN_IMG_LD;
+        if (conv_e(1, o4c, c1, ctx->g_enc1p, ctx->g_enc[0].bias, hw[0], hw[1])) {
+            // k_conv_g contracts 8 input channels per tap: widen the image first (this path: option enc_tiled = 0)
+            if (!o8w) o8w = ctx->allocT<float>((size_t)C * hw[0] * hw[0] * 8);
+            if (!o8w) return 1;
+            launch_nhwc4_to_8(o4c, o8w, (long)c * hw[0] * hw[0], st);
+            conv(ctx->g_enc[0], o8w, c1, c, hw[0], 8, hw[1], 32);
+        }
         if (conv_e(2, c1, c2, ctx->g_enc[1].Wp, ctx->g_enc[1].bias, hw[1], hw[2])) conv(ctx->g_enc[1], c1, c2, c, hw[1], 32, hw[2], 32);
         conv(ctx->g_enc[2], c2, c3, c, hw[2], 32, hw[3], 64);
         conv(ctx->g_enc[3], c3, c4, c, hw[3], 64, hw[4], 64);
@@ -624,7 +631,7 @@ int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channel
     if (ctx->enc_hw[4] < 1) { delete ctx; return 7; }
     if (ctx->generic) {
         const int64_t B = ctx->base, r = resolution;
-        ctx->img_store = (size_t)r * r * 8;
+        ctx->img_store = (size_t)r * r * GEN_IMG_LD;
         ctx->mac_dec = 10 * 256 + 2 * 256 * 256 + 256 * 64 * B * B + B * B * 9 * 64 * 64 * 2 + 4 * B * B * 9 * 64 * 32 + r * r * 9 * 32 * channels;
         // (the stride-1 third layer of the resolution-32 variant works on 2B x 2B inputs: the same 4 B^2 * 9 * 64 * 32 MACs)
         const int* hw = ctx->enc_hw;
@@ -1006,7 +1013,7 @@ int efe_decoder(efe_ctx* ctx, const float* s, int M, const efe_noise* nz, float*
     launch_pad16(s, x, M, S_DIM, st);
     NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;
     nc.gm = GroupMap{1, 1, {nz->pass, 0, 0}, nz->stage, nz->sample};
-    if (ctx->generic) {            // the generic path stores NHWC8 images: convert to the NCHW the API returns
+    if (ctx->generic) {            // the generic path stores NHWC4 images: convert to the NCHW the API returns
         float* tmp = ctx->allocT<float>((size_t)M * ctx->img_store);
         if (!tmp) return 1;
         if (run_decoder(ctx, x, M, nc, 0, 1, val, tmp, st)) return 1;
@@ -1029,7 +1036,7 @@ int efe_encoder(efe_ctx* ctx, const float* o, int M, const efe_noise* nz, const 
     if (ctx->generic) {
         float* o8 = ctx->allocT<float>((size_t)M * ctx->img_store);
         if (!o8) return 1;
-        launch_to_nhwc8(o, o8, M, ctx->res * ctx->res, ctx->chan, st);
+        launch_to_nhwc4(o, o8, M, ctx->res * ctx->res, ctx->chan, st);
         o = o8;
     }
     if (run_encoder(ctx, o, M, nc, enc, st)) return 1;
@@ -1114,7 +1121,7 @@ int efe_rollout(efe_ctx* ctx, const float* o, const float* pi, int M, int steps,
         if (ctx->generic) {
             float* o8 = ctx->allocT<float>((size_t)M * ctx->img_store);
             if (!o8) return 1;
-            launch_to_nhwc8(o, o8, M, ctx->res * ctx->res, ctx->chan, st);
+            launch_to_nhwc4(o, o8, M, ctx->res * ctx->res, ctx->chan, st);
             o = o8;
         }
         if (run_encoder(ctx, o, M, nc, enc0, st)) return 1;

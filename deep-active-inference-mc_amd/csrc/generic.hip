@@ -14,7 +14,7 @@
 //                an LDS ring of T rows, the per-image Bernoulli-entropy / reward sums in a fixed order, and the image store
 //   k_conv_g   : the encoder's Conv2d(k3, s2, p0) + ReLU with operands straight from L2 (the round-1 style kernel; also the
 //                fallback of the ConvT layers when a strip does not fit: blockIdx.z = output parity)
-//   k_to_nhwc8 / k_to_nchw : layout changes at the API boundary (observations are NCHW, torchmodel.py:134)
+//   k_to_nhwc4 / k_to_nchw : layout changes at the API boundary (observations are NCHW, torchmodel.py:134)
 #include "kernels.h"
 #include <type_traits>
 
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256, 2) k_final_g(const FinalGArgs a) {
     group_decode(a.gm, g, gt, gp, gs);
     const int mode = (gp == 0 && a.reward0) ? 1 : 0;
     const int slot = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
-    float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + r) * ((size_t)H * W * 8) : nullptr;
+    float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + r) * ((size_t)H * W * GEN_IMG_LD) : nullptr;
     const float* y = a.y3 + (size_t)img * H * W * 32;
     const float D1 = 1.00001f, D0 = 0.00001f;
     const float bias[3] = {a.b[0], a.b[1], a.b[2]};
@@ -269,9 +269,7 @@ __global__ void __launch_bounds__(256, 2) k_final_g(const FinalGArgs a) {
                 if (c < C) part += term;
             }
             if (po) {
-                float* pp = po + ((size_t)oh * W + x) * 8;
-                reinterpret_cast<float4*>(pp)[0] = make_float4(p[0], C > 1 ? p[1] : 0.f, C > 2 ? p[2] : 0.f, 0.f);
-                reinterpret_cast<float4*>(pp)[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(po + ((size_t)oh * W + x) * GEN_IMG_LD) = make_float4(p[0], C > 1 ? p[1] : 0.f, C > 2 ? p[2] : 0.f, 0.f);
             }
         }
     }
@@ -293,11 +291,11 @@ int launch_final_g(const FinalGArgs& a, hipStream_t st) {
     return 0;
 }
 
-// NCHW [M][C][H][W] -> NHWC8 [M][H*W][8] (channels >= C zero) and back (first C channels)
-__global__ void k_to_nhwc8(const float* in, float* out, long n_pix_total, int HW, int C) {
+// NCHW [M][C][H][W] -> NHWC4 [M][H*W][4] (channels >= C zero) and back (first C channels); NHWC4 -> NHWC8 for k_conv_g's first layer
+__global__ void k_to_nhwc4(const float* in, float* out, long n_pix_total, int HW, int C) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n_pix_total * 8) return;
-    const long pix = gid >> 3; const int c = (int)(gid & 7);
+    if (gid >= n_pix_total * GEN_IMG_LD) return;
+    const long pix = gid >> 2; const int c = (int)(gid & 3);
     const long img = pix / HW; const int p = (int)(pix - img * HW);
     out[gid] = c < C ? in[(img * C + c) * HW + p] : 0.f;
 }
@@ -306,15 +304,24 @@ __global__ void k_to_nchw(const float* in, float* out, long n_elem, int HW, int 
     if (gid >= n_elem) return;
     const long img = gid / ((long)C * HW); const int rem = (int)(gid - img * (long)C * HW);
     const int c = rem / HW, p = rem - c * HW;
-    out[gid] = in[(img * HW + p) * 8 + c];
+    out[gid] = in[(img * HW + p) * GEN_IMG_LD + c];
 }
-void launch_to_nhwc8(const float* in, float* out, long M, int HW, int C, hipStream_t st) {
-    const long n = M * HW * 8;
-    hipLaunchKernelGGL(k_to_nhwc8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, M * HW, HW, C);
+__global__ void k_nhwc4_to_8(const float4* in, float4* out, long n_pix) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_pix) return;
+    out[2 * gid] = in[gid];
+    out[2 * gid + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+void launch_to_nhwc4(const float* in, float* out, long M, int HW, int C, hipStream_t st) {
+    const long n = M * HW * GEN_IMG_LD;
+    hipLaunchKernelGGL(k_to_nhwc4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, M * HW, HW, C);
 }
 void launch_to_nchw(const float* in, float* out, long M, int HW, int C, hipStream_t st) {
     const long n = M * C * HW;
     hipLaunchKernelGGL(k_to_nchw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, n, HW, C);
+}
+void launch_nhwc4_to_8(const float* in, float* out, long n_pix, hipStream_t st) {
+    hipLaunchKernelGGL(k_nhwc4_to_8, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(in), reinterpret_cast<float4*>(out), n_pix);
 }
 
 // check_reward on an arbitrary NCHW batch, generic geometry (same expression as k_final_g's reward branch)

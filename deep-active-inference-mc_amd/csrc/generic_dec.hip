@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     group_decode(a.gm, g, gt, gp, gs);
     const int mode = (gp == 0 && a.reward0) ? 1 : 0;
     const int slot = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
-    float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + r) * ((size_t)Hout * Wout * 8) : nullptr;
+    float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + r) * ((size_t)Hout * Wout * GEN_IMG_LD) : nullptr;
 
     const int npix_img = Hin * Win;
     const float* src = a.y2 + (size_t)img * npix_img * Cin;
@@ -434,9 +434,8 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     };
     auto g_store = [&](int it) {
         if (po && gok[it]) {
-            float4* pp = reinterpret_cast<float4*>(po + ((size_t)goh[it] * Wout + gox[it]) * 8);
-            pp[0] = make_float4(gv[it][0], C > 1 ? gv[it][C > 1 ? 1 : 0] : 0.f, C > 2 ? gv[it][C > 2 ? 2 : 0] : 0.f, 0.f);
-            pp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(po + ((size_t)goh[it] * Wout + gox[it]) * GEN_IMG_LD) =
+                make_float4(gv[it][0], C > 1 ? gv[it][C > 1 ? 1 : 0] : 0.f, C > 2 ? gv[it][C > 2 ? 2 : 0] : 0.f, 0.f);
         }
     };
     // The same sums for a strip with a successor (2 TH rows = at most two passes), with everything that does not depend on the strip taken

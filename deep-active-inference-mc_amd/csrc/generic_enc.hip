@@ -11,7 +11,7 @@
 // slots.  Channels are the MFMA rows (A = packed weights), pixels its columns (B = the LDS strip): a lane ends with 16 channels of
 // one pixel and stores four float4.
 //   L = 2 (32 input channels): 9 float4 per slot (8 + 1 padding), 9 taps x 4 channel blocks through the shared TapPipe.
-//   L = 1 (C <= 3 input channels read from the NHWC8 image): one float4 per slot holding (c0, c2, c1, c3), so that lane half h reads
+//   L = 1 (C <= 3 input channels read from the NHWC4 image): one float4 per slot holding (c0, c2, c1, c3), so that lane half h reads
 //       the float2 (c_h, c_{2+h}) = its K operand of the tap's two MFMAs; weights as 18 resident registers.
 #include "mfma_pipe.h"
 
@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_e(const ConvEArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 sx[];        // [NR ring rows][Win slots][PS4]
     constexpr int CQ = L == 1 ? 1 : 8;           // float4 per input pixel that are staged
     constexpr int PS4 = L == 1 ? 1 : 9;          // float4 per LDS slot
-    constexpr int IS = L == 1 ? 8 : 32;          // floats per input pixel in global memory
+    constexpr int IS = L == 1 ? GEN_IMG_LD : 32; // floats per input pixel in global memory
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;

@@ -226,11 +226,11 @@ struct DecBGArgs {
     int reward0, store0, reward_intent;
     RowMask live;
     float* val;                         // [batch] per-image sums
-    float* po;                          // [slots][rows_per_group][Hout * Wout][8] stored images (NHWC, channels padded to 8)
+    float* po;                          // [slots][rows_per_group][Hout * Wout][4] stored images (NHWC, channels padded to 4)
 };
 // LDS-tiled encoder Conv2d(k3, s2, p0) + ReLU of the generic path, layers 1 and 2 (generic_enc.hip)
 struct ConvEArgs {
-    const float* in;                    // layer 1: NHWC8 image [n][Hin * Win][8]; layer 2: [n][Hin * Win][32]
+    const float* in;                    // layer 1: NHWC4 image [n][Hin * Win][4]; layer 2: [n][Hin * Win][32]
     float* out;                         // [n][Hout * Wout][32]
     const float* Wp; const float* bias; // layer 2: packed [9][1][4][64][4]; layer 1: [9 taps][64 lanes][2] = W[co][h][tap], W[co][2 + h][tap]
     int n_img, Hin, Win, Hout, Wout;
@@ -249,11 +249,13 @@ struct FinalGArgs {
     int reward0, store0, reward_intent;
     RowMask live;
     float* val;                       // [batch] per-image sums
-    float* po;                        // [slots][rows_per_group][H*W][8] stored images (NHWC, channels padded to 8)
+    float* po;                        // [slots][rows_per_group][H*W][4] stored images (NHWC, channels padded to 4)
 };
 int launch_final_g(const FinalGArgs& a, hipStream_t st);       // non-zero: geometry outside the kernel's limits (W <= 128, C <= 3)
 int init_generic_kernels();
-void launch_to_nhwc8(const float* in, float* out, long M, int HW, int C, hipStream_t st);
+constexpr int GEN_IMG_LD = 4;          // floats per pixel of the generic path's stored images (NHWC, C <= 3 channels padded to 4)
+void launch_to_nhwc4(const float* in, float* out, long M, int HW, int C, hipStream_t st);       // NCHW -> NHWC4
+void launch_nhwc4_to_8(const float* in, float* out, long n_pix, hipStream_t st);                // NHWC4 -> NHWC8 (k_conv_g's first layer contracts 8 input channels)
 void launch_to_nchw(const float* in, float* out, long M, int HW, int C, hipStream_t st);
 void launch_check_reward_g(const float* o, float* out, int M, int C, int H, int W, int intent, hipStream_t st);
 
