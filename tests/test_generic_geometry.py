@@ -349,3 +349,23 @@ def test_tiled_encoder_layers_equal_direct_kernel(A2, C2, R2):
     finally:
         m.set_option('enc_tiled', 1)
     assert torch.equal(m1, m0_) and torch.equal(l1, l0) and torch.equal(s1, s0)
+
+
+@pytest.mark.parametrize('fuse', [1, 0])
+def test_reserve_no_growth_generic(fuse):
+    """efe_rollout_scratch_bytes mirrors the generic path's allocations (with and without the fused last two decoder layers): after
+    efe_reserve, calls at that size never grow the arena and stay under the reported size"""
+    import daimc_amd
+    m = daimc_amd.ActiveInferenceModel(10, A, 0.0, 1.0, 1.0, colour_channels=C, resolution=R, device='cuda:0', seed=2)
+    m.set_option('fuse_final_g', fuse)
+    need = m.reserve(9, 2, 3)
+    st0 = m.arena_stats()
+    assert st0['capacity_bytes'] >= need
+    o = synth.make_frames_rgb(35, 9, C, R)
+    pi = np.eye(A, dtype=np.float32)[np.arange(9) % A]
+    for k in range(2):
+        m.calculate_G_repeated(o, pi, steps=2, samples=3, stage=10 * k)
+    torch.cuda.synchronize()
+    st1 = m.arena_stats()
+    assert st1['grow_count'] == st0['grow_count'] and st1['capacity_bytes'] == st0['capacity_bytes']
+    assert 0 < st1['high_water_bytes'] <= need
