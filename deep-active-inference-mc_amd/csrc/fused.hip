@@ -194,6 +194,7 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
     const unsigned ln = (unsigned)lane * 16u;
     const int e0 = blockIdx.x * FR;
     const int E = a.E, T = a.T;
+    const uint32_t stage_ = a.stage + stage_bump(a.ctr, a.ctr_mul);
     if (tid < FR * 16) {
         const int rr = tid >> 4, k = tid & 15, e = e0 + rr;
         srow[tid] = (k < 10 && e < E) ? a.s0[(size_t)e * 10 + k] : 0.f;
@@ -224,7 +225,7 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
             int act = 0;
             if (!bad && tot > 0.f) {
                 const float u = a.u_inj ? a.u_inj[(size_t)t * E + min(e, E - 1)]
-                                        : u01(noise_words(a.k0, a.k1, TAG_ACT, 0u, a.row_offset + e, stream_id(PASS_HABIT, (uint32_t)t), a.stage).x);
+                                        : u01(noise_words(a.k0, a.k1, TAG_ACT, 0u, a.row_offset + e, stream_id(PASS_HABIT, (uint32_t)t), stage_).x);
                 const float thr = u * tot;
                 float accq = 0.f; act = A - 1;
                 for (int k = 0; k < A; ++k) { accq += qq[k]; if (thr < accq) { act = k; break; } }
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
             }
             bufA[aswz(n, q)] = make_float4(v[0], v[1], v[2], v[3]);
         }
-        RowKey rk{a.row_offset + (uint32_t)(e0 + n), stream_id(PASS_SIM, (uint32_t)t), a.stage};
+        RowKey rk{a.row_offset + (uint32_t)(e0 + n), stream_id(PASS_SIM, (uint32_t)t), stage_};
         __syncthreads();
         trans_chain(a.W, bufA, bufB, w, n, q, ln, a.k0, a.k1, rk);
         // ---- reparameterise and scatter into the trajectory arrays (torchmodel.py:368-376, 382-390)
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
                 const float* o = reinterpret_cast<const float*>(bufA);
                 const float mean = o[4 * aswz(rr, k >> 2) + (k & 3)], lv = o[4 * aswz(rr, (10 + k) >> 2) + ((10 + k) & 3)];
                 const float eps = a.eps_inj ? a.eps_inj[((size_t)t * E + e) * 10 + k]
-                                            : normal_elem(a.k0, a.k1, a.row_offset + e, stream_id(PASS_SIM, (uint32_t)t), a.stage, k);
+                                            : normal_elem(a.k0, a.k1, a.row_offset + e, stream_id(PASS_SIM, (uint32_t)t), stage_, k);
                 const float samp = eps * expf(lv * 0.5f) + mean;
                 const size_t oo = ((size_t)e * T + t) * 10 + k;
                 a.s0_traj[oo] = srow[rr * 16 + k];

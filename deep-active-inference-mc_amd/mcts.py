@@ -34,6 +34,9 @@ class MCTS_Params:
         self.method = 'ai'
         self.using_prior_for_exploration = False
         self.samples = 1          # extension: MC samples per expansion (reference always expands with 1)
+        self.use_graph = False    # lock-step planner: replay the iteration as ONE captured hipGraph instead of ~50 launches (same results;
+                                  # measured neutral on MI355X -- a small-batch iteration is bound by its chain of dependent kernels on
+                                  # the GPU, 0.88 ms for one episode either way, not by the host's launches -- so it is off by default)
 
 
 class Node:
@@ -252,6 +255,18 @@ class BatchedMCTS:
         self.stop_at = torch.full((E,), -1, dtype=torch.int32, device=dev)
         self.n_active = torch.zeros(1, dtype=torch.int32, device=dev)
         self.q0 = torch.zeros(E, A, device=dev)
+        # graph form of the loop (see _loop_graph): the iteration index / noise stage live in device words, the iteration's history row
+        # is written to fixed scratch rows and copied into the history by a kernel, every buffer an iteration touches is persistent
+        self.active = torch.zeros(E, dtype=torch.uint8, device=dev)
+        self.it = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.stg = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.cur_act = torch.zeros(E, self.max_depth, dtype=torch.int32, device=dev)
+        self.cur_len = torch.zeros(E, dtype=torch.int32, device=dev)
+        self.cur_g = torch.zeros(E, device=dev)
+        self.cur_active = torch.zeros(E, dtype=torch.uint8, device=dev)
+        self.root_nodes = torch.zeros(E, dtype=torch.int32, device=dev)
+        self.plan_stream = None
+        self._graph, self._graph_key = None, None
         # The simulation of an iteration (habit rollout from the leaf + G over its trajectory: ~1 ms of small launches) is
         # independent of the expansion of the same leaf (~6 ms of large ones): with more than a few episodes it runs on a second
         # stream through a replica context, so its launch-bound chain hides under the expansion's MFMA-bound kernels.
@@ -271,14 +286,15 @@ class BatchedMCTS:
         import ctypes as C
         return C.c_void_p(t.data_ptr())
 
-    def _expand(self, nodes, mask, states_rep, stage=None):
+    def _expand(self, nodes, mask, states_rep, stage=None, eps_stage=None):
         """ONE engine call over E x pi_dim rows (Node.expand, mcts.py:64-86); tree bookkeeping only where mask[e]"""
         m, p_ = self.model, self._p
         ro = self.ep0 * self.pi_dim
         if self.p.use_means:
-            G, _, ps_next, _ = m.calculate_G_mean(states_rep, self.pi_hot, row_offset=ro, stage=stage)
+            G, _, ps_next, _ = m.calculate_G_mean(states_rep, self.pi_hot, row_offset=ro, stage=stage, eps_stage=eps_stage)
         else:
-            G, _, ps_next, _, _ = m.calculate_G(states_rep, self.pi_hot, samples=getattr(self.p, 'samples', 1), row_offset=ro, stage=stage)
+            G, _, ps_next, _, _ = m.calculate_G(states_rep, self.pi_hot, samples=getattr(self.p, 'samples', 1), row_offset=ro, stage=stage,
+                                                eps_stage=eps_stage)
         G, ps_next = G.contiguous(), ps_next.contiguous()
         self._call(m._engine.lib.efe_mcts_expand, p_(self.n_nodes), p_(nodes), p_(mask), p_(G), p_(ps_next))
 
@@ -294,10 +310,17 @@ class BatchedMCTS:
                 break
         return _trim_path(visited, self.pi_dim)
 
+    def reset(self):
+        """fresh trees (a planner object, with its buffers and its captured iteration, is reused across decisions)"""
+        self.W.zero_(); self.N.zero_(); self.Qpi.zero_()
+        self.child.fill_(-1); self.n_nodes.fill_(1); self.stop_at.fill_(-1)
+
     def run(self, frames, o_shape=(64, 64, 1)):
         # the little host-side work left (habit shortcut, final path read-out) uses tiny tensors: one intra-op thread
         prev = torch.get_num_threads()
         torch.set_num_threads(1)
+        if self.overlap:
+            self.sim_model = self.model.cached_replica()       # same object unless the weights changed; refreshed noise settings
         try:
             return self._run(frames, o_shape)
         finally:
@@ -323,14 +346,15 @@ class BatchedMCTS:
                     active_h[e] = False
         if not bool(active_h.any()):        # every episode was decided by the habit shortcut (mcts.py:166-169): nothing to plan
             return res
-        active = active_h.to(torch.uint8).to(m.device)
+        self.active.copy_(active_h.to(torch.uint8))
+        active = self.active
         # early-stopped (and habit-decided) episodes stop costing flops: the engine's per-image kernels read `active` on the device
         # and skip their rows (efe_set_row_mask; efe_mcts_stop clears entries as the loop runs, no host round trip involved)
         if getattr(p, 'skip_stopped', True):
             m.set_row_mask(active, A)
             if self.overlap:
                 self.sim_model.set_row_mask(active, 1)
-        self._expand(torch.zeros(E, dtype=torch.int32, device=m.device), active, self.S[:, 0].repeat_interleave(A, dim=0).contiguous())
+        self._expand(self.root_nodes, active, self.S[:, 0].repeat_interleave(A, dim=0).contiguous())
         n_iter = 0
         # The per-episode early stop (mcts.py:176) is applied on the device every iteration (stopped episodes are masked out of
         # every tree update); the host only needs to know when ALL episodes have stopped, to end the loop early.  It looks at
@@ -342,7 +366,10 @@ class BatchedMCTS:
         # reserved up front and indexed by the iteration: what a later call draws does not depend on E or on when the loop ended
         per_it = 1 + p.simulation_repeats
         st0 = m._take_stage(None, p.repeats * per_it)
-        for repeat in range(p.repeats):
+        use_graph = bool(getattr(p, 'use_graph', False))
+        if use_graph and p.repeats > 0:
+            n_iter = self._loop_graph(st0, per_it, can_stop, CHECK)
+        for repeat in range(0 if not use_graph else p.repeats, p.repeats):
             self._call(lib.efe_mcts_stop, p_(active), p_(self.stop_at), repeat, float(p.threshold), p_(self.n_active))
             if can_stop and (repeat % CHECK == 0 or E == 1) and int(self.n_active.item()) == 0:
                 break
@@ -386,6 +413,84 @@ class BatchedMCTS:
             res[e] = (self.action_selection(e, N, child), reps, explored, paths, Gs)
         return res
 
+    # ---- the iteration as a replayable launch sequence -----------------------------------------------------
+    def _body(self, eps_stage=None):
+        """ONE planner iteration (early stop -> select -> expansion || simulation -> back-propagation -> history row) whose kernel arguments
+        do not depend on the iteration: the index comes from self.it, the noise stage from self.stg (efe_set_stage_counter), the history
+        row goes through fixed scratch rows (efe_mcts_record).  eps_stage: the iteration's first stage, for injected-noise runs only."""
+        m, p, p_ = self.model, self.p, self._p
+        lib = m._engine.lib
+        e = m._ready()
+        self._call(lib.efe_mcts_stop_dev, p_(self.active), p_(self.stop_at), p_(self.it), float(p.threshold), p_(self.n_active))
+        self._call(lib.efe_mcts_select, p_(self.active), float(p.C), 1 if p.using_prior_for_exploration else 0, self.max_depth,
+                   p_(self.path_nodes), p_(self.cur_act), p_(self.cur_len), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))
+        es = (lambda k: None) if eps_stage is None else (lambda k: eps_stage + k)
+
+        def simulate(model):
+            for r in range(p.simulation_repeats):
+                G, _, q0 = model.simulate_batch(self.leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0, stage=1 + r, eps_stage=es(1 + r))
+                self.sims[r].copy_(G)
+                self.q0.copy_(q0)
+        if self.overlap:
+            cur = torch.cuda.current_stream(m.device)
+            self.ev_sel.record(cur)
+            with torch.cuda.stream(self.sim_stream):
+                self.sim_stream.wait_event(self.ev_sel)
+                simulate(self.sim_model)
+                self.ev_sim.record(self.sim_stream)
+            self._expand(self.leaf, self.active, self.leaf_rep, stage=0, eps_stage=es(0))
+            cur.wait_event(self.ev_sim)
+        else:
+            self._expand(self.leaf, self.active, self.leaf_rep, stage=0, eps_stage=es(0))
+            simulate(m)
+        self._call(lib.efe_mcts_backprop, p_(self.path_nodes), p_(self.cur_act), p_(self.cur_len), p_(self.leaf), p_(self.active),
+                   p_(self.sims), int(p.simulation_repeats), p_(self.q0), self.max_depth, p_(self.cur_g), p_(self.cur_active))
+        e.check(lib.efe_mcts_record(e.ctx, p_(self.it), self.E, self.max_depth, p_(self.cur_act), p_(self.cur_len), p_(self.cur_g),
+                                    p_(self.cur_active), p_(self.H_act), p_(self.H_len), p_(self.H_g), p_(self.H_active), e.stream()))
+        e.check(lib.efe_counter_add(e.ctx, p_(self.it), 1, e.stream()))
+        e.check(lib.efe_counter_add(e.ctx, p_(self.stg), 1 + p.simulation_repeats, e.stream()))
+
+    def _loop_graph(self, st0, per_it, can_stop, CHECK):
+        """the planning loop as: iteration 0 launched normally (it also sizes the scratch arenas), iterations 1.. as replays of ONE captured
+        hipGraph of _body -- ~50 launches per iteration become one graph launch, which is what a few-episode decision is bound by.
+        Device noise only (injected-noise runs launch _body every iteration: their normals are built on the host per stage)."""
+        m, p = self.model, self.p
+        dev = m.device
+        if self.plan_stream is None:
+            self.plan_stream = torch.cuda.Stream(device=dev)
+        models = [m] + ([self.sim_model] if self.overlap else [])
+        injected = m.eps_source is not None or m.u_source is not None
+        self.plan_stream.wait_stream(torch.cuda.current_stream(dev))
+        n_iter = 0
+        try:
+            with torch.cuda.stream(self.plan_stream):
+                self.it.zero_()
+                self.stg.fill_(int(st0))
+                for mm in models:
+                    mm.set_stage_counter(self.stg, 1)
+                self._body(eps_stage=st0 if injected else None)
+                n_iter = 1
+                key = (getattr(m, '_weights_version', 0),) + tuple(tuple(sorted(mm.arena_stats().items())) for mm in models)
+                if not injected and (self._graph is None or self._graph_key != key):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.plan_stream):
+                        self._body()
+                    self._graph, self._graph_key = g, key
+                while n_iter < p.repeats:
+                    if injected:
+                        self._body(eps_stage=st0 + n_iter * per_it)
+                    else:
+                        self._graph.replay()
+                    n_iter += 1
+                    if can_stop and n_iter % CHECK == 0 and int(self.n_active.item()) == 0:
+                        break
+                self.plan_stream.synchronize()
+        finally:
+            for mm in models:
+                mm.set_stage_counter(None)
+        torch.cuda.current_stream(dev).wait_stream(self.plan_stream)
+        return n_iter
+
     def root_visit_distribution(self):
         """N / sum N at the roots, [E, pi_dim]: the policy-value that multi-GPU runs gather (mcts.py:177)"""
         n = self.N[:, 0].cpu()
@@ -396,6 +501,21 @@ def active_inference_mcts_batch(model, frames, params, o_shape=(64, 64, 1), epis
     """E planning decisions in lock-step; returns a list of E tuples shaped like active_inference_mcts's result and
     the [E, pi_dim] root visit distribution."""
     frames = torch.as_tensor(frames)
-    planner = BatchedMCTS(model, frames.shape[0], params, episode_offset)
+    # planner objects (device buffers + the captured iteration graph) are kept per (episodes, offset, parameters) on the model
+    try:
+        key = (int(frames.shape[0]), int(episode_offset), tuple(sorted((k, v) for k, v in vars(params).items())))
+        hash(key)
+    except TypeError:
+        key = None
+    cache = model.__dict__.setdefault('_planners', {})
+    planner = cache.get(key) if key is not None else None
+    if planner is None:
+        planner = BatchedMCTS(model, frames.shape[0], params, episode_offset)
+        if key is not None:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            cache[key] = planner
+    else:
+        planner.reset()
     out = planner.run(frames, o_shape)
     return out, planner.root_visit_distribution()

@@ -359,6 +359,20 @@ class ActiveInferenceModel:
         self._row_mask = mask
         e.check(e.lib.efe_set_row_mask(e.ctx, C.c_void_p(mask.data_ptr()), int(rows_per_entry)))
 
+    def set_stage_counter(self, counter, mul=1):
+        """efe_set_stage_counter: every noise stage of the following calls on this model is stage + counter[0] * mul, read on the device
+        when the kernels run (`counter`: a 1-element int32 / uint32 tensor on this device, kept alive by the caller; None clears).  This is
+        what lets a captured launch sequence (hipGraph) replay with fresh noise."""
+        e = self._ready()
+        if counter is None:
+            self._stage_counter = None
+            e.check(e.lib.efe_set_stage_counter(e.ctx, None, 0))
+            return
+        if counter.device != self.device or counter.numel() != 1 or counter.element_size() != 4:
+            raise ValueError('set_stage_counter: a 1-element 32-bit integer tensor on the model device is required')
+        self._stage_counter = counter
+        e.check(e.lib.efe_set_stage_counter(e.ctx, C.c_void_p(counter.data_ptr()), int(mul)))
+
     def arena_stats(self):
         """-> dict(capacity_bytes, high_water_bytes, grow_count)"""
         e = self._engine
@@ -466,7 +480,7 @@ class ActiveInferenceModel:
         _, Qpi, _ = self.model_top.encode_s(qs_mean)
         return Qpi
 
-    def calculate_G(self, s0, pi0, samples=10, *, stage=None, eps=None, row_offset=None, _mean_mode=False, _parts=None):
+    def calculate_G(self, s0, pi0, samples=10, *, stage=None, eps=None, row_offset=None, _mean_mode=False, _parts=None, eps_stage=None):
         """torchmodel.py:270-300 -> (G, [term0, term1, term2], ps1, ps1_mean, po1)"""
         e = self._ready()
         s0 = e.tensor(s0, (-1, self.s_dim)); pi0 = e.tensor(pi0, (-1, self.pi_dim))
@@ -475,8 +489,8 @@ class ActiveInferenceModel:
         S = 1 if _mean_mode else int(samples)
         if S < 1:
             raise RuntimeError('efe engine: samples must be >= 1')
-        if eps is None and self.eps_source is not None:
-            eps = self._src_eps_calcG(M, S, nz.stage, row_offset)
+        if eps is None and self.eps_source is not None:       # (eps_stage: the stage the injected normals belong to when a device-side
+            eps = self._src_eps_calcG(M, S, nz.stage if eps_stage is None else int(eps_stage), row_offset)      # stage counter supplies part of it)
         eps_t = e.tensor(eps, (3 * S, M, 10)) if eps is not None else None
         G, terms, ps1, ps1_mean, po1, parts = e.ops.calculate_g(e.h, s0, pi0, S, bool(_mean_mode), self._seed64(), nz.stage,
                                                                 nz.row_offset, eps_t)
@@ -486,9 +500,9 @@ class ActiveInferenceModel:
             return G, [terms[0], terms[1], terms[2]], ps1_mean, po1
         return G, [terms[0], terms[1], terms[2]], ps1, ps1_mean, po1
 
-    def calculate_G_mean(self, s0, pi0, *, stage=None, eps=None, row_offset=None, _parts=None):
+    def calculate_G_mean(self, s0, pi0, *, stage=None, eps=None, row_offset=None, _parts=None, eps_stage=None):
         """torchmodel.py:302-327 -> (G, terms, ps1_mean, po1)"""
-        return self.calculate_G(s0, pi0, 1, stage=stage, eps=eps, row_offset=row_offset, _mean_mode=True, _parts=_parts)
+        return self.calculate_G(s0, pi0, 1, stage=stage, eps=eps, row_offset=row_offset, _mean_mode=True, _parts=_parts, eps_stage=eps_stage)
 
     def _rollout(self, o, pi, steps, calc_mean, samples, per_stage_mean, stage, eps, row_offset):
         e = self._ready()
@@ -539,7 +553,7 @@ class ActiveInferenceModel:
         eps_t = e.tensor(eps, (3, T, 10)) if eps is not None else None
         return e.ops.trajectory(e.h, s0, ps1, mean, lv, pi0, self._seed64(), nz.stage, nz.row_offset, eps_t)
 
-    def simulate_batch(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None, eps=None, u=None):
+    def simulate_batch(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None, eps=None, u=None, eps_stage=None):
         """mcts_step_simulate for E lock-step episodes -> (G[E], pi0[E,depth,4], Qpi0[E,4]).
         eps: optional injected normals, flat [depth*E*10 (step transitions)] + [3*E*depth*10 (trajectory T1/T2/D2B)];
         u: optional injected action uniforms [depth, E]."""
@@ -548,12 +562,13 @@ class ActiveInferenceModel:
         E, T = s.shape[0], int(depth)
         nz = self._noise(stage, 0, 0, row_offset)
         ro = self.row_offset if row_offset is None else int(row_offset)
+        src_stage = nz.stage if eps_stage is None else int(eps_stage)
         if eps is None and self.eps_source is not None:
-            parts = [self._src_eps(E, 10, PASS_SIM, t, nz.stage, ro).reshape(-1) for t in range(T)]
-            parts.append(self._src_eps_calcG(E * T, 1, nz.stage, ro * T).reshape(-1))
+            parts = [self._src_eps(E, 10, PASS_SIM, t, src_stage, ro).reshape(-1) for t in range(T)]
+            parts.append(self._src_eps_calcG(E * T, 1, src_stage, ro * T).reshape(-1))
             eps = np.concatenate(parts)
         if u is None and self.u_source is not None:
-            u = np.stack([np.asarray(self.u_source(self.seed, E, PASS_HABIT, t, nz.stage, ro), dtype=np.float32) for t in range(T)], 0)
+            u = np.stack([np.asarray(self.u_source(self.seed, E, PASS_HABIT, t, src_stage, ro), dtype=np.float32) for t in range(T)], 0)
         eps_t = e.tensor(eps).reshape(-1) if eps is not None else None
         if eps_t is not None and eps_t.numel() != 4 * T * E * 10:
             raise ValueError(f'eps has {eps_t.numel()} elements, efe_simulate expects depth*E*10 + 3*E*depth*10 = {4 * T * E * 10}')

@@ -17,3 +17,20 @@ p = daimc_amd.MCTS_Params(); p.repeats = 50; p.simulation_depth = 5; p.threshold
 print('active_inference_mcts 50 repeats %.1f ms' % t(lambda: daimc_amd.active_inference_mcts(m, frame, p, o_shape=(1, 64, 64)), n=3))
 p.use_means = False
 print('  ... use_means=False            %.1f ms' % t(lambda: daimc_amd.active_inference_mcts(m, frame, p, o_shape=(1, 64, 64)), n=3))
+# lock-step planner with one episode: every iteration launched vs the iteration replayed from a captured hipGraph (device noise)
+fr1 = frame.reshape(1, 1, 64, 64)
+for samples in (1, 10):
+    for mode in (False, True):
+        q = daimc_amd.MCTS_Params(); q.repeats = 50; q.simulation_depth = 5; q.threshold = 2.0; q.use_means = False; q.samples = samples; q.use_graph = mode
+        print('active_inference_mcts_batch E=1, 50 repeats, samples=%d, %s  %.1f ms' % (samples, 'hipGraph replay ' if mode else 'launched        ',
+              t(lambda: daimc_amd.active_inference_mcts_batch(m, fr1, q, o_shape=(1, 64, 64)), n=5)))
+fr4 = torch.rand(4, 1, 64, 64, device='cuda')
+for mode in (False, True):
+    q = daimc_amd.MCTS_Params(); q.repeats = 50; q.simulation_depth = 5; q.threshold = 2.0; q.use_means = False; q.samples = 10; q.use_graph = mode
+    print('active_inference_mcts_batch E=4, 50 repeats, samples=10, %s  %.1f ms' % ('hipGraph replay ' if mode else 'launched        ',
+          t(lambda: daimc_amd.active_inference_mcts_batch(m, fr4, q, o_shape=(1, 64, 64)), n=5)))
+fr64 = torch.rand(64, 1, 64, 64, device='cuda')
+for mode in (False, True):
+    q = daimc_amd.MCTS_Params(); q.repeats = 50; q.simulation_depth = 5; q.threshold = 2.0; q.use_means = False; q.samples = 10; q.use_graph = mode
+    print('active_inference_mcts_batch E=64, 50 repeats, samples=10, %s  %.1f ms' % ('hipGraph replay ' if mode else 'launched        ',
+          t(lambda: daimc_amd.active_inference_mcts_batch(m, fr64, q, o_shape=(1, 64, 64)), n=3)))
