@@ -224,8 +224,12 @@ class BatchedMCTS:
 
     def __init__(self, model, n_episodes, params, episode_offset=0):
         import ctypes as C
+        import weakref
         from . import _lib
-        self.model, self.E, self.p = model, int(n_episodes), params
+        # (a weak reference: planner objects are cached ON the model, a strong one would make a cycle and defer the engine context's
+        # release to the garbage collector)
+        self._model_ref = weakref.ref(model)
+        self.E, self.p = int(n_episodes), params
         self.pi_dim = A = model.pi_dim
         self.ep0 = int(episode_offset)
         self.cap = cap = 1 + A * (params.repeats + 2)
@@ -276,6 +280,10 @@ class BatchedMCTS:
             self.sim_stream = torch.cuda.Stream(device=dev)
             self.ev_sel = torch.cuda.Event()
             self.ev_sim = torch.cuda.Event()
+
+    @property
+    def model(self):
+        return self._model_ref()
 
     def _call(self, fn, *args):
         e = self.model._ready()
