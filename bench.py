@@ -494,6 +494,11 @@ def main():
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(a))
+    # stdout carries exactly ONE line, the JSON: everything else that writes to file descriptor 1 (RCCL prints a version banner there
+    # when the process group is torn down) is pointed at stderr; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = 0 if a.share_device else int(os.environ.get('LOCAL_RANK', '0'))
@@ -520,7 +525,7 @@ def main():
 
     def emit(out):
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            os.write(real_stdout, (json.dumps(out) + '\n').encode())
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
