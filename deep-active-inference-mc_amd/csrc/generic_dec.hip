@@ -60,12 +60,13 @@ __global__ void __launch_bounds__(256, 3) k_convt_p(const ConvGArgs a) {
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
     };
     // strip 0: rows -PADT .. TH -> slots 0 .. RP - 1; the zero region
-    for (int pp0 = ppt; pp0 < RP; pp0 += 4 * pstep) {
-        float4 v[4];
+    // (all requests of the block in flight together: batches of 4 were up to four HBM round trips per image with the workgroup idle)
+    for (int pp0 = ppt; pp0 < RP; pp0 += 8 * pstep) {
+        float4 v[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fetch(pp0 + i * pstep - PADT * Win, pp0 + i * pstep < RP);
+        for (int i = 0; i < 8; ++i) v[i] = fetch(pp0 + i * pstep - PADT * Win, pp0 + i * pstep < RP);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 8; ++i)
             if (pp0 + i * pstep < RP) cl_x[(pp0 + i * pstep) * PS4 + c4] = v[i];
     }
     for (int i = tid; i < 16 * PS4; i += 256) cl_x[ZP * PS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -333,13 +334,14 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
         const unsigned off = ok ? (unsigned)((P * Cin + 4 * c4) * 4) : 0x80000000u;
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
     };
-    for (int pp0 = ppt; pp0 < RP; pp0 += 64) {        // strip 0: rows 0 .. TH -> slots 0 .. RP - 1
-        float4 v[4];
+    {   // strip 0: rows 0 .. TH -> slots 0 .. RP - 1 (RP <= 192 pixels = 12 float4 per thread, all requested before the first is written:
+        // one HBM round trip per image instead of three)
+        float4 v[12];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fetch(pp0 + 16 * i, pp0 + 16 * i < RP);
+        for (int i = 0; i < 12; ++i) v[i] = fetch(ppt + 16 * i, ppt + 16 * i < RP);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (pp0 + 16 * i < RP) sm[(pp0 + 16 * i) * PS4 + c4] = v[i];
+        for (int i = 0; i < 12; ++i)
+            if (ppt + 16 * i < RP) sm[(ppt + 16 * i) * PS4 + c4] = v[i];
     }
     for (int i = tid; i < 16 * PS4; i += 256) sm[ZP * PS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];

@@ -47,12 +47,15 @@ __global__ void __launch_bounds__(256, 2) k_conv_e(const ConvEArgs a) {
         return (r * Win + ((x & 1) ? WE + (x >> 1) : (x >> 1))) * PS4 + c4;
     };
     // strip 0: input rows 0 .. 2 TY -> ring slots 0 .. NR - 1
-    for (int pp0 = ppt; pp0 < NR * Win; pp0 += 4 * pstep) {
-        float4 v[4];
+    // (NPRO requests in flight together: the whole block for the shapes of BASELINE configs[4] -- batches of 4 were five HBM round trips
+    // per image at a third of a layer-2 image's time)
+    constexpr int NPRO = L == 1 ? 4 : 20;
+    for (int pp0 = ppt; pp0 < NR * Win; pp0 += NPRO * pstep) {
+        float4 v[NPRO];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fetch(pp0 + i * pstep, pp0 + i * pstep < NR * Win);
+        for (int i = 0; i < NPRO; ++i) v[i] = fetch(pp0 + i * pstep, pp0 + i * pstep < NR * Win);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NPRO; ++i)
             if (pp0 + i * pstep < NR * Win) sx[slot_of(pp0 + i * pstep, 0)] = v[i];
     }
     // this lane's output pixel of a strip
