@@ -92,3 +92,18 @@ def test_stale_library_is_refused(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, '_lib', None)
     with pytest.raises(ImportError, match='stale'):
         _lib.load()
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` without a launcher environment starts its own N ranks -- one per GPU; with fewer visible HIP devices
+    than ranks it stops with a message (exit code 2) instead of stacking ranks on one device (--share-device is the explicit
+    launcher-test mode).  Runs on the CPU box: zero devices are visible here."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], capture_output=True, text=True, env=env, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('two devices are visible: the launcher would start the ranks')
+    assert r.returncode == 2, (r.returncode, r.stderr[-400:])
+    assert 'one rank per GPU' in r.stderr and r.stdout.strip() == ''
