@@ -23,7 +23,6 @@ constexpr int EN_B2 = EN_W1 + 320;             // conv2 / conv3 / conv4 biases [
 constexpr int EN_B3 = EN_B2 + 32;              // load there exposes an L2 round trip per phase and image)
 constexpr int EN_B4 = EN_B3 + 64;
 constexpr int EN_END = EN_B4 + 64;             // 11776 floats = 47104 B: three workgroups per CU
-constexpr int EN_RED = EN_C2;                  // conv4 split-K partials alias the (dead) conv2 output
 
 __global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
@@ -38,7 +37,7 @@ __global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs 
     const float4* w1s = reinterpret_cast<const float4*>(smf + EN_W1);
     const float4* W2 = reinterpret_cast<const float4*>(a.w2) + lane;      // [9][1][4][64]
     const float4* W3 = reinterpret_cast<const float4*>(a.w3);             // [9][2][4][64] (uniform base, see TapPipe)
-    const float4* W4 = reinterpret_cast<const float4*>(a.w4);             // [9][2][8][64]
+    const float4* W4 = reinterpret_cast<const float4*>(a.w4);             // [9][4][4][64], packed for the 16x16x4 form
 
     for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
         if (!row_live(a.live, img)) continue;            // a dead row of the call (efe_set_row_mask): workgroup-uniform
@@ -162,42 +161,46 @@ __global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs 
         }
         __syncthreads();
 
-        // ================= conv4: 9 pixels x 64 channels, K = 9 taps x 64 split over two waves per channel tile ==================
+        // ================= conv4: 9 pixels x 64 channels on v_mfma_f32_16x16x4_f32 (9 of 16 columns live, against 9 of 32 on the wide
+        // tile): wave w owns channels 16w..16w+15 over the whole K = 9 taps x 64, two accumulator chains (the form's dependent latency
+        // is 40 cycles against a 32-cycle issue).  D row 4q + r of lane (q, px) = four consecutive channels of one pixel: one store.
         {
-            const int mt = w & 1, kh2 = w >> 1;                 // kh2 = 0: taps 0..4, kh2 = 1: taps 5..8
-            const bool pv = j < 9;
-            const int mm = pv ? j : 0;
+            const int px = ll & 15, q = ll >> 4;
+            const bool pv = px < 9;
+            const int mm = pv ? px : 0;
             const int oy = mm / 3, ox = mm - oy * 3;
-            const int t0 = kh2 ? 5 : 0, nt_ = kh2 ? 4 : 5;
-            f32x16 acc[1][1];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.f;
-            tap_loop_kc<1, 1, 8>(acc, nt_, W4, sm4 + EN_C3 / 4, h, [&](int tt, int (&bs)[1], int (&sw)[1], int& wt) {
-                const int t = t0 + tt;
-                const int kh = t / 3, kw = t - kh * 3;
-                wt = t;
+            const unsigned ln = (unsigned)lane * 16u;
+            const __amdgpu_buffer_rsrc_t wr = wrsrc(W4);
+            constexpr int PD = 4;                           // weight fragments (L2) requested four 128-cycle steps ahead
+            auto bfrag = [&](int i) {
+                const int t = i >> 2, kh = t / 3, kw = t - kh * 3;
                 const int sp = (2 * oy + kh) * 7 + 2 * ox + kw;
-                bs[0] = sp * 16; sw[0] = sp & 15;
-            }, PackedWIdx{2, 8, mt});
-            float* red = smf + EN_RED + (size_t)mt * 16 * 64;   // [mt][e 0..15][lane]
-            if (kh2 == 1) {
+                return sm4[EN_C3 / 4 + sp * 16 + (((i & 3) * 4 + q) ^ (sp & 15))];
+            };
+            float4 aq[PD];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) red[e * 64 + lane] = acc[0][0][e];
+            for (int p = 0; p < PD; ++p) aq[p] = wfrag(wr, ln, (size_t)(p * 4 + w) * 64);
+            float4 bv = bfrag(0);
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 36; ++i) {
+                const float4 av = aq[i % PD];
+                if (i + PD < 36) aq[i % PD] = wfrag(wr, ln, (size_t)((i + PD) * 4 + w) * 64);
+                const float4 bn = bfrag(i + 1 < 36 ? i + 1 : i);
+                __builtin_amdgcn_sched_barrier(0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, c1, 0, 0, 0);
+                bv = bn;
             }
-            __syncthreads();
-            if (kh2 == 0 && pv) {
-                float* op = a.out + (size_t)img * 576 + j * 64;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int c4 = mt * 8 + 2 * g4 + h;
-                    const float4 bb = sm4[EN_B4 / 4 + c4];
-                    float4 v;
-                    v.x = fmaxf(acc[0][0][4 * g4 + 0] + red[(4 * g4 + 0) * 64 + lane] + bb.x, 0.f);
-                    v.y = fmaxf(acc[0][0][4 * g4 + 1] + red[(4 * g4 + 1) * 64 + lane] + bb.y, 0.f);
-                    v.z = fmaxf(acc[0][0][4 * g4 + 2] + red[(4 * g4 + 2) * 64 + lane] + bb.z, 0.f);
-                    v.w = fmaxf(acc[0][0][4 * g4 + 3] + red[(4 * g4 + 3) * 64 + lane] + bb.w, 0.f);
-                    reinterpret_cast<float4*>(op)[c4] = v;
-                }
+            if (pv) {
+                const int c4 = w * 4 + q;
+                const float4 bb = sm4[EN_B4 / 4 + c4];
+                float4 v;
+                v.x = fmaxf(c0[0] + c1[0] + bb.x, 0.f); v.y = fmaxf(c0[1] + c1[1] + bb.y, 0.f);
+                v.z = fmaxf(c0[2] + c1[2] + bb.z, 0.f); v.w = fmaxf(c0[3] + c1[3] + bb.w, 0.f);
+                reinterpret_cast<float4*>(a.out + (size_t)img * 576 + px * 64)[c4] = v;
             }
         }
         __syncthreads();        // conv3's output (aliasing the input image buffer) is consumed: the next image may be staged

@@ -827,6 +827,15 @@ int efe_commit_weights(efe_ctx* ctx) {
         const float* W = w->data.data(); const int Cin = cci[i];
         if (upload_packed(ctx, ctx->enc_conv[i], 9, cco[i], Cin,
                           [&](int t, int co, int ci) { return W[((size_t)co * Cin + ci) * 9 + t]; }, b->data.data(), nullptr)) return 1;
+        if (i == 2) {
+            // conv4 runs on v_mfma_f32_16x16x4_f32 (its 9 output pixels fill 9/16 of that tile, 9/32 of the 32-wide one): same buffer size,
+            // [tap][16-channel block of Cin][16-channel tile of Cout][lane = (m, q)][s] = W[16 mt + m][16 blk + 4 q + s][tap]
+            std::vector<float> p((size_t)9 * 4 * 4 * 256);
+            for (int t = 0; t < 9; ++t) for (int blk = 0; blk < 4; ++blk) for (int mt = 0; mt < 4; ++mt) for (int lane = 0; lane < 64; ++lane)
+                for (int s_ = 0; s_ < 4; ++s_)
+                    p[((((size_t)t * 4 + blk) * 4 + mt) * 64 + lane) * 4 + s_] = W[((size_t)(16 * mt + (lane & 15)) * 64 + 16 * blk + 4 * (lane >> 4) + s_) * 9 + t];
+            HIPCHK(hipMemcpy(ctx->enc_conv[2].Wp, p.data(), p.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     {   // Flatten is channel-major c*9 + p (torchmodel.py:93); our conv4 output is NHWC p*64 + c
         std::vector<int> colp(576);

@@ -120,7 +120,7 @@ struct EncArgs {
     const float* w1; const float* b1;   // conv1 [9 taps][32], [32]
     const float* w2; const float* b2;   // packed [9][1][4][64][4]
     const float* w3; const float* b3;   // packed [9][2][4][64][4]
-    const float* w4; const float* b4;   // packed [9][2][8][64][4]
+    const float* w4; const float* b4;   // packed [9][4][4][64][4] (16x16x4 form)
     int rows;
     RowMask live;
 };
