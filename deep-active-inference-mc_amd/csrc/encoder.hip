@@ -3,9 +3,9 @@
 // one image per workgroup, every intermediate in LDS; only the 576-vector (NHWC p*64+c order, the column order the
 // packed first dense layer expects) leaves the chip.
 //
-//   conv1 (Cin = 1) is never materialised: while the conv2 MFMAs run, the VALU recomputes the conv1 activations a
-//   lane needs for its next B fragment straight from the 16 KiB input image in LDS (9 FMAs per value, conv1 weights
-//   as broadcast LDS reads).  conv2..4 are MFMA tap contractions (v_mfma_f32_32x32x2_f32) over swizzled LDS images.
+//   conv1 (Cin = 1) is never materialised: the conv1 activations a conv2 tap needs are produced by five MFMAs straight from
+//   the 16 KiB input image in LDS, in the register layout of the conv2 B operand.  conv2, conv3 are MFMA tap contractions
+//   (v_mfma_f32_32x32x2_f32) over swizzled LDS images, conv4 (9 pixels) runs on the 16-column form v_mfma_f32_16x16x4_f32.
 #include "mfma_pipe.h"
 
 #ifndef EFE_ENC_WAVES
@@ -18,8 +18,8 @@ constexpr int EN_IMG = 0;                      // [64][64] input image          
 constexpr int EN_C2 = 4096;                    // [225 px][32 ch] conv2 output, 8 quads/pixel, quad ^= px & 7
 constexpr int EN_C3 = EN_IMG;                  // [49 px][64 ch] conv3 output, 16 quads/pixel, quad ^= px & 15: aliases the input image
                                                // (dead once conv2 is done); 3136 <= 4096 floats
-constexpr int EN_W1 = EN_C2 + 225 * 32;        // conv1 weights [9 taps][32 ch] + bias [32]
-constexpr int EN_B2 = EN_W1 + 320;             // conv2 / conv3 / conv4 biases [32] [64] [64]: read in the epilogues from LDS (a global
+constexpr int EN_ONE = EN_C2 + 225 * 32;       // 320 x 1.0f: the "pixel" the conv1 bias row multiplies (any tap offset stays inside)
+constexpr int EN_B2 = EN_ONE + 320;             // conv2 / conv3 / conv4 biases [32] [64] [64]: read in the epilogues from LDS (a global
 constexpr int EN_B3 = EN_B2 + 32;              // load there exposes an L2 round trip per phase and image)
 constexpr int EN_B4 = EN_B3 + 64;
 constexpr int EN_END = EN_B4 + 64;             // 11776 floats = 47104 B: three workgroups per CU
@@ -31,11 +31,12 @@ __global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs 
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // conv1 weights + bias live in LDS ([tap][32 ch] so a lane's 4 channels of a chunk are one broadcast ds_read_b128)
-    for (int i = tid; i < 320; i += 256) smf[EN_W1 + i] = (i < 288) ? a.w1[i] : a.b1[i - 288];
+    for (int i = tid; i < 320; i += 256) smf[EN_ONE + i] = 1.0f;
+    // conv1 as a [32 ch] x [K = 9 taps + bias] A operand: lane (ch, h) holds column 2 s + h of MFMA step s, for the whole kernel
+    float a1[5];
+#pragma unroll
+    for (int s_ = 0; s_ < 5; ++s_) { const int k = 2 * s_ + (lane >> 5); a1[s_] = k < 9 ? a.w1[k * 32 + (lane & 31)] : a.b1[lane & 31]; }
     if (tid < 160) smf[EN_B2 + tid] = tid < 32 ? a.b2[tid] : tid < 96 ? a.b3[tid - 32] : a.b4[tid - 96];
-    const float4* w1s = reinterpret_cast<const float4*>(smf + EN_W1);
-    const float4* W2 = reinterpret_cast<const float4*>(a.w2) + lane;      // [9][1][4][64]
     const float4* W3 = reinterpret_cast<const float4*>(a.w3);             // [9][2][4][64] (uniform base, see TapPipe)
     const float4* W4 = reinterpret_cast<const float4*>(a.w4);             // [9][4][4][64], packed for the 16x16x4 form
 
@@ -52,67 +53,100 @@ __global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs 
         }
         __syncthreads();
 
-        // ================= conv2 (with conv1 computed on the fly): 225 output pixels = 8 tiles of 32 ==================
+        // ================= conv2 with conv1 on the matrix pipe ==================
+        // 8 tiles of two conv2 rows x 16 columns (15 live): lane (h, r, ox) <-> conv2 pixel (2 T + r, ox).  The B operand of conv2 tap
+        // (kh, kw) is conv1 + ReLU at position (2 oy + kh, 2 ox + kw), all 32 channels: five 32x32x2 MFMAs over K = 9 image taps + the
+        // bias against a constant 1 give it in exactly the register layout the conv2 MFMAs consume (D row 8 g + 4 h + r = B channel of
+        // chunk g), so no conv1 value ever goes through LDS or the VALU (a VALU instruction costs ~19 cycles of wave time next to a
+        // streaming MFMA wave: the 9-FMA-per-value form spent as long there as in the conv2 MFMAs).  Tap kw = 2 of a pixel is tap kw = 0
+        // of its right neighbour: one DPP row shift per register instead of five MFMAs.
         {
-            int ibase[2]; bool pv[2]; int m[2];
+            const int rr = j >> 4, ox = j & 15;
+            bool pv[2]; int m[2];
+            const float* pa[2][5];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                m[nt] = 32 * (w + 4 * nt) + j;
-                pv[nt] = m[nt] < 225;
-                const int mm = pv[nt] ? m[nt] : 0;
-                const int oy = mm / 15, ox = mm - oy * 15;
-                ibase[nt] = (4 * oy) * 64 + 4 * ox;            // image offset of conv1 position (2oy, 2ox)
+                const int oy = 2 * (w + 4 * nt) + rr;
+                pv[nt] = ox < 15 && oy < 15;
+                const int oyc = oy < 15 ? oy : 14;                        // the half tile below the image recomputes row 14 (discarded)
+                m[nt] = oyc * 15 + ox;
+#pragma unroll
+                for (int s_ = 0; s_ < 5; ++s_) {
+                    const int k = 2 * s_ + h;                             // this lane's conv1 tap of MFMA step s_ (k = 9: the bias row)
+                    pa[nt][s_] = (k < 9) ? smf + EN_IMG + (4 * oyc + k / 3) * 64 + 4 * ox + k % 3 : smf + EN_ONE;
+                }
             }
-            f32x16 acc[2];
+            f32x16 acc[2], bA[2], bB[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
-            // B fragment generator: conv1 + ReLU of channels 8*kc + 4*h .. +3 at this lane's conv1 position of tap t
-            auto load_patch = [&](int t, float (&patch)[2][9]) {
-                const int kh = t / 3, kw = t - kh * 3;
+            float pb[2][5];
+            auto patch = [&](int kh, int kw) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const float* ip = smf + EN_IMG + ibase[nt] + (2 * kh) * 64 + 2 * kw;   // conv1 position (2oy+kh, 2ox+kw)
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int aa = 0; aa < 3; ++aa)
+                    for (int s_ = 0; s_ < 5; ++s_) pb[nt][s_] = pa[nt][s_][(2 * kh) * 64 + 2 * kw];
+            };
+            auto conv1 = [&](f32x16 (&bx)[2]) {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                bx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], pb[0][0], z, 0, 0, 0);
+                bx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], pb[1][0], z, 0, 0, 0);
 #pragma unroll
-                        for (int bb = 0; bb < 3; ++bb) patch[nt][aa * 3 + bb] = ip[aa * 64 + bb];
+                for (int s_ = 1; s_ < 5; ++s_) {
+                    bx[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s_], pb[0][s_], bx[0], 0, 0, 0);
+                    bx[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s_], pb[1][s_], bx[1], 0, 0, 0);
                 }
             };
-            // (packed v_pk_fma_f32 for the two channel pairs was measured: 6 % slower than scalar FMAs here)
-            auto gen_b = [&](const float (&patch)[2][9], int kc, int hq, float4 (&bv)[2]) {
+            auto relu = [&](f32x16 (&bx)[2]) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    float4 x = w1s[72 + kc * 2 + hq];                         // bias
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int ab = 0; ab < 9; ++ab) {
-                        const float4 ww = w1s[ab * 8 + kc * 2 + hq];
-                        const float p_ = patch[nt][ab];
-                        x.x = fmaf(p_, ww.x, x.x); x.y = fmaf(p_, ww.y, x.y); x.z = fmaf(p_, ww.z, x.z); x.w = fmaf(p_, ww.w, x.w);
+                    for (int e = 0; e < 16; ++e) bx[nt][e] = relu_bits(bx[nt][e]);
+            };
+            auto shl = [&](f32x16 (&bx)[2], int kc) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int e = 4 * kc; e < 4 * kc + 4; ++e) bx[nt][e] = dpp_shl1_zero(bx[nt][e]);
+            };
+            const unsigned ln2 = (unsigned)lane * 16u;
+            const __amdgpu_buffer_rsrc_t wr2 = wrsrc(a.w2);              // [9 taps][4 chunks][64 lanes] float4
+            float4 an = wfrag(wr2, ln2, 0);
+            // conv2 tap `tap` over the 32 conv1 channels in bx; `nxt` = the tap whose first weight fragment is requested at the end
+            auto conv2 = [&](int tap, int nxt, f32x16 (&bx)[2], auto&& during) {
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const float4 av = an;
+                    an = wfrag(wr2, ln2, (size_t)(kc < 3 ? tap * 4 + kc + 1 : nxt * 4) * 64);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const float4 b4 = make_float4(bx[nt][4 * kc], bx[nt][4 * kc + 1], bx[nt][4 * kc + 2], bx[nt][4 * kc + 3]);
+                        MFMA4(acc[nt], av, b4)
                     }
-                    bv[nt] = make_float4(fmaxf(x.x, 0.f), fmaxf(x.y, 0.f), fmaxf(x.z, 0.f), fmaxf(x.w, 0.f));
+                    during(kc);
                 }
             };
-            // software pipeline over the 36 (tap, chunk) steps: while the 8 MFMAs of step i issue, the VALU produces the B
-            // fragments of step i+1 and the A fragment of step i+1 is in flight
-            float patch[2][9];
-            float4 bcur[2], bnxt[2];
-            float4 av = W2[0];
-            load_patch(0, patch);
-            {
-                int hq = h; asm volatile("" : "+v"(hq));
-                gen_b(patch, 0, hq, bcur);
-            }
-#pragma unroll 1
-            for (int i = 0; i < 36; ++i) {
-                const int ni = (i + 1 < 36) ? i + 1 : 35;
-                const float4 an = W2[(size_t)ni * 64];
-                int hq = h; asm volatile("" : "+v"(hq));        // laundered per step: stops hipcc hoisting the weight reads into 160 registers
-                if ((ni & 3) == 0) load_patch(ni >> 2, patch);
-                gen_b(patch, ni & 3, hq, bnxt);
-                MFMA4(acc[0], av, bcur[0]) MFMA4(acc[1], av, bcur[1])
-                av = an; bcur[0] = bnxt[0]; bcur[1] = bnxt[1];
+            patch(0, 0); conv1(bA); relu(bA); patch(0, 1);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                // tap (kh, 0) from bA; under it conv1 of (kh, 1) -> bB
+                conv2(kh * 3 + 0, kh * 3 + 2, bA, [&](int kc) {
+                    if (kc == 0) conv1(bB);
+                    if (kc == 2) relu(bB);
+                    if (kc == 3) shl(bA, 0);
+                });
+                // tap (kh, 2): bA shifted one pixel to the left, a chunk ahead of its use
+                conv2(kh * 3 + 2, kh * 3 + 1, bA, [&](int kc) { if (kc < 3) shl(bA, kc + 1); else if (kh < 2) patch(kh + 1, 0); });
+                // tap (kh, 1) from bB; under it conv1 of (kh + 1, 0) -> bA
+                conv2(kh * 3 + 1, kh < 2 ? kh * 3 + 3 : 8, bB, [&](int kc) {
+                    if (kh < 2) {
+                        if (kc == 0) conv1(bA);
+                        if (kc == 2) relu(bA);
+                        if (kc == 3) patch(kh + 1, 1);
+                    }
+                });
             }
             // bias + ReLU -> conv2 image in LDS
 #pragma unroll
