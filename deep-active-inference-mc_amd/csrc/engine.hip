@@ -59,6 +59,9 @@ struct efe_ctx {
     float* g_wf = nullptr; float g_bf[4] = {0.f, 0.f, 0.f, 0.f};
     float* g_enc1p = nullptr;       // first encoder conv for k_conv_e: [9 taps][64 lanes][2] = W[co][h][tap], W[co][2 + h][tap]
     int64_t mac_dec = 43256320, mac_enc = 3868960, mac_trans = 541696, mac_habit = 18176;
+    MlpW dec16{}, enc16{};         // decoder / encoder dense heads packed the same way (k_head)
+    int enc16_kc0 = 0;
+    int64_t head_unfused = 0;      // option: 1 = layer-by-layer k_dense heads (A/B experiments)
     MlpW mid16{}, top16{};         // the same transition / habit weights packed for the fused 16x16x4 kernels (fused.hip)
     int64_t mid_unfused = 0;       // option: 1 = layer-by-layer k_dense transition (A/B experiments)
     float *enc_w1 = nullptr, *enc_b1 = nullptr, *dec_wf = nullptr;
@@ -182,7 +185,7 @@ int pack_linear(efe_ctx* ctx, Layer& L, const std::string& key, int out, int in,
 }
 
 // packed for v_mfma_f32_16x16x4_f32 (fused.hip): [16-feature tile][16-channel chunk][lane = (m, q)][s] = W[16 mt + m][16 kc + 4 q + s]
-int pack_linear16(efe_ctx* ctx, const float4*& Wout, const float*& bout, const std::string& key, int out, int in) {
+int pack_linear16(efe_ctx* ctx, const float4*& Wout, const float*& bout, const std::string& key, int out, int in, const int* col_perm = nullptr) {
     const HostTensor* w = need(ctx, key + ".weight", {out, in});
     const HostTensor* b = need(ctx, key + ".bias", {out});
     if (!w || !b) return 1;
@@ -193,7 +196,7 @@ int pack_linear16(efe_ctx* ctx, const float4*& Wout, const float*& bout, const s
             for (int lane = 0; lane < 64; ++lane)
                 for (int s_ = 0; s_ < 4; ++s_) {
                     const int co = 16 * mt + (lane & 15), ci = 16 * kc + 4 * (lane >> 4) + s_;
-                    if (co < out && ci < in) p[(((size_t)mt * KC + kc) * 64 + lane) * 4 + s_] = w->data[(size_t)co * in + ci];
+                    if (co < out && ci < in) p[(((size_t)mt * KC + kc) * 64 + lane) * 4 + s_] = w->data[(size_t)co * in + (col_perm ? col_perm[ci] : ci)];
                 }
     for (int co = 0; co < out; ++co) bb[co] = b->data[co];
     float *dW = nullptr, *dB = nullptr;
@@ -235,6 +238,18 @@ void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float*
         if (tiles22 < 2048) { NT = 1; if (tiles22 * 2 < 2048) MT = 1; }
         if (launch_dense(MT, NT, a, st)) ctx->pending = "launch_dense: unsupported tile shape";
     }
+    ctx->prof_end(e0, st);
+}
+
+// decoder head (enc = false: X [M][16] -> Y [M][256]) or encoder head (X [M][16 * kc0] -> Y [M][32]) as one launch (fused.hip k_head)
+void head(efe_ctx* ctx, bool enc, const float* X, float* Y, int M, const NoiseCfg& nc, int m0, hipStream_t st) {
+    HeadArgs a{};
+    a.W = enc ? ctx->enc16 : ctx->dec16; a.kc0 = enc ? ctx->enc16_kc0 : 1; a.nl = enc ? 4 : 3; a.out_tiles = 2;
+    a.tag0 = enc ? TAG_ENC : TAG_DEC; a.X = X; a.Y = Y; a.M = M; a.k0 = nc.k0; a.k1 = nc.k1; a.gm = nc.gm;
+    a.gm.ctr = ctx->stage_ctr; a.gm.ctr_mul = ctx->stage_mul;
+    a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = m0;
+    hipEvent_t e0 = ctx->prof_begin(st);
+    launch_head(a, st);
     ctx->prof_end(e0, st);
 }
 
@@ -289,9 +304,12 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
     float* y3 = fused ? nullptr : ctx->allocT<float>((size_t)C * H3 * H3 * 32);
     if (!hA || !hB || !x4 || !y1 || !y2 || (!fused && !y3)) return 1;
     ctx->cls = PROF_DEC_FC;
-    fc(ctx, ctx->dec_fc[0], dec_in, 16, 0, hA, 256, N, true, true, TAG_DEC + 0, nc, 0, st);
-    fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, N, true, true, TAG_DEC + 1, nc, 0, st);
-    fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, N, true, true, TAG_DEC + 2, nc, 0, st);
+    if (!ctx->head_unfused) head(ctx, false, dec_in, hA, N, nc, 0, st);
+    else {
+        fc(ctx, ctx->dec_fc[0], dec_in, 16, 0, hA, 256, N, true, true, TAG_DEC + 0, nc, 0, st);
+        fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, N, true, true, TAG_DEC + 1, nc, 0, st);
+        fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, N, true, true, TAG_DEC + 2, nc, 0, st);
+    }
     int cur_m0 = 0;
     auto conv = [&](const Layer& L, const float* in, float* out, int n, int hin, int cin, int hout, int cout, int mode) {
         ConvGArgs a{};
@@ -387,10 +405,13 @@ int run_encoder_g(efe_ctx* ctx, const float* o8, int N, const NoiseCfg& nc, floa
         if (conv_e(2, c1, c2, ctx->g_enc[1].Wp, ctx->g_enc[1].bias, hw[1], hw[2])) conv(ctx->g_enc[1], c1, c2, c, hw[1], 32, hw[2], 32);
         conv(ctx->g_enc[2], c2, c3, c, hw[2], 32, hw[3], 64);
         conv(ctx->g_enc[3], c3, c4, c, hw[3], 64, hw[4], 64);
-        fc(ctx, ctx->enc_fc[0], c4, flat, 0, hA, 256, c, true, true, TAG_ENC + 0, nc, m0, st);
-        fc(ctx, ctx->enc_fc[1], hA, 256, 0, hB, 256, c, true, true, TAG_ENC + 1, nc, m0, st);
-        fc(ctx, ctx->enc_fc[2], hB, 256, 0, hA, 256, c, true, true, TAG_ENC + 2, nc, m0, st);
-        fc(ctx, ctx->enc_fc[3], hA, 256, 0, enc + (size_t)m0 * 32, 32, c, false, false, 0, nc, m0, st);
+        if (!ctx->head_unfused) head(ctx, true, c4, enc + (size_t)m0 * 32, c, nc, m0, st);
+        else {
+            fc(ctx, ctx->enc_fc[0], c4, flat, 0, hA, 256, c, true, true, TAG_ENC + 0, nc, m0, st);
+            fc(ctx, ctx->enc_fc[1], hA, 256, 0, hB, 256, c, true, true, TAG_ENC + 1, nc, m0, st);
+            fc(ctx, ctx->enc_fc[2], hB, 256, 0, hA, 256, c, true, true, TAG_ENC + 2, nc, m0, st);
+            fc(ctx, ctx->enc_fc[3], hA, 256, 0, enc + (size_t)m0 * 32, 32, c, false, false, 0, nc, m0, st);
+        }
     }
     ctx->cls = PROF_OTHER;
     ctx->last_macs += (int64_t)N * ctx->mac_enc;
@@ -410,9 +431,12 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
     float* y2 = ctx->allocT<float>((size_t)C * 65536);
     if (!hA || !hB || !x4 || !y2) return 1;
     ctx->cls = PROF_DEC_FC;
-    fc(ctx, ctx->dec_fc[0], dec_in, 16, 0, hA, 256, N, true, true, TAG_DEC + 0, nc, 0, st);
-    fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, N, true, true, TAG_DEC + 1, nc, 0, st);
-    fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, N, true, true, TAG_DEC + 2, nc, 0, st);
+    if (!ctx->head_unfused) head(ctx, false, dec_in, hA, N, nc, 0, st);
+    else {
+        fc(ctx, ctx->dec_fc[0], dec_in, 16, 0, hA, 256, N, true, true, TAG_DEC + 0, nc, 0, st);
+        fc(ctx, ctx->dec_fc[1], hA, 256, 0, hB, 256, N, true, true, TAG_DEC + 1, nc, 0, st);
+        fc(ctx, ctx->dec_fc[2], hB, 256, 0, hA, 256, N, true, true, TAG_DEC + 2, nc, 0, st);
+    }
     const int nchunks = (N + C - 1) / C;
     int* queues = ctx->allocT<int>((size_t)nchunks);        // one image-ticket counter per k_dec_a launch
     if (!queues) return 1;
@@ -460,10 +484,13 @@ int run_encoder(efe_ctx* ctx, const float* o, int N, const NoiseCfg& nc, float* 
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_enc_trunk(ea, st);
         ctx->prof_end(e0, st);
-        fc(ctx, ctx->enc_fc[0], c4, 576, 0, hA, 256, c, true, true, TAG_ENC + 0, nc, m0, st);
-        fc(ctx, ctx->enc_fc[1], hA, 256, 0, hB, 256, c, true, true, TAG_ENC + 1, nc, m0, st);
-        fc(ctx, ctx->enc_fc[2], hB, 256, 0, hA, 256, c, true, true, TAG_ENC + 2, nc, m0, st);
-        fc(ctx, ctx->enc_fc[3], hA, 256, 0, enc + (size_t)m0 * 32, 32, c, false, false, 0, nc, m0, st);
+        if (!ctx->head_unfused) head(ctx, true, c4, enc + (size_t)m0 * 32, c, nc, m0, st);
+        else {
+            fc(ctx, ctx->enc_fc[0], c4, 576, 0, hA, 256, c, true, true, TAG_ENC + 0, nc, m0, st);
+            fc(ctx, ctx->enc_fc[1], hA, 256, 0, hB, 256, c, true, true, TAG_ENC + 1, nc, m0, st);
+            fc(ctx, ctx->enc_fc[2], hB, 256, 0, hA, 256, c, true, true, TAG_ENC + 2, nc, m0, st);
+            fc(ctx, ctx->enc_fc[3], hA, 256, 0, enc + (size_t)m0 * 32, 32, c, false, false, 0, nc, m0, st);
+        }
     }
     ctx->cls = PROF_OTHER;
     ctx->last_macs += (int64_t)N * ctx->mac_enc;
@@ -709,6 +736,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "trace")) { ctx->trace = value; return 0; }
     if (!strcmp(name, "arena_align")) { if (value < 256 || (value & (value - 1))) return ctx->fail("arena_align must be a power of two >= 256"); ctx->arena_align = value; return 0; }
     if (!strcmp(name, "mid_unfused")) { ctx->mid_unfused = value; return 0; }
+    if (!strcmp(name, "head_unfused")) { ctx->head_unfused = value; return 0; }
     if (!strcmp(name, "enc_chunk")) { if (value < 1) return ctx->fail("enc_chunk < 1"); ctx->enc_chunk = value; return 0; }
     return ctx->fail(std::string("unknown option ") + name);
 }
@@ -749,6 +777,14 @@ int efe_commit_weights(efe_ctx* ctx) {
     if (pack_linear(ctx, ctx->dec_fc[0], "down.po_net.0", 256, 10, nullptr, nullptr)) return 1;
     if (pack_linear(ctx, ctx->dec_fc[1], "down.po_net.3", 256, 256, nullptr, nullptr)) return 1;
     if (pack_linear(ctx, ctx->dec_fc[2], "down.po_net.6", 256, 256, nullptr, nullptr)) return 1;
+    {   // the heads packed for k_head (the encoder's first layer follows with the geometry below)
+        const char* dk[3] = {"down.po_net.0", "down.po_net.3", "down.po_net.6"};
+        const int di[3] = {10, 256, 256};
+        for (int i = 0; i < 3; ++i) if (pack_linear16(ctx, ctx->dec16.w[i], ctx->dec16.b[i], dk[i], 256, di[i])) return 1;
+        const char* ek[3] = {"down.qs_net.12", "down.qs_net.15", "down.qs_net.18"};
+        const int eo[3] = {256, 256, 20};
+        for (int i = 0; i < 3; ++i) if (pack_linear16(ctx, ctx->enc16.w[i + 1], ctx->enc16.b[i + 1], ek[i], eo[i], 256)) return 1;
+    }
     const char* tk[3] = {"down.po_net.13", "down.po_net.15", "down.po_net.17"};
     const int tci[3] = {64, 64, 64}, tco[3] = {64, 64, 32};
     if (ctx->generic) {
@@ -781,6 +817,8 @@ int efe_commit_weights(efe_ctx* ctx) {
             std::vector<int> colp((size_t)F * 64);
             for (int p_ = 0; p_ < F; ++p_) for (int c = 0; c < 64; ++c) colp[(size_t)p_ * 64 + c] = c * F + p_;
             if (pack_linear(ctx, ctx->enc_fc[0], "down.qs_net.9", 256, F * 64, nullptr, colp.data())) return 1;
+            if (pack_linear16(ctx, ctx->enc16.w[0], ctx->enc16.b[0], "down.qs_net.9", 256, F * 64, colp.data())) return 1;
+            ctx->enc16_kc0 = F * 4;
         }
         {   // Unflatten(1,(64,B,B)) is channel-major c*B*B + p; emitted NHWC p*64 + c
             std::vector<int> rowp((size_t)B * B * 64);
@@ -841,6 +879,8 @@ int efe_commit_weights(efe_ctx* ctx) {
         std::vector<int> colp(576);
         for (int p = 0; p < 9; ++p) for (int c = 0; c < 64; ++c) colp[p * 64 + c] = c * 9 + p;
         if (pack_linear(ctx, ctx->enc_fc[0], "down.qs_net.9", 256, 576, nullptr, colp.data())) return 1;
+        if (pack_linear16(ctx, ctx->enc16.w[0], ctx->enc16.b[0], "down.qs_net.9", 256, 576, colp.data())) return 1;
+        ctx->enc16_kc0 = 36;
     }
     {   // Unflatten(1,(64,16,16)) is channel-major c*256 + p (torchmodel.py:119); we emit NHWC p*64 + c directly
         std::vector<int> rowp(16384);

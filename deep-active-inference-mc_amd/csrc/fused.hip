@@ -277,7 +277,145 @@ void launch_sim_chain(const SimChainArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(k_sim_chain, dim3((a.E + FR - 1) / FR), dim3(256), lds, st, a);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_head<FR>: the three 256-wide hidden layers of the decoder / encoder head (+ the encoder's 256 -> 20 output layer) for FR batch
+// rows per workgroup.  Same scheme as above with 256-float activation rows (64 quads) and NB = FR / 16 batch tiles per weight
+// fragment: a 16-row workgroup streams 8 flop per weight byte out of L2 (the bound of k_trans_fused), 32 rows halve that traffic,
+// so large launches use FR = 32.  The first layer's B operand comes straight from the global input rows (K up to 64 * F floats).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ int aswz64(int n, int c4) { return n * 64 + ((c4 & ~15) | ((c4 ^ n) & 15)); }
+
+template <int NMT, int NB, bool GLB>
+__device__ __forceinline__ void gemm16h(f32x4 (&acc)[NMT][NB], const float4* __restrict__ Wp, int mt0, int KC, const float4* act,
+                                        const float4* const (&xr)[NB], int n, int q, unsigned ln) {
+    const __amdgpu_buffer_rsrc_t wr = rsrc16(Wp);
+    float4 a0[NMT], a1[NMT], a2[NMT], b0[NB], b1[NB], b2[NB];
+    auto lda = [&](float4 (&A)[NMT], int k) {
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) A[mt] = wfrag16(wr, ln, (unsigned)((mt0 + mt) * KC + k) * 64u);
+    };
+    auto ldb = [&](float4 (&B)[NB], int k) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) B[nb] = GLB ? xr[nb][4 * k] : act[aswz64(16 * nb + n, 4 * k + q)];
+    };
+    // fragments two chunks ahead through three statically indexed buffers (see gemm16); consecutive MFMAs on different accumulators
+#define H16_STEP(AU, AL, BU, BL, K)                                                                                          \
+    {                                                                                                                        \
+        const int kn_ = (K) + 2 < KC ? (K) + 2 : KC - 1;                                                                     \
+        lda(AL, kn_); ldb(BL, kn_);                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                  \
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(AU[mt].x, BU[nb].x, acc[mt][nb], 0, 0, 0);                    \
+        _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                  \
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(AU[mt].y, BU[nb].y, acc[mt][nb], 0, 0, 0);                    \
+        _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                  \
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(AU[mt].z, BU[nb].z, acc[mt][nb], 0, 0, 0);                    \
+        _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt) _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                  \
+            acc[mt][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(AU[mt].w, BU[nb].w, acc[mt][nb], 0, 0, 0);                    \
+    }
+    lda(a0, 0); ldb(b0, 0);
+    lda(a1, KC > 1 ? 1 : 0); ldb(b1, KC > 1 ? 1 : 0);
+    int kc = 0;
+    for (; kc + 3 <= KC; kc += 3) {
+        H16_STEP(a0, a2, b0, b2, kc)
+        H16_STEP(a1, a0, b1, b0, kc + 1)
+        H16_STEP(a2, a1, b2, b1, kc + 2)
+    }
+    if (kc < KC) H16_STEP(a0, a2, b0, b2, kc)
+    if (kc + 1 < KC) H16_STEP(a1, a0, b1, b0, kc + 1)
+#undef H16_STEP
+}
+
+// one layer of one wave: features 16 * mt0 .. + 16 * NMT of the NB batch tiles; bias (+ ReLU + MC-dropout) -> LDS
+template <int NMT, int NB, bool GLB, bool HIDDEN>
+__device__ __forceinline__ void head_layer(const float4* __restrict__ Wp, const float* __restrict__ bias, int mt0, int KC, const float4* act_in,
+                                           const float4* const (&xr)[NB], float4* act_out, int n, int q, unsigned ln, uint32_t k0, uint32_t k1,
+                                           uint32_t tag, const RowKey (&rk)[NB]) {
+    f32x4 acc[NMT][NB];
+    float4 bq[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+        bq[mt] = *reinterpret_cast<const float4*>(bias + 16 * (mt0 + mt) + 4 * q);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[mt][nb] = (f32x4)(0.f);
+    }
+    gemm16h<NMT, NB, GLB>(acc, Wp, mt0, KC, act_in, xr, n, q, ln);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        uint4 rnd = make_uint4(0u, 0u, 0u, 0u);
+        if (HIDDEN) rnd = noise_words(k0, k1, tag, (uint32_t)((16 * mt0) >> 7), rk[nb].row, rk[nb].stream, rk[nb].stage);
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+            const int f = 16 * (mt0 + mt) + 4 * q;
+            float v[4] = {acc[mt][nb][0] + bq[mt].x, acc[mt][nb][1] + bq[mt].y, acc[mt][nb][2] + bq[mt].z, acc[mt][nb][3] + bq[mt].w};
+            if (HIDDEN) {
+                const int wsel = (f >> 5) & 3;
+                const uint32_t word = wsel == 0 ? rnd.x : wsel == 1 ? rnd.y : wsel == 2 ? rnd.z : rnd.w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ((word >> ((f + e) & 31)) & 1u) ? fmaxf(v[e], 0.0f) * 2.0f : 0.0f;
+            }
+            act_out[aswz64(16 * nb + n, 4 * (mt0 + mt) + q)] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+}  // namespace
+
+template <int FR>
+__global__ void __launch_bounds__(256, 2) k_head(const HeadArgs a) {
+    constexpr int NB = FR / 16;
+    extern __shared__ __attribute__((aligned(16))) float4 sm[];
+    float4* bufA = sm;
+    float4* bufB = sm + FR * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const unsigned ln = (unsigned)lane * 16u;
+    const int row0 = blockIdx.x * FR;
+    RowKey rk[NB];
+    const float4* xr[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int m = min(row0 + 16 * nb + n, a.M - 1);               // rows past the end recompute the last row (never stored)
+        const int mg = a.m0 + m;
+        const int g = mg / a.rows_per_group;
+        rk[nb].row = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
+        const uint2 key = group_key(a.gm, g);
+        rk[nb].stream = key.x; rk[nb].stage = key.y;
+        xr[nb] = reinterpret_cast<const float4*>(a.X) + (size_t)m * (4 * a.kc0) + q;
+    }
+    head_layer<4, NB, true, true>(a.W.w[0], a.W.b[0], 4 * w, a.kc0, nullptr, xr, bufA, n, q, ln, a.k0, a.k1, a.tag0 + 0, rk);
+    __syncthreads();
+    head_layer<4, NB, false, true>(a.W.w[1], a.W.b[1], 4 * w, 16, bufA, xr, bufB, n, q, ln, a.k0, a.k1, a.tag0 + 1, rk);
+    __syncthreads();
+    head_layer<4, NB, false, true>(a.W.w[2], a.W.b[2], 4 * w, 16, bufB, xr, bufA, n, q, ln, a.k0, a.k1, a.tag0 + 2, rk);
+    __syncthreads();
+    if (a.nl == 4) {
+        if (w < a.out_tiles) head_layer<1, NB, false, false>(a.W.w[3], a.W.b[3], w, 16, bufA, xr, bufB, n, q, ln, 0u, 0u, 0u, rk);
+        __syncthreads();
+        const int oq = 4 * a.out_tiles;                                 // output quads per row
+        for (int i = tid; i < FR * oq; i += 256) {
+            const int r = i / oq, c4 = i - r * oq;
+            if (row0 + r < a.M) reinterpret_cast<float4*>(a.Y)[(size_t)(row0 + r) * oq + c4] = bufB[aswz64(r, c4)];
+        }
+    } else {
+        for (int i = tid; i < FR * 64; i += 256) {
+            const int r = i >> 6, c4 = i & 63;
+            if (row0 + r < a.M) reinterpret_cast<float4*>(a.Y)[(size_t)(row0 + r) * 64 + c4] = bufA[aswz64(r, c4)];
+        }
+    }
+}
+
+void launch_head(const HeadArgs& a, hipStream_t st) {
+    if (a.M >= 16384) hipLaunchKernelGGL(k_head<32>, dim3((a.M + 31) / 32), dim3(256), 2 * 32 * 64 * sizeof(float4), st, a);
+    else hipLaunchKernelGGL(k_head<16>, dim3((a.M + 15) / 16), dim3(256), 2 * 16 * 64 * sizeof(float4), st, a);
+}
+
 int init_fused_kernels() {
+    if (hipFuncSetAttribute((const void*)k_head<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32 * 64 * sizeof(float4)) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_head<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * 64 * sizeof(float4)) != hipSuccess) return 1;
     const size_t lds = 2 * ACT_F4 * sizeof(float4) + (FR * 16 + FR * 8) * sizeof(float);
     if (hipFuncSetAttribute((const void*)k_trans_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ACT_F4 * sizeof(float4)) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_sim_chain, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;

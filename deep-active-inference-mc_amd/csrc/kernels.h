@@ -185,6 +185,22 @@ void launch_counter_add(int32_t* counter, int delta, hipStream_t st);
 // ---- fused small-MLP kernels (fused.hip) ---------------------------------------------------------------------
 // weights packed for v_mfma_f32_16x16x4_f32: [16-feature tile][16-channel chunk][64 lanes][4], biases padded to the tile count
 struct MlpW { const float4* w[4]; const float* b[4]; };
+// the dense heads next to the conv stacks, one launch each (fused.hip k_head):
+//   decoder head po_net.0/.3/.6 (torchmodel.py:107-115): s[16] -> 256 -> 256 -> 256, ReLU + MC-dropout each          -> Y [M][256]
+//   encoder head qs_net.9/.12/.15/.18 (torchmodel.py:94-103): flat -> 256 -> 256 -> 256 (same) -> 20 (linear)       -> Y [M][32]
+struct HeadArgs {
+    MlpW W;                // packed for the 16x16x4 form (pack_linear16)
+    int kc0;               // 16-channel chunks of the first layer's input: X rows are 16 * kc0 floats
+    int nl;                // 3: Y = the third hidden layer [M][256];  4: + a linear layer of out_tiles 16-feature tiles, Y [M][16 * out_tiles]
+    int out_tiles;
+    uint32_t tag0;         // noise tag of the first layer (layer i uses tag0 + i)
+    const float* X; float* Y;
+    int M;
+    uint32_t k0, k1;
+    GroupMap gm; int rows_per_group; uint32_t row_offset; int m0;
+};
+void launch_head(const HeadArgs& a, hipStream_t st);
+
 struct TransFusedArgs {
     MlpW W;                // ps_net.0 / .3 / .6 / .9
     const float* X;        // [rows][16] = [pi | s0 | 0 0]

@@ -517,6 +517,27 @@ def test_decoder_many_rows_vs_oracle(models, weights_cache):
     assert torch.equal(po, po2)          # the dynamic image schedule does not change any bit
 
 
+@pytest.mark.parametrize('M', [37, 16400])
+def test_fused_dense_heads_equal_layerwise_launches(models, weights_cache, M):
+    """k_head (the decoder's three 256-wide layers / the encoder's four dense layers as one launch, activations in LDS; 16 rows per
+    workgroup, 32 from 16384 rows up) against the same layers as k_dense launches (option head_unfused = 1): the same MC-dropout
+    masks, values equal up to the fp32 summation order of the two contractions.  Ragged tails in both tile sizes."""
+    seed, st = 47, 6
+    m = models(1234, 1.15, seed)
+    s = PX.uniform_fill(12, (M, 10), 905, -1.5, 1.5)
+    po1 = m.model_down.decoder(s, stage=st, pass_=PX.PASS_D2B, sample=2)
+    _, mean1, lv1 = m.model_down.encoder_with_sample(po1, stage=st, pass_=PX.PASS_E1, sample=2)
+    m.set_option('head_unfused', 1)
+    try:
+        po0 = m.model_down.decoder(s, stage=st, pass_=PX.PASS_D2B, sample=2)
+        _, mean0, lv0 = m.model_down.encoder_with_sample(po1, stage=st, pass_=PX.PASS_E1, sample=2)
+    finally:
+        m.set_option('head_unfused', 0)
+    np.testing.assert_allclose(c(po1), c(po0), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c(mean1), c(mean0), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(c(lv1), c(lv0), rtol=1e-5, atol=2e-5)
+
+
 def test_given_trajectory_vs_oracle(models, weights_cache):
     seed, st, T = 51, 4, 5
     w = weights_cache(1234, 1.15)
