@@ -1,10 +1,11 @@
 """GPU parity tests (-m gpu): the HIP engine, called through the C ABI via the Python mirror, against
 (1) the fixtures captured from the shimmed reference and (2) the CPU oracle on fresh seeded inputs.
 
-Tolerances (fp32; observed maxima over the fixtures in profiles/r2_observed_errors.txt, tools/measure_errors.py):
-network outputs rtol 1e-5 / atol 2e-6 (observed 1.9e-6), sigmoid images atol 4e-6 (observed 1.6e-6); term0 / term1 atol 1e-4
-(observed 1.1e-5 / 2.9e-6); term2 and G: atol = 1e-6 * max(|term2_1|, 1) + 5e-4, i.e. 3.3e-3 at |term2_1| = 2.8e3 (observed
-4.9e-4 = 2 ulp of the 4096-pixel sums whose cancelling difference term2 is: the oracle's own fp32 rounding bounds it)."""
+Tolerances (fp32; observed maxima over the fixtures in profiles/r3_observed_errors.txt, tools/measure_errors.py):
+network outputs rtol 1e-5 / atol 2e-6 (observed 2.0e-6), sigmoid images atol 4e-6 (observed 1.8e-6); term0 / term1 atol 1e-4
+(observed 1.1e-5 / 2.4e-6); term2 and G: atol = 1e-6 * max(|term2_1|, 1) + 5e-4, i.e. 3.3e-3 at |term2_1| = 2.8e3 (observed
+7.3e-4 = 3 ulp of the 4096-pixel sums whose cancelling difference term2 is: the oracle's own fp32 rounding bounds it; 4.9e-4 in
+round 2, before the gather's sigmoid / log terms moved to the hardware exp2 / rcp / log2 instructions)."""
 import os
 
 import numpy as np
