@@ -301,11 +301,11 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
         // hardware exp2 / rcp / log2 (v_exp_f32, v_rcp_f32, v_log_f32: 1 ulp each) instead of the libm expansions: ~14 instead of ~60 VALU
         // instructions per pixel, each of which costs ~19 cycles of wave time beside the other wave's MFMA stream; the image stays within
         // 3e-7 of the libm form, the 4096-pixel sums within their own fp32 rounding (tests/test_gpu_parity.py tolerances unchanged)
-        gpr[q] = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        gpr[q] = hw_sigmoid(v);
     };
     auto g_term = [&](int oh, int q) {          // branch-free: both forms are evaluated (the reward form is four FMAs), rows above the image add zero
         const float pr = gpr[q];
-        const float te = -(1.0f - pr) * __logf(D1 - pr) - pr * __logf(D0 + pr);
+        const float te = -(1.0f - pr) * hw_log(D1 - pr) - pr * hw_log(D0 + pr);
         const float tw = reward_term(pr, oh, lane, 64, 64, a.reward_intent);
         const float t = mode == 0 ? te : tw;
         part += oh >= 0 ? t : 0.0f;

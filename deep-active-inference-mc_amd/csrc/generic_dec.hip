@@ -295,7 +295,6 @@ void launch_convt_p(const ConvGArgs& a, hipStream_t st) {
 // accurate forms stay: parity pinned, one output per pixel).  Error: |x| 2^-24 relative on e^-x, i.e. < 5e-7 absolute on the sigmoid
 // for |x| < 30, and < 2 ulp on the logarithms -- inside the fp32 tolerances of tests/test_generic_geometry.py, which compare against
 // the libm-evaluated oracle.
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 template <int C>
 __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
@@ -420,14 +419,14 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     // otherwise sinks the whole computation there -- back into the non-MFMA phase)
     auto g_sig = [&](int it) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) { gv[it][c] = fast_sigmoid(gv[it][c]); asm volatile("" : "+v"(gv[it][c])); }
+        for (int c = 0; c < C; ++c) { gv[it][c] = hw_sigmoid(gv[it][c]); asm volatile("" : "+v"(gv[it][c])); }
     };
     auto g_term = [&](int it) {             // branch-free: both forms are evaluated (the reward form is a few FMAs), discarded threads add zero
         float t = 0.f;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float pr = gv[it][c];
-            const float te = -(1.0f - pr) * __logf(D1 - pr) - pr * __logf(D0 + pr);
+            const float te = -(1.0f - pr) * hw_log(D1 - pr) - pr * hw_log(D0 + pr);
             const float tw = reward_term(pr, goh[it], gox[it], Hout, Wout, a.reward_intent);
             t += mode == 0 ? te : tw;
         }

@@ -47,6 +47,12 @@ __device__ __forceinline__ float relu_bits(float x) {
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
+// sigmoid and natural log on the hardware transcendental instructions alone (v_exp_f32 = 2^x, v_rcp_f32, v_log_f32 = log2 x: 1 ulp each).
+// __expf / __logf add a denormal-range rescue (compare + ldexp + select per call) that these call sites do not need: the log arguments
+// are d + p and (d + 1) - p with p in [0, 1], d = 1e-5; 2^x underflowing to 0 or overflowing to inf gives the sigmoid's limits 1 and 0.
+__device__ __forceinline__ float hw_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+__device__ __forceinline__ float hw_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
 // DPP row shifts of one fp32 register inside 16-lane rows (measured semantics, tools/ubench/dpp_probe.hip): shr1: lane i <- lane i - 1,
 // shl1: lane i <- lane i + 1; lanes without a source are zero (_zero) or keep `old` (_keep); ror1: lane i <- lane (i - 1) & 15, ror15: <- (i + 1) & 15
 __device__ __forceinline__ float dpp_shr1_zero(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xf, 0xf, true)); }

@@ -1,0 +1,45 @@
+"""Register / spill budget of the BUILT library's kernels, read from the AMDGPU code-object metadata inside libefe_mi355x.so
+(tools/isa_report.py; no GPU, no recompilation).  The occupancies the kernels are designed for depend on these
+figures: a kernel that starts spilling to scratch, or grows past the register count of its waves-per-SIMD target, loses its roofline
+fraction without failing any numerical test."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def kernels():
+    spec = importlib.util.spec_from_file_location('isa_report', os.path.join(ROOT, 'tools', 'isa_report.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.DEFAULT_LIB):
+        pytest.skip('engine library not built')
+    ks = mod.kernels()
+    assert len(ks) > 40, sorted(ks)
+    return ks
+
+
+def test_no_kernel_uses_scratch_memory(kernels):
+    """no VGPR spills and no private segment anywhere in the product library (SGPR spills go to VGPR lanes, not to memory)"""
+    bad = {k: v for k, v in kernels.items() if v.get('.vgpr_spill_count', 0) or v.get('.private_segment_fixed_size', 0)}
+    assert not bad, bad
+
+
+# kernel -> registers per lane (VGPR + AGPR) its waves-per-SIMD target allows on gfx950 (512 per SIMD lane, allocated in blocks of 8)
+BUDGET = {
+    'k_dec_b4': 256, 'k_dec_a': 256, 'k_fc4': 256,                              # 2 workgroups x 4 waves per CU
+    'k_dec_bg<1>': 256, 'k_dec_bg<2>': 256, 'k_dec_bg<3>': 256,
+    'k_enc_trunk': 168,                                                         # 3 workgroups per CU
+    'k_convt_p<1, 4>': 168, 'k_convt_p<1, 8>': 168, 'k_convt_p<2, 4>': 168, 'k_convt_p<2, 8>': 168,
+    'k_conv_e<1, 4>': 168, 'k_conv_e<2, 16>': 168,
+    'k_trans_fused': 256, 'k_head<16>': 256, 'k_head<32>': 256,
+}
+
+
+@pytest.mark.parametrize('name', sorted(BUDGET))
+def test_hot_kernel_fits_its_occupancy_target(kernels, name):
+    assert name in kernels, sorted(kernels)
+    assert kernels[name]['.vgpr_count'] <= BUDGET[name], (name, kernels[name])
