@@ -15,14 +15,19 @@
 namespace efe {
 
 constexpr int EN_IMG = 0;                      // [64][64] input image                       (floats)
-constexpr int EN_C2 = 4096;                    // [225 px][32 ch] conv2 output, 8 quads/pixel, quad ^= px & 7
-constexpr int EN_C3 = EN_IMG;                  // [49 px][64 ch] conv3 output, 16 quads/pixel, quad ^= px & 15: aliases the input image
-                                               // (dead once conv2 is done); 3136 <= 4096 floats
-constexpr int EN_ONE = EN_C2 + 225 * 32;       // 320 x 1.0f: the "pixel" the conv1 bias row multiplies (any tap offset stays inside)
+// Activation images in LDS are PADDED, not swizzled: a pixel's channels take P2 = 9 (conv2 output, 8 quads + 1) / P3 = 17 (conv3 output,
+// 16 + 1) float4 slots.  The stride-2 taps of 16 consecutive lanes then fall 2-way on the banks (the XOR swizzle: 4-way, its key only
+// takes even values), the epilogue's stores are conflict-free, and a fragment address is base + constant: the chunk offset is an
+// immediate of the ds_read instead of an XOR + add per chunk (conv3 / conv4 spent more VALU than MFMA instructions on those).
+constexpr int EN_P2 = 9, EN_P3 = 17;
+constexpr int EN_C2 = 4096;                    // [225 px][EN_P2 quads] conv2 output
+constexpr int EN_C3 = EN_IMG;                  // [49 px][EN_P3 quads] conv3 output: aliases the input image (dead once conv2 is done);
+                                               // 49 * 68 = 3332 <= 4096 floats
+constexpr int EN_ONE = EN_C2 + 225 * 4 * EN_P2;       // 320 x 1.0f: the "pixel" the conv1 bias row multiplies (any tap offset stays inside)
 constexpr int EN_B2 = EN_ONE + 320;             // conv2 / conv3 / conv4 biases [32] [64] [64]: read in the epilogues from LDS (a global
 constexpr int EN_B3 = EN_B2 + 32;              // load there exposes an L2 round trip per phase and image)
 constexpr int EN_B4 = EN_B3 + 64;
-constexpr int EN_END = EN_B4 + 64;             // 11776 floats = 47104 B: three workgroups per CU
+constexpr int EN_END = EN_B4 + 64;             // 12676 floats = 50704 B: three workgroups per CU (160 KiB)
 
 __global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
@@ -159,7 +164,7 @@ __global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs 
                     float4 v;
                     v.x = fmaxf(acc[nt][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[nt][4 * g4 + 1] + bb.y, 0.f);
                     v.z = fmaxf(acc[nt][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[nt][4 * g4 + 3] + bb.w, 0.f);
-                    sm4[EN_C2 / 4 + m[nt] * 8 + (c4 ^ (m[nt] & 7))] = v;
+                    sm4[EN_C2 / 4 + m[nt] * EN_P2 + c4] = v;
                 }
             }
         }
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs 
                 const int kh = t / 3, kw = t - kh * 3;
                 wt = t;
                 const int sp = (2 * oy + kh) * 15 + 2 * ox + kw;
-                bs[0] = sp * 8; sw[0] = sp & 7;
+                bs[0] = sp * EN_P2; sw[0] = 0;
             }, PackedWIdx{2, 4, mt});
             if (pv) {
 #pragma unroll
@@ -189,7 +194,7 @@ __global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs 
                     float4 v;
                     v.x = fmaxf(acc[0][0][4 * g4 + 0] + bb.x, 0.f); v.y = fmaxf(acc[0][0][4 * g4 + 1] + bb.y, 0.f);
                     v.z = fmaxf(acc[0][0][4 * g4 + 2] + bb.z, 0.f); v.w = fmaxf(acc[0][0][4 * g4 + 3] + bb.w, 0.f);
-                    sm4[EN_C3 / 4 + m * 16 + (c4 ^ (m & 15))] = v;
+                    sm4[EN_C3 / 4 + m * EN_P3 + c4] = v;
                 }
             }
         }
@@ -209,7 +214,7 @@ __global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs 
             auto bfrag = [&](int i) {
                 const int t = i >> 2, kh = t / 3, kw = t - kh * 3;
                 const int sp = (2 * oy + kh) * 7 + 2 * ox + kw;
-                return sm4[EN_C3 / 4 + sp * 16 + (((i & 3) * 4 + q) ^ (sp & 15))];
+                return sm4[EN_C3 / 4 + sp * EN_P3 + (i & 3) * 4 + q];
             };
             float4 aq[PD];
 #pragma unroll
