@@ -213,7 +213,11 @@ void launch_dec_a(const DecAArgs& a, hipStream_t st) {
 __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     constexpr int SR = 4, NW = 4, NTHR = 256;
     constexpr int DB_ZERO = (SR + 1) * 32;
-    constexpr int DB_IN_F4 = (DB_ZERO + 1) * 16;
+    // float4 slots per input pixel: 16 channel quads + 1 pad.  Padded, not XOR-swizzled: 16 consecutive pixels still cover the 16 bank
+    // quads (17 j mod 16 = j), and a fragment address is (pixel base + h) + a constant chunk offset -- an immediate of the ds_read, where
+    // the swizzle cost the contraction an XOR / OR and an add per chunk (VALU work beside the other wave's MFMA stream)
+    constexpr int DB_PS = 17;
+    constexpr int DB_IN_F4 = (DB_ZERO + 1) * DB_PS;
     constexpr int DB_YROWS = 4 * SR + 2;
     constexpr int NPF = (SR + 1) * 512 / NTHR;        // 10 float4s of the input strip per thread
     constexpr int NS = 32 / SR;
@@ -249,7 +253,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
         sW4[tid] = kw < 3 ? reinterpret_cast<const float4*>(a.w4 + (3 * kh + kw) * 32)[2 * g4 + hh] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float4* w4p = sW4 + (h * 4 + (lane & 3)) * 12;
-    if (tid < 16) sm[DB_ZERO * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 16) sm[DB_ZERO * DB_PS + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const float4* X = reinterpret_cast<const float4*>(a.y2) + (size_t)img * (32 * 32 * 16);
     const float4* W3 = reinterpret_cast<const float4*>(a.w3);
@@ -334,7 +338,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
             const int idx = it * NTHR + tl;
             const int rl = idx >> 9, seg = (idx & 511) >> 5, wi = idx & 31;
             const int ix = 2 * (wi >> 1) + (seg >> 3), c4 = 2 * (seg & 7) + (wi & 1);
-            smv[swz(rl * 32 + ix, c4)] = (SR * s + rl < 32) ? pf[it] : (f32x4)(0.f);
+            smv[(rl * 32 + ix) * DB_PS + c4] = (SR * s + rl < 32) ? pf[it] : (f32x4)(0.f);
         }
         float4 a0 = wf(4, 0), a1 = wf(5, 0), a2 = wf(7, 0), a3 = wf(8, 0);      // the strip's first weight fragments: in flight across the barrier
         __syncthreads();
@@ -350,16 +354,16 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
         // ---- contraction, software-pipelined one chunk ahead: shift A (4 chains), shift B (2), shifts C + D fused (2 + 1, so the
         // single-chain shift never runs alone).  The first weight fragments were requested before the staging barrier.
         {
-            float4 b = sm[spA * 16 + (h ^ (spA & 15))];
+            float4 b = sm[spA * DB_PS + h];
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
                 const float4 c0 = a0, c1 = a1, c2 = a2, c3 = a3, cb = b;
                 if (kc < 7) {
                     a0 = wf(4, kc + 1); a1 = wf(5, kc + 1); a2 = wf(7, kc + 1); a3 = wf(8, kc + 1);
-                    b = sm[spA * 16 + ((2 * (kc + 1) + h) ^ (spA & 15))];
+                    b = sm[spA * DB_PS + 2 * (kc + 1) + h];
                 } else {
                     a0 = wf(3, 0); a1 = wf(6, 0);
-                    b = sm[spB * 16 + (h ^ (spB & 15))];
+                    b = sm[spB * DB_PS + h];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kc == 0) { MFMA4I(acc[0], bias16, c0, cb) MFMA4I(acc[1], bias16, c1, cb) MFMA4I(acc[2], bias16, c2, cb) MFMA4I(acc[3], bias16, c3, cb) }
@@ -376,11 +380,11 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 const float4 c0 = a0, c1 = a1, cb = b;
                 if (kc < 7) {
                     a0 = wf(3, kc + 1); a1 = wf(6, kc + 1);
-                    b = sm[spB * 16 + ((2 * (kc + 1) + h) ^ (spB & 15))];
+                    b = sm[spB * DB_PS + 2 * (kc + 1) + h];
                 } else {
                     a0 = wf(1, 0); a1 = wf(2, 0); a2 = wf(0, 0);
-                    b = sm[spC * 16 + (h ^ (spC & 15))];
-                    bd = sm[spD * 16 + (h ^ (spD & 15))];
+                    b = sm[spC * DB_PS + h];
+                    bd = sm[spD * DB_PS + h];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[1], c0, cb) MFMA4(acc[3], c1, cb)
@@ -391,8 +395,8 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 const float4 c0 = a0, c1 = a1, c2 = a2, cb = b, cd = bd;
                 if (kc < 7) {
                     a0 = wf(1, kc + 1); a1 = wf(2, kc + 1); a2 = wf(0, kc + 1);
-                    b = sm[spC * 16 + ((2 * (kc + 1) + h) ^ (spC & 15))];
-                    bd = sm[spD * 16 + ((2 * (kc + 1) + h) ^ (spD & 15))];
+                    b = sm[spC * DB_PS + 2 * (kc + 1) + h];
+                    bd = sm[spD * DB_PS + 2 * (kc + 1) + h];
                 }
                 if (kc == 6) prefetch((s < NS - 1) ? s + 1 : NS - 1, tl);       // the next strip's input, behind this strip's last weight-fragment request
                 __builtin_amdgcn_sched_barrier(0);
@@ -458,7 +462,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     if (tid == 0) a.val[mg] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
-constexpr size_t DB_LDS4D = ((5 * 32 + 1) * 16) * sizeof(float4) + 18 * 2 * 3 * 64 * sizeof(float);  // input strip + H planes per channel half (4 SR + 2 rows)
+constexpr size_t DB_LDS4D = ((5 * 32 + 1) * 17) * sizeof(float4) + 18 * 2 * 3 * 64 * sizeof(float);  // input strip + H planes per channel half (4 SR + 2 rows)
 int init_dec_b_kernels() {
     if (hipFuncSetAttribute((const void*)k_dec_b4, hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4D) != hipSuccess) return 1;
     return 0;
