@@ -406,20 +406,46 @@ class BatchedMCTS:
             self._call(lib.efe_mcts_backprop, p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(active),
                        p_(self.sims), int(p.simulation_repeats), p_(self.q0), self.max_depth, p_(self.H_g[repeat]), p_(self.H_active[repeat]))
             n_iter += 1
-        # read the history back once, then plain numpy on the host (per-element torch indexing here cost ~30 ms per 64-episode decision)
+        # read the history back once, then plain Python lists on the host: per-element torch indexing here cost ~30 ms per 64-episode
+        # decision, per-element numpy indexing 2.6 ms (during which the GPU has nothing queued); whole-array tolist() + list slicing 1.0 ms
         H_act, H_len = self.H_act[:n_iter].cpu().numpy(), self.H_len[:n_iter].cpu().numpy()
         H_g, H_active = self.H_g[:n_iter].cpu().numpy(), self.H_active[:n_iter].cpu().numpy().astype(bool)
-        stop_at, N, child = self.stop_at.cpu().numpy(), self.N.cpu().numpy(), self.child.cpu().numpy()
+        stop_at, N, child = self.stop_at.cpu().tolist(), self.N.cpu().numpy(), self.child.cpu().numpy()
+        acts, lens, gs = H_act.transpose(1, 0, 2).tolist(), H_len.T.tolist(), H_g.T.tolist()        # [E][iteration]...
+        live = H_active.T
+        all_live = live.all(axis=1).tolist()
+        visited = self._most_visited_paths(N, child)
         for e in range(E):
             if res[e] is not None:
                 continue
-            its = np.nonzero(H_active[:, e])[0]
-            paths = [H_act[i, e, :H_len[i, e]].tolist() for i in its]
-            Gs = [float(g) for g in H_g[its, e]]
-            reps = int(stop_at[e]) if stop_at[e] >= 0 else p.repeats
-            explored = len(its) * p.simulation_depth * p.simulation_repeats
-            res[e] = (self.action_selection(e, N, child), reps, explored, paths, Gs)
+            its = range(n_iter) if all_live[e] else np.flatnonzero(live[e]).tolist()
+            Ae, Le, Ge = acts[e], lens[e], gs[e]
+            paths = [Ae[i][:Le[i]] for i in its]
+            Gs = [Ge[i] for i in its]
+            reps = stop_at[e] if stop_at[e] >= 0 else p.repeats
+            explored = len(paths) * p.simulation_depth * p.simulation_repeats
+            res[e] = (_trim_path(visited[e], self.pi_dim), reps, explored, paths, Gs)
         return res
+
+    @staticmethod
+    def _most_visited_paths(N, child):
+        """Node.action_selection's walk (mcts.py:98-110: argmax of the visit counts, first index on ties, down to the first node without
+        children) for every episode at once: host arrays N [E][cap][A], child [E][cap][A] -> E lists of actions"""
+        E = N.shape[0]
+        ar = np.arange(E)
+        node = np.zeros(E, dtype=np.int64)
+        done = np.zeros(E, dtype=bool)
+        out = [[] for _ in range(E)]
+        for _ in range(child.shape[1]):                       # a path is shorter than the node count
+            if done.all():
+                break
+            a = np.argmax(N[ar, node], axis=1)
+            for e, (ae, d) in enumerate(zip(a.tolist(), done.tolist())):
+                if not d:
+                    out[e].append(ae)
+            node = np.where(done, node, child[ar, node, a])
+            done |= child[ar, node, 0] < 0
+        return out
 
     # ---- the iteration as a replayable launch sequence (SURVEY section 7 step 6) -----------------------------------------------------
     def _body(self, eps_stage=None):
