@@ -5,11 +5,11 @@
 //
 //   conv1 (Cin = 1) is never materialised: the conv1 activations a conv2 tap needs are produced by five MFMAs straight from
 //   the 16 KiB input image in LDS, in the register layout of the conv2 B operand.  conv2, conv3 are MFMA tap contractions
-//   (v_mfma_f32_32x32x2_f32) over swizzled LDS images, conv4 (9 pixels) runs on the 16-column form v_mfma_f32_16x16x4_f32.
+//   (v_mfma_f32_32x32x2_f32) over padded LDS images, conv4 (9 pixels) runs on the 16-column form v_mfma_f32_16x16x4_f32.
 #include "mfma_pipe.h"
 
 #ifndef EFE_ENC_WAVES
-#define EFE_ENC_WAVES 3      // waves per SIMD = workgroups per CU (47 KiB LDS, <= 168 VGPRs)
+#define EFE_ENC_WAVES 3      // waves per SIMD = workgroups per CU (50 KiB LDS, <= 168 VGPRs)
 #endif
 
 namespace efe {
