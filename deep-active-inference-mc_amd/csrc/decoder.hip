@@ -20,13 +20,17 @@ namespace efe {
 // ---------------------------------------------------------------------------------------------------------
 // k_dec_a: ConvTranspose2d(64,64,3,s1,p1)+ReLU then ConvTranspose2d(64,64,3,s2,p1,op1)+ReLU, one image per WG.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int DA_BIAS = 257 * 16;          // float4 index of the two bias vectors behind the image + zero pixel
+// The staged image takes DA_PS = 17 float4 slots per pixel (16 channel quads + 1 pad): 16 consecutive pixels cover the 16 bank quads
+// (17 p mod 16 = p), and a fragment address is pixel base + constant -- the chunk offset is an immediate of the ds_read (the XOR swizzle
+// of rounds 1-2 cost an XOR and an add per chunk and 11 % of the LDS cycles in bank conflicts).
+constexpr int DA_PS = 17;
+constexpr int DA_BIAS = 257 * DA_PS;       // float4 index of the two bias vectors behind the image + zero pixel
 // Four waves of 64 features x 64 pixels each (NTW = 2 32-pixel tiles per wave; 256 VGPRs, 2 waves per SIMD).
 __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
     constexpr int NTW = 2;
     constexpr int NTHR = 512 / NTW;
     constexpr int NPH = 2048 / NTHR;                  // float4s per thread of each image half
-    extern __shared__ __attribute__((aligned(16))) float4 sm[];        // [257 pixels][16 quads]; pixel 256 = zeros
+    extern __shared__ __attribute__((aligned(16))) float4 sm[];        // [257 pixels][DA_PS slots]; pixel 256 = zeros
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -52,7 +56,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
 #pragma unroll
         for (int it = 0; it < NPH; ++it) pfb[it] = X[(it + NPH) * NTHR + tid];
     }
-    if (tid < 16) sm[256 * 16 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 16) sm[256 * DA_PS + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     // biases live in LDS: a global bias load inside an epilogue forces s_waitcnt vmcnt(0), i.e. waits for every store
     // issued before it (vmcnt retires in order) and serialises the whole store stream
     if (tid < 16) sm[DA_BIAS + tid] = reinterpret_cast<const float4*>(a.b1)[tid];
@@ -70,12 +74,12 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
         const int prow0 = 2 * NTW * w + (j >> 4);                      // tile nt covers rows prow0 + 2*nt
         // a dead row of the call (efe_set_row_mask) keeps the schedule -- barriers, ticket, the next image's prefetch -- and skips the work
         const bool live = row_live(a.live, img);
-        if (live) {   // swz(it*(NTHR/16) + (tid>>4), tid&15) = it*NTHR + sbase: one address register, immediate offsets
-            const int sbase = (tl_ >> 4) * 16 + ((tl_ & 15) ^ ((tl_ >> 4) & 15));
+        if (live) {   // pixel it * (NTHR / 16) + (tid >> 4), quad tid & 15: one address register, immediate offsets
+            const int sbase = (tl_ >> 4) * DA_PS + (tl_ & 15);
 #pragma unroll
-            for (int it = 0; it < NPH; ++it) smv[sbase + it * NTHR] = pfa[it];
+            for (int it = 0; it < NPH; ++it) smv[sbase + it * (NTHR / 16) * DA_PS] = pfa[it];
 #pragma unroll
-            for (int it = 0; it < NPH; ++it) smv[sbase + (it + NPH) * NTHR] = pfb[it];
+            for (int it = 0; it < NPH; ++it) smv[sbase + (it + NPH) * (NTHR / 16) * DA_PS] = pfb[it];
         }
         __syncthreads();
         const int nnimg = slot[0];                     // the image after nimg (written one iteration ago)
@@ -114,13 +118,13 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
                 const int sy = prow0 + 2 * nt + 1 - kh, sx = pcol + 1 - kw;
                 const bool ok = sy >= 0 && sy < 16 && sx >= 0 && sx < 16;
                 const int sp = ok ? sy * 16 + sx : 256;
-                bs[nt] = sp * 16; sw[nt] = sp & 15;
+                bs[nt] = sp * DA_PS; sw[nt] = 0;
             }
         }, ConvWIdx{});
         }
         __syncthreads();                // every wave is done reading the input image (and slot[0])
         if (tid == 0) slot[0] = ticket;
-        // bias + ReLU, written back IN PLACE as the input image of layer 2 (same swizzled layout)
+        // bias + ReLU, written back IN PLACE as the input image of layer 2 (same padded layout)
         if (live)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
                     float4 v;
                     v.x = relu_bits(acc[mt][nt][4 * g4 + 0]); v.y = relu_bits(acc[mt][nt][4 * g4 + 1]);
                     v.z = relu_bits(acc[mt][nt][4 * g4 + 2]); v.w = relu_bits(acc[mt][nt][4 * g4 + 3]);
-                    sm[swz(pix, c4)] = v;
+                    sm[pix * DA_PS + c4] = v;
                 }
         }
         __syncthreads();
@@ -144,7 +148,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
         for (int par = 0; par < (live ? 4 : 0); ++par) {
             const int ph = par >> 1, pw = par & 1;
             acc_init(16);
-            tap_loop_pd<2, NTW, 1>(acc, (1 + ph) * (1 + pw), W2, sm, h, ConvT2Addr<NTW>{ph, pw, prow0, 2, pcol, 16, 16, 256}, ConvWIdx{});
+            tap_loop_pd<2, NTW, 1>(acc, (1 + ph) * (1 + pw), W2, sm, h, ConvT2Addr<NTW, DA_PS>{ph, pw, prow0, 2, pcol, 16, 16, 256}, ConvWIdx{});
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 // y2 layout (float4 units): [parity][8 channel groups][256 input positions][2 quads] -- for one (mt, g4) the 64
@@ -167,7 +171,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
     }
 }
 
-constexpr size_t DA_LDS_BYTES = (257 * 16 + 33) * sizeof(float4);
+constexpr size_t DA_LDS_BYTES = (257 * DA_PS + 33) * sizeof(float4);
 int init_dec_b_kernels();
 // kernels that need more than the default 64 KiB of dynamic LDS: set once per device (called from efe_create)
 int init_decoder_kernels() {

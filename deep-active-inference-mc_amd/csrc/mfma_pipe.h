@@ -84,7 +84,8 @@ struct DenseWIdx {         // packed dense weights [feature tile][32 chunks][64 
 
 // tap -> LDS source of the stride-2 transposed convs (oh = 2*ih - 1 + kh: even output rows use kh=1 (ih=a); odd rows use
 // kh=0 (ih=a+1) and kh=2 (ih=a)); `rows`/`cols` bound the staged image, `zero` is the zero-pixel slot.
-template <int NT>
+// PS = float4 slots per staged pixel: 16 = XOR-swizzled quads (swz), 17 = padded slots (no swizzle key)
+template <int NT, int PS = 16>
 struct ConvT2Addr {
     int ph, pw, row0, row_step, col, rows, cols, zero;
     __device__ __forceinline__ void operator()(int t, int (&bs)[NT], int (&sw)[NT], int& wt) const {
@@ -96,7 +97,7 @@ struct ConvT2Addr {
         for (int nt = 0; nt < NT; ++nt) {
             const int sy = row0 + row_step * nt + da, sx = col + db;
             const int sp = (sy < rows && sx < cols) ? sy * cols + sx : zero;
-            bs[nt] = sp * 16; sw[nt] = sp & 15;
+            bs[nt] = sp * PS; sw[nt] = PS == 16 ? (sp & 15) : 0;
         }
     }
 };
