@@ -1,5 +1,5 @@
-// Shared MFMA pipeline pieces of the LDS-staged kernels (decoder.hip, encoder.hip): fp32 32x32x2 MFMA macros, the
-// XOR-swizzled LDS image addressing, and the software-pipelined tap contraction (TapPipe).
+// Shared MFMA pipeline pieces of the LDS-staged kernels (decoder.hip, encoder.hip): fp32 32x32x2 MFMA macros and the
+// software-pipelined tap contraction (TapPipe) over LDS images (padded pixel slots; k_fc4's batch tile is XOR-swizzled).
 #pragma once
 #include "kernels.h"
 
@@ -65,7 +65,6 @@ __device__ __forceinline__ float dpp_ror1(float x) { return __builtin_bit_cast(f
 __device__ __forceinline__ float dpp_ror15(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x12f, 0xf, 0xf, false)); }
 
 
-__device__ __forceinline__ int swz(int pix, int c4) { return pix * 16 + (c4 ^ (pix & 15)); }   // float4 index
 
 // Software-pipelined contraction over `ntaps` taps x 64 input channels (8 chunks of 8): the A fragments (weights,
 // L2) and B fragments (activations, LDS) of chunk i+1 are requested before the MFMAs of chunk i issue, so neither
