@@ -324,6 +324,22 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
                                            'note': 'HIP events of this rank on both engine contexts (expansions on the main stream, simulations on '
                                                    'the replica stream: the two overlap, so a launch shares the GPU with the other stream\'s kernels), '
                                                    'one un-timed decision batch'}
+            # the same launches with the GPU to themselves: one more un-timed decision batch planned WITHOUT the second stream
+            # (MCTS_Params.overlap_simulate = False: simulations behind the expansions on the main stream), so a k_dec_b launch of the
+            # planner's sizes (7680 images per expansion, 960 per simulation) is timed alone
+            import copy
+            p1 = copy.copy(p)
+            p1.overlap_simulate = False
+            model.prof_enable(True, classes=[DOM])
+            daimc_amd.active_inference_mcts_batch(model, frames, p1, o_shape=(1, 64, 64), episode_offset=rank * E)
+            ms1, n1 = model.prof_read()[DOM]
+            model.prof_enable(False)
+            if ms1 > 0:
+                ach1 = 2 * MAC_DECB_ROW * n_img / (ms1 * 1e-3) / 1e12
+                out['roofline']['dominant_unshared'] = {'kernel': 'k_dec_b', 'achieved': ach1, 'frac': ach1 / PEAK_FP32_MFMA_TF, 'launches': int(n1),
+                                                        'avg_launch_ms': ms1 / max(n1, 1),
+                                                        'note': 'one un-timed decision batch with the simulations on the main stream: 51 launches of '
+                                                                '7680 images + 50 of 960, each with the GPU to itself'}
     if with_cpu:
         out['cpu_baseline'] = cpu_baseline_mcts(a.samples)
         out['speedup_vs_cpu_baseline'] = dec / out['cpu_baseline']['value']
