@@ -281,10 +281,15 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
     return 0;
 }
 
+// does the generic decoder run its last two layers as k_dec_bg?  Decided from the geometry BEFORE scratch is sized (y3 exists only when
+// the final layer is its own launch), so that efe_reserve / efe_rollout_scratch_bytes and the call itself always agree
+static bool generic_dec_fused(const efe_ctx* ctx) {
+    return ctx->fuse_final_g && !ctx->last_s1 && dec_bg_ok(2 * ctx->base, 2 * ctx->base, ctx->chan);
+}
 // images per launch group of the generic decoder: bounded by the chunk options and by a byte budget for the group's layer activations
 int64_t generic_dec_chunk(const efe_ctx* ctx, int64_t N) {
     const int64_t B = ctx->base, H2 = 2 * B, H3 = ctx->last_s1 ? 2 * B : 4 * B;
-    const bool fused = ctx->fuse_final_g && !ctx->last_s1;          // y3 exists only when the final layer is its own launch
+    const bool fused = generic_dec_fused(ctx);
     const int64_t per_image = (2 * B * B * 64 + H2 * H2 * 64 + (fused ? 0 : H3 * H3 * 32)) * (int64_t)sizeof(float);
     const int64_t by_bytes = std::max<int64_t>(256, ctx->dec_budget_g / per_image);
     return std::min<int64_t>(std::min<int64_t>(std::min<int64_t>(ctx->dec_chunk, ctx->dec_chunk_g), by_bytes), N);
@@ -295,7 +300,7 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
                   hipStream_t st) {
     const int B = ctx->base, H2 = 2 * B, H3 = ctx->last_s1 ? 2 * B : 4 * B;
     const int C = (int)generic_dec_chunk(ctx, N);
-    bool fused = ctx->fuse_final_g && !ctx->last_s1;
+    const bool fused = generic_dec_fused(ctx);
     float* hA = ctx->allocT<float>((size_t)N * 256);
     float* hB = ctx->allocT<float>((size_t)N * 256);
     float* x4 = ctx->allocT<float>((size_t)C * B * B * 64);
@@ -338,11 +343,8 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
             hipEvent_t e0 = ctx->prof_begin(st);
             const int rc = launch_dec_bg(f, st);
             ctx->prof_end(e0, st);
-            if (rc == 0) continue;
-            // geometry outside the fused kernel's limits: fall back to separate layers for the rest of the call
-            fused = false;
-            y3 = ctx->allocT<float>((size_t)C * H3 * H3 * 32);
-            if (!y3) return 1;
+            if (rc) return ctx->fail("fused decoder tail: unsupported geometry");      // (dec_bg_ok said yes: not reachable)
+            continue;
         }
         conv(ctx->g_ct[2], y2, y3, c, H2, 64, H3, 32, ctx->last_s1 ? 1 : 2);
         ctx->cls = PROF_FINAL;
@@ -1357,7 +1359,7 @@ int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples) {
         t += al(D * 2 * S * R * 32 * 4) + al(D * 3 * S * R * 16 * 4) + al(2 * R * 16 * 4) + al(D * 3 * S * R * 4) + al(D * S * R * IS * 4)
            + al(D * S * R * 32 * 4) + al(3 * R * 4);
         {   const size_t N = D * 3 * S * R, C = (size_t)generic_dec_chunk(ctx, (int64_t)N);
-            const bool fused = ctx->fuse_final_g && !ctx->last_s1;
+            const bool fused = generic_dec_fused(ctx);
             t += 2 * al(N * 256 * 4) + 2 * al(C * B * B * 64 * 4) + al(C * 4 * B * B * 64 * 4) + (fused ? 0 : al(C * (size_t)ctx->res * ctx->res * 32 * 4)); }
         enc(D * S * R);
         return (int64_t)(t + ((size_t)1 << 20));

@@ -296,22 +296,38 @@ void launch_convt_p(const ConvGArgs& a, hipStream_t st) {
 // for |x| < 30, and < 2 ulp on the logarithms -- inside the fp32 tolerances of tests/test_generic_geometry.py, which compare against
 // the libm-evaluated oracle.
 
+// Lane predicates that do not change from strip to strip (is this lane's pixel inside the strip / at an image edge / at a tile edge,
+// does this output element exist, does a tile boundary split its horizontal sum) are kept as BIT MASKS IN VGPRs (all ones / zero,
+// made opaque to the optimiser once) and applied with v_and / v_bfi: as conditions hipcc hoists each of them out of the strip loop
+// as a 64-bit SGPR mask -- about 25 of them, 47 SGPRs spilled to VGPR lanes and read back with v_readlane inside the MFMA phase.
+// Everything else that used to be a predicate is an addressing rule instead:
+//   * the next strip's rows are fetched as a fixed 128 pixels (8 float4 per thread): pixels past the strip's block land in ring
+//     slots nobody reads (the ring has 128 + Win slots, rounded up to 16), pixels past the image are zeros of the buffer resource;
+//   * an H-ring row above the image is a zeroed ring row (the two rows in front of strip 0), so the gather adds it unconditionally;
+//   * an output element whose horizontal sum is not split reads edge entry 4 of its row group, which always holds zero (no boundary
+//     lane ever exports to it: it would be the left neighbour of tile 0);
+//   * a lane without a pixel (the last lanes of the last tile when Win does not divide 128) writes its H values to a dummy slot.
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int bsel(int m, int a, int b) { return (a & m) | (b & ~m); }      // v_bfi_b32
+__device__ __forceinline__ int wrap1(int x, int n) { return (int)min((unsigned)x, (unsigned)(x - n)); }      // x in [0, 2n) -> x mod n
+
 template <int C>
 __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
-    extern __shared__ float4 sm[];                    // [RPa ring slots + 16 zero slots][17], then H planes, then edge values
+    extern __shared__ float4 sm[];                    // [RPa ring slots + 16 zero slots][17], then H planes, edge values, dummy slots
     __shared__ float sred[4];
     __shared__ float4 sb3[8];
-    constexpr int PS4 = 17, C4 = 16, Cin = 64;
+    constexpr int PS4 = 17, Cin = 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     constexpr int NG = 3 * C;
     const int Win = a.Win, Hin = a.Hin, TH = a.TH;
     const int Wout = 2 * Win, Hout = 2 * Hin;
-    const int SPX = TH * Win, RP = (TH + 1) * Win, RPa = (RP + 15) & ~15, ZP = RPa;
+    const int SPX = TH * Win, RP = (TH + 1) * Win, RPa = a.RPa, ZP = RPa;
     const int RING = 2 * TH + 2;
     float* sH = reinterpret_cast<float*>(sm + (size_t)(RPa + 16) * PS4);      // [RING][NG][Wout]
     float* sE = sH + RING * NG * Wout;                                         // [RING][NG][2 sides][4 tiles]
+    float* sD = sE + RING * NG * 8;                                            // [64 lanes][2 + 2]: where lanes without a pixel / a row group write
     const int img = blockIdx.x;
     if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
 
@@ -326,23 +342,24 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
 
     const int npix_img = Hin * Win;
     const float* src = a.y2 + (size_t)img * npix_img * Cin;
+    // a buffer resource over exactly this image: a pixel past its end has an out-of-range offset and the hardware returns zeros
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, npix_img * Cin * 4, 0x00020000);
-    const int c4 = tid & 15, ppt = tid >> 4;           // this thread's channel quad and first pixel of a 16-pixel step
-    auto fetch = [&](int P, bool in_block) -> float4 {
-        const bool ok = in_block && P < npix_img;
-        const unsigned off = ok ? (unsigned)((P * Cin + 4 * c4) * 4) : 0x80000000u;
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
-    };
+    const int c4 = tid & 15, ppt = tid >> 4;           // this thread's channel quad and first pixel of a 16-pixel step: byte tid * 16 of a pixel block
     {   // strip 0: rows 0 .. TH -> slots 0 .. RP - 1 (RP <= 192 pixels = 12 float4 per thread, all requested before the first is written:
         // one HBM round trip per image instead of three)
         float4 v[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) v[i] = fetch(ppt + 16 * i, ppt + 16 * i < RP);
+        for (int i = 0; i < 12; ++i) v[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(tid * 16 + i * 4096), 0, 0));
 #pragma unroll
         for (int i = 0; i < 12; ++i)
             if (ppt + 16 * i < RP) sm[(ppt + 16 * i) * PS4 + c4] = v[i];
     }
     for (int i = tid; i < 16 * PS4; i += 256) sm[ZP * PS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {   // H ring, edge array and dummy slots start as zeros (the two ring rows in front of strip 0 and edge entry 4 stay zero as long as they are read)
+        float4* z = reinterpret_cast<float4*>(sH);
+        const int nz = (RING * NG * (Wout + 8) + 256) >> 2;
+        for (int i = tid; i < nz; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];
 
     // A fragments of the tap contraction: row m of the 32 x 32 tile <-> (lane half hm, register u): hm = (m >> 2) & 1,
@@ -365,6 +382,17 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     const bool qv = q < SPX;
     const int lrow = (qv ? q : 0) / Win, ix = (qv ? q : 0) - lrow * Win;
     const bool first_col = ix == 0, last_col = ix == Win - 1;
+    // strip-invariant lane masks (see the note above the kernel)
+    const int m_q = opaque(qv ? -1 : 0);                                  // the lane has a pixel
+    const int m_qr = opaque((qv && !last_col) ? -1 : 0);                  // ... and that pixel has a right neighbour
+    const int m_l = opaque((j == 0 || first_col) ? 0 : -1);               // the left neighbour's value comes from the DPP shift
+    const int m_r = opaque((j == 31 || last_col) ? 0 : -1);
+    const int m_q0 = opaque((qv && h == 0) ? -1 : 0), m_q1 = opaque((qv && h == 1) ? -1 : 0);      // ... in lane half 0 / 1
+    const int wmask = w > 0 ? -1 : 0;                                     // (uniform) tile 0 has no left neighbour tile: its export slot is the zero entry
+    const int lrow2 = 2 * lrow;
+    const int hp_lane = (2 * ix + (h ? 5 * Wout : 0)) * 4;                // byte offset of this lane's H values inside a ring row: column 2 ix of row group h ? 5 : 0
+    const int ep_lane = (w + (h ? 5 * 8 : 0)) * 4;
+    const int dummy = (int)(size_t)sD + lane * 16;                        // LDS byte address
 
     const float4* W3 = reinterpret_cast<const float4*>(a.w3);
     const __amdgpu_buffer_rsrc_t wr = wrsrc(W3);
@@ -381,13 +409,13 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     // A strip with a successor only does g_sum between its barriers (the H rows it reads are rewritten by the next strip's tap phase,
     // which starts behind the next barrier); the transcendental pieces run inside the NEXT strip's contraction, between MFMA groups
     // (a wave's VALU instructions issue in the shadow of its own 64-cycle MFMAs), the stores behind that strip's barrier.
-    float gv[2][C]; int goh[2], gox[2]; bool gok[2];
+    float gv[2][C]; int goh[2], gox[2], gokm[2];
     auto g_sum = [&](int it, int f0, int r0g, int nrows) {      // it = state slot, f0 = first element of this pass
         const int f = f0 + tid;
         const int orow = (int)__umulhi((unsigned)f, a.magicW);
         const int ox = f - orow * Wout, oh = 2 * r0g - 1 + orow;
         goh[it] = oh; gox[it] = ox;
-        gok[it] = f < nrows * Wout && oh >= 0 && oh < Hout;
+        gokm[it] = (f < nrows * Wout && oh >= 0 && oh < Hout) ? -1 : 0;
         const int ohc = min(max(oh, 0), Hout - 1);          // (a thread without an output element reads valid slots and is discarded)
 #pragma unroll
         for (int c = 0; c < C; ++c) gv[it][c] = a.b4[c];
@@ -430,11 +458,11 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
             const float tw = reward_term(pr, goh[it], gox[it], Hout, Wout, a.reward_intent);
             t += mode == 0 ? te : tw;
         }
-        part += gok[it] ? t : 0.0f;
+        part += __builtin_bit_cast(float, __builtin_bit_cast(int, t) & gokm[it]);      // (every discarded thread's t is finite: its sums come from valid LDS slots)
         asm volatile("" : "+v"(part));
     };
     auto g_store = [&](int it) {
-        if (po && gok[it]) {
+        if (po && gokm[it]) {
             *reinterpret_cast<float4*>(po + ((size_t)goh[it] * Wout + gox[it]) * GEN_IMG_LD) =
                 make_float4(gv[it][0], C > 1 ? gv[it][C > 1 ? 1 : 0] : 0.f, C > 2 ? gv[it][C > 2 ? 2 : 0] : 0.f, 0.f);
         }
@@ -442,55 +470,98 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     // The same sums for a strip with a successor (2 TH rows = at most two passes), with everything that does not depend on the strip taken
     // out of the loop: output element f = p * 256 + tid is always (row orow, column ox) of the strip's 2 TH output rows, its tap row kh
     // always reads y3 row 2 r0 + (orow - kh), and whether (and where) a tile boundary splits its horizontal sum depends on
-    // (orow - kh) >> 1 and ox only.  Per strip only the ring slot and the image-edge tests remain.
-    int fox[2], forow[2], feo[2][3];
+    // (orow - kh) >> 1 and ox only.  Per strip only the ring slot remains: no predicates (a source row above the image is one of the
+    // zeroed ring rows in front of strip 0; an element without a split sum reads the zero edge entry 4).
+    int fox4[2], forow[2], feo4[2][3], m_f[2];
 #pragma unroll
     for (int p_ = 0; p_ < 2; ++p_) {
         const int f = p_ * 256 + tid;
         forow[p_] = (int)__umulhi((unsigned)f, a.magicW);
-        fox[p_] = f - forow[p_] * Wout;
-        const int ixx = fox[p_] >> 1;
+        const int fox = f - forow[p_] * Wout;
+        const int ixx = fox >> 1;
+        m_f[p_] = opaque(f < 2 * TH * Wout ? -1 : 0);
+        if (f >= 2 * TH * Wout) forow[p_] = 0;             // (a thread without an element reads the strip's first rows)
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             int lr_ = (forow[p_] - kh) >> 1;              // input row of the source y3 row, relative to the strip (-1 = the previous strip's last row)
             if (lr_ < 0) lr_ += TH;
             const int qq = lr_ * Win + ixx;
-            const bool needL = !(fox[p_] & 1) && (qq & 31) == 0 && ixx > 0;
-            const bool needR = (fox[p_] & 1) && (qq & 31) == 31 && ixx < Win - 1;
-            feo[p_][kh] = needL ? (qq >> 5) - 1 : needR ? 4 + (qq >> 5) + 1 : -1;
+            const bool needL = !(fox & 1) && (qq & 31) == 0 && ixx > 0;
+            const bool needR = (fox & 1) && (qq & 31) == 31 && ixx < Win - 1;
+            feo4[p_][kh] = opaque(((needL ? (qq >> 5) - 1 : needR ? 4 + (qq >> 5) + 1 : 4) + kh * C * 8) * 4);
         }
+        fox4[p_] = opaque((m_f[p_] ? fox : 0) * 4);
     }
+    const int rowH = NG * Wout * 4, rowE = NG * 8 * 4;      // bytes of a ring row of the H planes / of the edge array
+    const int sHb = (int)(size_t)sH, sEb = (int)(size_t)sE;
+    auto lds_f = [](int byte_addr) -> float { return *reinterpret_cast<const float __attribute__((address_space(3)))*>((size_t)byte_addr); };
     auto g_sum_fast = [&](int p_, int r0g) {
-        const int oh = 2 * r0g - 1 + forow[p_], ox = fox[p_];
-        goh[p_] = oh; gox[p_] = ox;
-        gok[p_] = p_ * 256 + tid < 2 * TH * Wout && oh >= 0 && oh < Hout;
+        const int oh = 2 * r0g - 1 + forow[p_];
+        goh[p_] = oh; gox[p_] = fox4[p_] >> 2;
+        gokm[p_] = m_f[p_] & ~(oh >> 31);                  // (oh < Hout for every strip with a successor)
 #pragma unroll
         for (int c = 0; c < C; ++c) gv[p_][c] = a.b4[c];
+        int hbm = hb - 2; hbm = hbm < 0 ? hbm + RING : hbm;          // uniform
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-            const int d = forow[p_] - kh;                  // y3 source row = 2 r0 + d
-            const int tr = 2 * r0g + d;
-            const bool rv = tr >= 0 && tr < Hout && forow[p_] < 2 * TH;
-            int hs = hb + (rv ? d : 0);
-            hs = hs < 0 ? hs + RING : hs;
-            hs = hs >= RING ? hs - RING : hs;
-            const float* hq = sH + ((size_t)hs * NG + kh * C) * Wout + ox;
-            const bool ed = rv && feo[p_][kh] >= 0;
-            const float* eq = sE + (hs * NG + kh * C) * 8 + (ed ? feo[p_][kh] : 0);
+            // y3 source row = 2 r0 + (forow - kh), ring slot hb + (forow - kh) = (hb - 2) + (2 - kh) + forow, in [0, 2 RING)
+            const int hs = wrap1(hbm + (2 - kh) + forow[p_], RING);
+            const int hq = hs * rowH + (sHb + kh * C * Wout * 4) + fox4[p_];
+            const int eq = hs * rowE + sEb + feo4[p_][kh];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const float hv = hq[c * Wout], ev = eq[c * 8];
-                gv[p_][c] += rv ? hv : 0.0f;
-                gv[p_][c] += ed ? ev : 0.0f;
+                gv[p_][c] += lds_f(hq + c * Wout * 4);
+                gv[p_][c] += lds_f(eq + c * 32);
             }
         }
     };
-    gok[0] = gok[1] = false; goh[0] = goh[1] = 0; gox[0] = gox[1] = 0;
+    gokm[0] = gokm[1] = 0; goh[0] = goh[1] = 0; gox[0] = gox[1] = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) gv[0][c] = gv[1][c] = 0.f;
     float4 pf[8];
     float4 a0 = wf(4, 0), a1 = wf(5, 0), a2 = wf(7, 0), a3 = wf(8, 0);      // a strip's first weight fragments are in flight across the barrier in front of it
     __syncthreads();
+
+    // ---- ReLU + tap contraction of one output-row parity (two column parities): T = Wt x relu(acc)
+    auto tap_mfma = [&](f32x16& A0, f32x16& A1, f32x16& T0, f32x16& T1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { A0[e] = relu_bits(A0[e]); A1[e] = relu_bits(A1[e]); T0[e] = 0.f; T1[e] = 0.f; }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            T0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], A0[e], T0, 0, 0, 0);
+            T1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], A1[e], T1, 0, 0, 0);
+        }
+    };
+    // ---- horizontal pre-sum of row group t of lane half h (G = h ? 5 + t : t) and its stores; hpa / epa = LDS byte addresses of the
+    // lane's H pair / edge entries in the ring row of (lrow, ph)
+    auto presum = [&](auto TC, const f32x16& T0, const f32x16& T1, int hpa, int epa) {
+        constexpr int t = decltype(TC)::value;
+        constexpr bool v0 = t < NG, v1 = 5 + t < NG;         // is G a row group at all, per lane half
+        if constexpr (v0 || v1) {
+            // out column 2 ix     takes kw = 0 from x = 2 ix + 1, kw = 1 from x = 2 ix, kw = 2 from x = 2 ix - 1 (left neighbour's odd column)
+            // out column 2 ix + 1 takes kw = 0 from x = 2 ix + 2 (right neighbour's even column), kw = 1 from x = 2 ix + 1, kw = 2 from x = 2 ix
+            float l = wave_shr1(T1[3 * t + 2]), rr = wave_shl1(T0[3 * t]);
+            l = __builtin_bit_cast(float, __builtin_bit_cast(int, l) & m_l);       // tile boundary (the neighbour is another wave's lane: edge array) or image edge
+            rr = __builtin_bit_cast(float, __builtin_bit_cast(int, rr) & m_r);
+            f32x2 eo;
+            eo.x = (T1[3 * t] + T0[3 * t + 1]) + l;
+            eo.y = (rr + T1[3 * t + 1]) + T0[3 * t + 2];
+            // a lane without a pixel, and the lane half whose G is not a row group, write to their dummy slot
+            const int mv = (v0 && v1) ? m_q : v0 ? m_q0 : m_q1;
+            const int ha = bsel(mv, hpa + t * Wout * 4, dummy), ea = bsel(mv, epa + t * 32, dummy);
+            *reinterpret_cast<f32x2 __attribute__((address_space(3)))*>((size_t)ha) = eo;
+            // exports of the tile's boundary lanes: for output column 2 (ix + 1) of the next tile's first lane / column 2 (ix - 1) + 1 of the previous tile's last lane
+            // (the elements are copied to scalars first: __builtin_bit_cast on a vector-element lvalue reads element 0)
+            const float e31 = T1[3 * t + 2], e00 = T0[3 * t];
+            if (j == 31) *reinterpret_cast<float __attribute__((address_space(3)))*>((size_t)ea) = e31;
+            if (j == 0) *reinterpret_cast<float __attribute__((address_space(3)))*>((size_t)(ea + 4 * (mv & 4))) = __builtin_bit_cast(float, __builtin_bit_cast(int, e00) & wmask);
+        }
+    };
+    auto ring_addr = [&](int ph, int& hpa, int& epa) {      // y3 row 2 (r0 + lrow) + ph of this lane -> H-ring slot -> byte addresses
+        const int hs = wrap1(hb + ph + lrow2, RING);         // hb + 1 + 2 (TH - 1) < 2 RING
+        hpa = hs * rowH + sHb + hp_lane;
+        epa = hs * rowE + sEb + ep_lane;
+    };
 
     for (int s = 0; s < NS; ++s) {
         const int r0 = s * TH;
@@ -498,14 +569,11 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
         // the four shifted views: LDS float4 index of (slot, quad h)
         int pA, pB, pC, pD;
         {
-            int nA = bs + q; if (nA >= RPa) nA -= RPa;
-            int nB = nA + 1; if (nB >= RPa) nB -= RPa;
-            int nC = nA + Win; if (nC >= RPa) nC -= RPa;
-            int nD = nC + 1; if (nD >= RPa) nD -= RPa;
-            pA = (qv ? nA : ZP + (nA & 15)) * PS4 + h;
-            pB = ((qv && !last_col) ? nB : ZP + (nB & 15)) * PS4 + h;
-            pC = (qv ? nC : ZP + (nC & 15)) * PS4 + h;
-            pD = ((qv && !last_col) ? nD : ZP + (nD & 15)) * PS4 + h;
+            const int nA = wrap1(bs + q, RPa), nB = wrap1(nA + 1, RPa), nC = wrap1(nA + Win, RPa), nD = wrap1(nC + 1, RPa);
+            pA = bsel(m_q, nA, ZP + (nA & 15)) * PS4 + h;
+            pB = bsel(m_qr, nB, ZP + (nB & 15)) * PS4 + h;
+            pC = bsel(m_q, nC, ZP + (nC & 15)) * PS4 + h;
+            pD = bsel(m_qr, nD, ZP + (nD & 15)) * PS4 + h;
         }
         f32x16 acc[4];
 #pragma unroll
@@ -515,7 +583,11 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
             for (int p_ = 0; p_ < 4; ++p_) { acc[p_][4 * g4] = bb.x; acc[p_][4 * g4 + 1] = bb.y; acc[p_][4 * g4 + 2] = bb.z; acc[p_][4 * g4 + 3] = bb.w; }
         }
         // ---- contraction, software-pipelined one chunk ahead: view A (4 chains: taps (1,1) (1,2) (2,1) (2,2) of parities 0..3), view B
-        // (taps (1,0) (2,0) of parities 1, 3), views C + D fused (taps (0,1) (0,2) of parities 2, 3; tap (0,0) of parity 3)
+        // (taps (1,0) (2,0) of parities 1, 3), views C + D fused (taps (0,1) (0,2) of parities 2, 3; tap (0,0) of parity 3).  Parities 0
+        // and 1 (output rows 2 y) are complete after view B: their tap contraction is issued in front of the C + D section and its
+        // horizontal pre-sums and LDS stores run between that section's MFMA groups.
+        f32x16 T0, T1;
+        int hpa, epa;
         {
             float4 b = sm[pA];
 #pragma unroll
@@ -551,6 +623,9 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[1], c0, cb) MFMA4(acc[3], c1, cb)
             }
+            __builtin_amdgcn_sched_barrier(0);
+            tap_mfma(acc[0], acc[1], T0, T1);
+            ring_addr(0, hpa, epa);
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
                 const float4 c0 = a0, c1 = a1, c2 = a2, cb = b, cd = bd;
@@ -559,52 +634,29 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
                     b = sm[pC + 2 * (kc + 1)];
                     bd = sm[pD + 2 * (kc + 1)];
                 }
-                if (kc == 6 && more) {       // the next strip's new rows (one contiguous block of SPX pixels), behind the strip's last weight-fragment request
-                    const int P0 = (r0 + TH + 1) * Win;
+                if (kc == 6 && more) {       // the next strip's new rows (128 pixels from the first new one), behind the strip's last weight-fragment request
+                    const unsigned P0b = (unsigned)((r0 + TH + 1) * Win) * (Cin * 4);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) pf[i] = fetch(P0 + ppt + 16 * i, ppt + 16 * i < SPX);
+                    for (int i = 0; i < 8; ++i) pf[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(tid * 16) + (P0b + i * 4096u), 0, 0));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[3], c1, cb) MFMA4(acc[2], c0, cb) MFMA4(acc[3], c2, cd)
+                if (kc == 1) presum(std::integral_constant<int, 0>{}, T0, T1, hpa, epa);
+                if (kc == 2) presum(std::integral_constant<int, 1>{}, T0, T1, hpa, epa);
+                if (kc == 3) presum(std::integral_constant<int, 2>{}, T0, T1, hpa, epa);
+                if (kc == 4) presum(std::integral_constant<int, 3>{}, T0, T1, hpa, epa);
+                if (kc == 5) presum(std::integral_constant<int, 4>{}, T0, T1, hpa, epa);
             }
         }
-        // ---- ReLU, tap contraction and horizontal pre-sum, one output-row parity ph at a time (two column parities)
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            f32x16 T0, T1;                               // column parity 0 (x = 2 ix) / 1 (x = 2 ix + 1)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                acc[2 * ph][e] = relu_bits(acc[2 * ph][e]); acc[2 * ph + 1][e] = relu_bits(acc[2 * ph + 1][e]);
-                T0[e] = 0.f; T1[e] = 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                T0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], acc[2 * ph][e], T0, 0, 0, 0);
-                T1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], acc[2 * ph + 1][e], T1, 0, 0, 0);
-            }
-            // y3 row 2 (r0 + lrow) + ph of this lane -> H-ring slot
-            int hs = hb + 2 * lrow + ph;
-            if (hs >= RING) hs -= RING;
-            float* hp = sH + (size_t)hs * NG * Wout + 2 * ix;
-            float* ep = sE + hs * NG * 8 + w;
-#pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                const int G = h ? 5 + t : t;
-                // out column 2 ix     takes kw = 0 from x = 2 ix + 1, kw = 1 from x = 2 ix, kw = 2 from x = 2 ix - 1 (left neighbour's odd column)
-                // out column 2 ix + 1 takes kw = 0 from x = 2 ix + 2 (right neighbour's even column), kw = 1 from x = 2 ix + 1, kw = 2 from x = 2 ix
-                float l = wave_shr1(T1[3 * t + 2]), rr = wave_shl1(T0[3 * t]);
-                l = (j == 0 || first_col) ? 0.f : l;          // tile boundary (the neighbour is another wave's lane: edge array) or image edge
-                rr = (j == 31 || last_col) ? 0.f : rr;
-                float2 eo;
-                eo.x = (T1[3 * t] + T0[3 * t + 1]) + l;
-                eo.y = (rr + T1[3 * t + 1]) + T0[3 * t + 2];
-                if (qv && G < NG) {         // (qv is false only for the last lanes of the last tile when Win does not divide 128)
-                    *reinterpret_cast<float2*>(hp + G * Wout) = eo;
-                    if (j == 31) ep[G * 8] = T1[3 * t + 2];          // for output column 2 (ix + 1) of the next tile's first lane
-                    if (j == 0) ep[G * 8 + 4] = T0[3 * t];           // for output column 2 (ix - 1) + 1 of the previous tile's last lane
-                }
-            }
-        }
+        // ---- output rows 2 y + 1 (parities 2, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        tap_mfma(acc[2], acc[3], T0, T1);
+        ring_addr(1, hpa, epa);
+        presum(std::integral_constant<int, 0>{}, T0, T1, hpa, epa);
+        presum(std::integral_constant<int, 1>{}, T0, T1, hpa, epa);
+        presum(std::integral_constant<int, 2>{}, T0, T1, hpa, epa);
+        presum(std::integral_constant<int, 3>{}, T0, T1, hpa, epa);
+        presum(std::integral_constant<int, 4>{}, T0, T1, hpa, epa);
         __syncthreads();
         g_store(0); g_store(1);                            // the previous strip's pixels
         if (!more) {
@@ -615,15 +667,14 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
         }
         // ---- output rows 2 r0 - 1 .. 2 r0 + 2 TH - 2 are complete: take their sums now, the rest inside the next strip
         g_sum_fast(0, r0); g_sum_fast(1, r0);
-        // ---- the new rows take the slots of the strip's own TH rows (every wave is past the MFMA phase: barrier above)
+        // ---- the new rows take the slots behind the halo row (every wave is past the MFMA phase: barrier above); the pixels past the
+        // block's TH rows go to slots that no strip reads before they are rewritten (the ring has >= 128 + Win slots)
         {
+            int nb = bs + RP; nb = nb >= RPa ? nb - RPa : nb;       // uniform: slot of pixel (r0 + TH + 1, 0)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int pp = ppt + 16 * i;
-                int sl = bs + RP + pp;                     // pixel (r0 + TH + 1) Win + pp = pixel (r0, 0) + RP + pp, mod RPa
-                if (sl >= RPa) sl -= RPa;
-                if (sl >= RPa) sl -= RPa;
-                if (pp < SPX) sm[sl * PS4 + c4] = pf[i];
+                const int sl = wrap1(nb + ppt + 16 * i, RPa);
+                sm[sl * PS4 + c4] = pf[i];
             }
         }
         bs += SPX; if (bs >= RPa) bs -= RPa;
@@ -638,9 +689,10 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     if (tid == 0) a.val[mg] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
+static int dec_bg_rpa(int Win) { return (128 + Win + 15) & ~15; }      // ring slots: the TH + 1 rows of a strip and the 128-pixel fetch of the next one
 static size_t dec_bg_lds(int Win, int TH, int C) {
-    const int RPa = ((TH + 1) * Win + 15) & ~15, RING = 2 * TH + 2, NG = 3 * C;
-    return (size_t)(RPa + 16) * 17 * sizeof(float4) + (size_t)RING * NG * (2 * Win) * sizeof(float) + (size_t)RING * NG * 8 * sizeof(float);
+    const int RPa = dec_bg_rpa(Win), RING = 2 * TH + 2, NG = 3 * C;
+    return (size_t)(RPa + 16) * 17 * sizeof(float4) + (size_t)RING * NG * (2 * Win + 8) * sizeof(float) + 256 * sizeof(float);
 }
 constexpr size_t DEC_BG_MAX_LDS = 96 * 1024;
 int init_generic_dec_kernels() {
@@ -653,13 +705,17 @@ int init_generic_dec_kernels() {
     if (hipFuncSetAttribute((const void*)k_convt_p<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_P_MAX_LDS) != hipSuccess) return 1;
     return 0;
 }
-// 0 = launched; 1 = geometry outside the kernel's limits (the caller runs the layers separately)
+// the fused kernel's limits: C <= 3 channels, a full-width strip of 128 / Win rows in LDS (the caller runs the layers separately otherwise)
+bool dec_bg_ok(int Hin, int Win, int C) {
+    if (Win < 4 || Win > 64 || Hin < 2 || C < 1 || C > 3) return false;
+    return dec_bg_lds(Win, 128 / Win, C) <= DEC_BG_MAX_LDS;
+}
+// 0 = launched; 1 = geometry outside the kernel's limits
 int launch_dec_bg(DecBGArgs a, hipStream_t st) {
-    if (a.Win < 4 || a.Win > 64 || a.Hin < 2 || a.C < 1 || a.C > 3) return 1;
+    if (!dec_bg_ok(a.Hin, a.Win, a.C)) return 1;
     a.TH = 128 / a.Win;
-    if (a.TH < 1 || a.TH * a.Win * 16 > 256 * 8) return 1;
+    a.RPa = dec_bg_rpa(a.Win);
     const size_t lds = dec_bg_lds(a.Win, a.TH, a.C);
-    if (lds > DEC_BG_MAX_LDS) return 1;
     a.magicW = (unsigned)((0x100000000ull + (unsigned)(2 * a.Win) - 1) / (unsigned)(2 * a.Win));
     const dim3 grid((unsigned)a.rows), blk(256);
     if (a.C == 1) hipLaunchKernelGGL(k_dec_bg<1>, grid, blk, lds, st, a);

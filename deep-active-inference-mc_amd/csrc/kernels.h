@@ -246,7 +246,7 @@ struct DecBGArgs {
     const float* w3; const float* b3;   // packed [9][1][8][64][4], bias [32]
     const float* w4; float b4[4];       // [9 taps][32 ci][4 c], bias
     int rows, m0, rows_per_group, Hin, Win, C;
-    int TH; unsigned magicW;            // set by launch_dec_bg: input rows per strip, ceil(2^32 / Wout)
+    int TH, RPa; unsigned magicW;       // set by launch_dec_bg: input rows per strip, ring slots of the LDS strip, ceil(2^32 / Wout)
     GroupMap gm;
     int reward0, store0, reward_intent;
     RowMask live;
@@ -265,6 +265,7 @@ struct ConvEArgs {
 int launch_conv_e(ConvEArgs a, int layer, hipStream_t st);     // non-zero: outside the kernel's limits (use k_conv_g)
 int init_generic_enc_kernels();
 int launch_dec_bg(DecBGArgs a, hipStream_t st);                 // non-zero: geometry outside the kernel's limits
+bool dec_bg_ok(int Hin, int Win, int C);                        // the fused kernel takes this geometry (decided before scratch is sized)
 int init_generic_dec_kernels();
 struct FinalGArgs {
     const float* y3;                  // [rows][H*W][32]
