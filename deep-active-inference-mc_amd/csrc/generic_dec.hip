@@ -326,8 +326,8 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     const int SPX = TH * Win, RP = (TH + 1) * Win, RPa = a.RPa, ZP = RPa;
     const int RING = 2 * TH + 2;
     float* sH = reinterpret_cast<float*>(sm + (size_t)(RPa + 16) * PS4);      // [RING][NG][Wout]
-    float* sE = sH + RING * NG * Wout;                                         // [RING][NG][2 sides][4 tiles]
-    float* sD = sE + RING * NG * 8;                                            // [64 lanes][2 + 2]: where lanes without a pixel / a row group write
+    float* sE = sH + RING * NG * Wout;                                         // [RING][NG][2 sides][4 tiles][2]
+    float* sD = sE + RING * NG * 16;                                           // [64 lanes][2]: where lanes without a pixel / a row group write
     const int img = blockIdx.x;
     if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
 
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     for (int i = tid; i < 16 * PS4; i += 256) sm[ZP * PS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     {   // H ring, edge array and dummy slots start as zeros (the two ring rows in front of strip 0 and edge entry 4 stay zero as long as they are read)
         float4* z = reinterpret_cast<float4*>(sH);
-        const int nz = (RING * NG * (Wout + 8) + 256) >> 2;
+        const int nz = (RING * NG * (Wout + 16) + 128) >> 2;
         for (int i = tid; i < nz; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];
@@ -388,11 +388,12 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     const int m_l = opaque((j == 0 || first_col) ? 0 : -1);               // the left neighbour's value comes from the DPP shift
     const int m_r = opaque((j == 31 || last_col) ? 0 : -1);
     const int m_q0 = opaque((qv && h == 0) ? -1 : 0), m_q1 = opaque((qv && h == 1) ? -1 : 0);      // ... in lane half 0 / 1
+    const int m_j31 = opaque(j == 31 ? -1 : 0);
     const int wmask = w > 0 ? -1 : 0;                                     // (uniform) tile 0 has no left neighbour tile: its export slot is the zero entry
     const int lrow2 = 2 * lrow;
     const int hp_lane = (2 * ix + (h ? 5 * Wout : 0)) * 4;                // byte offset of this lane's H values inside a ring row: column 2 ix of row group h ? 5 : 0
-    const int ep_lane = (w + (h ? 5 * 8 : 0)) * 4;
-    const int dummy = (int)(size_t)sD + lane * 16;                        // LDS byte address
+    const int ep_lane = (w + (h ? 5 * 8 : 0) + (j == 0 ? 4 : 0)) * 8;     // a tile's lane 31 exports to entry w, its lane 0 to entry 4 + w
+    const int dummy = (int)(size_t)sD + lane * 8;                         // LDS byte address
 
     const float4* W3 = reinterpret_cast<const float4*>(a.w3);
     const __amdgpu_buffer_rsrc_t wr = wrsrc(W3);
@@ -403,23 +404,105 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     const int NS = (Hin + TH - 1) / TH;
     int bs = 0;                                        // ring slot of pixel (r0, 0)
     int hb = 0;                                        // H-ring slot of y3 row 2 r0
-    // ---- gather of the output elements of a strip (thread = output pixel f of rows 2 r0 - 1 .. , 256 per pass; C channels), in pieces:
-    //   g_sum  : v[c] = b4[c] + sum_kh H[kh][c] (+ the other wave's half at a tile boundary)   -- LDS reads + adds
-    //   g_sig  : sigmoid                 g_term : entropy / reward term into the thread's partial sum                g_store : image store
-    // A strip with a successor only does g_sum between its barriers (the H rows it reads are rewritten by the next strip's tap phase,
-    // which starts behind the next barrier); the transcendental pieces run inside the NEXT strip's contraction, between MFMA groups
-    // (a wave's VALU instructions issue in the shadow of its own 64-cycle MFMAs), the stores behind that strip's barrier.
-    float gv[2][C]; int goh[2], gox[2], gokm[2];
-    auto g_sum = [&](int it, int f0, int r0g, int nrows) {      // it = state slot, f0 = first element of this pass
-        const int f = f0 + tid;
-        const int orow = (int)__umulhi((unsigned)f, a.magicW);
-        const int ox = f - orow * Wout, oh = 2 * r0g - 1 + orow;
-        goh[it] = oh; gox[it] = ox;
-        gokm[it] = (f < nrows * Wout && oh >= 0 && oh < Hout) ? -1 : 0;
-        const int ohc = min(max(oh, 0), Hout - 1);          // (a thread without an output element reads valid slots and is discarded)
+    // ---- gather of the output elements of a strip.  A thread owns one COLUMN PAIR (2 xp, 2 xp + 1) of one output row -- the H pair one
+    // lane of the tap phase wrote -- so the 2 TH rows of a strip with a successor are one pass of <= 256 threads, every LDS read is a
+    // ds_read_b64 and the sums are packed adds.  Pieces:
+    //   g_load : the 3 C H pairs and 3 C edge pairs of the thread's element            g_add : v[c] = b4[c] + sum_kh (H[kh][c] + E[kh][c])
+    //   g_sig  : sigmoid       g_term : entropy / reward term into the thread's partial sum (image-uniform branch)       g_store : image store
+    // All of them run inside the NEXT strip's contraction, between MFMA groups (the H rows they read are rewritten behind that strip's
+    // barrier A at the earliest); the last strip of an image is gathered in full behind its barrier B (g_last).
+    // Edge entries are PAIRS (to the even column, to the odd column): a tile's lane 31 exports (x, 0) to entry w -- read by the next tile's
+    // first lane, whose even column misses its left neighbour's kw = 2 value -- and its lane 0 exports (0, x) to entry 4 + w.  An element
+    // whose sums are not split reads entry 4, which always holds (0, 0) (tile 0 exports zero there).
+    f32x2 gv[C]; int goh, gxp, gokm;
+    const int f2 = tid;                                   // pair index inside the strip's 2 TH output rows
+    int forow = (int)__umulhi((unsigned)f2, a.magicWin);
+    const int fxp0 = f2 - forow * Win;
+    const int m_f = opaque(f2 < 2 * TH * Win ? -1 : 0);
+    if (f2 >= 2 * TH * Win) forow = 0;                    // (a thread without an element reads the strip's first rows and is discarded)
+    const int fxp8 = opaque((m_f ? fxp0 : 0) * 8);        // byte offset of the pair inside an H row
+    int feo8[3];
 #pragma unroll
-        for (int c = 0; c < C; ++c) gv[it][c] = a.b4[c];
-        const int ixx = ox >> 1;
+    for (int kh = 0; kh < 3; ++kh) {
+        int lr_ = (forow - kh) >> 1;                      // input row of the source y3 row, relative to the strip (-1 = the previous strip's last row)
+        if (lr_ < 0) lr_ += TH;
+        const int qq = lr_ * Win + (m_f ? fxp0 : 0);
+        const bool needL = (qq & 31) == 0 && fxp0 > 0;
+        const bool needR = (qq & 31) == 31 && fxp0 < Win - 1;
+        feo8[kh] = opaque(((needL ? (qq >> 5) - 1 : needR ? 4 + (qq >> 5) + 1 : 4) + kh * C * 8) * 8);
+    }
+    const int rowH = NG * Wout * 4, rowE = NG * 8 * 8;      // bytes of a ring row of the H planes / of the edge array
+    const int sHb = (int)(size_t)sH, sEb = (int)(size_t)sE;
+    auto lds_f2 = [](int byte_addr) -> f32x2 { return *reinterpret_cast<const f32x2 __attribute__((address_space(3)))*>((size_t)byte_addr); };
+    f32x2 gh[C], ge[C];
+    int g_hbm;
+    auto g_begin = [&](int r0g, int hbg) {
+        const int oh = 2 * r0g - 1 + forow;
+        goh = oh; gxp = fxp8 >> 3;
+        gokm = m_f & ~(oh >> 31);                          // (oh < Hout for every strip with a successor)
+        g_hbm = hbg - 2; g_hbm = g_hbm < 0 ? g_hbm + RING : g_hbm;          // uniform
+#pragma unroll
+        for (int c = 0; c < C; ++c) { gv[c].x = a.b4[c]; gv[c].y = a.b4[c]; }
+    };
+    auto g_load = [&](auto KH) {           // tap row kh: its C H pairs and C edge pairs
+        constexpr int kh = decltype(KH)::value;
+        // y3 source row = 2 r0 + (forow - kh), ring slot hb + (forow - kh) = (hb - 2) + (2 - kh) + forow, in [0, 2 RING); a source row above
+        // the image is one of the two zeroed ring rows in front of strip 0
+        const int hs = wrap1(g_hbm + (2 - kh) + forow, RING);
+        const int hq = hs * rowH + (sHb + kh * C * Wout * 4) + fxp8;
+        const int eq = hs * rowE + sEb + feo8[kh];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { gh[c] = lds_f2(hq + c * Wout * 4); ge[c] = lds_f2(eq + c * 64); }
+    };
+    auto g_add = [&]() {                   // in the fixed order b4 + (H0 + E0) + (H1 + E1) + (H2 + E2), one tap row per call
+#pragma unroll
+        for (int c = 0; c < C; ++c) { gv[c] += gh[c]; gv[c] += ge[c]; asm volatile("" : "+v"(gv[c])); }
+    };
+    // (the empty asm statements pin a piece where it is written: its results have no reader until after the strip barrier, and LLVM
+    // otherwise sinks the whole computation there -- out of the MFMA groups)
+    auto g_sig = [&]() {
+#pragma unroll
+        for (int c = 0; c < C; ++c) { gv[c].x = hw_sigmoid(gv[c].x); gv[c].y = hw_sigmoid(gv[c].y); asm volatile("" : "+v"(gv[c])); }
+    };
+    auto g_term = [&]() {                   // (every discarded thread's terms are finite: its sums come from valid LDS slots)
+        f32x2 t; t.x = 0.f; t.y = 0.f;
+        if (mode == 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const f32x2 pr = gv[c];
+                f32x2 l1, l0;
+                l1.x = hw_log(D1 - pr.x); l1.y = hw_log(D1 - pr.y); l0.x = hw_log(D0 + pr.x); l0.y = hw_log(D0 + pr.y);
+                t += (pr - 1.0f) * l1 - pr * l0;          // -(1 - p) ln((1e-5 + 1) - p) - p ln(1e-5 + p)
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                t.x += reward_term(gv[c].x, goh, 2 * gxp, Hout, Wout, a.reward_intent);
+                t.y += reward_term(gv[c].y, goh, 2 * gxp + 1, Hout, Wout, a.reward_intent);
+            }
+        }
+        part += __builtin_bit_cast(float, __builtin_bit_cast(int, t.x + t.y) & gokm);
+        asm volatile("" : "+v"(part));
+    };
+    auto g_store = [&]() {
+        if (po && gokm) {
+            float4* d = reinterpret_cast<float4*>(po + ((size_t)goh * Wout + 2 * gxp) * GEN_IMG_LD);
+            d[0] = make_float4(gv[0].x, C > 1 ? gv[C > 1 ? 1 : 0].x : 0.f, C > 2 ? gv[C > 2 ? 2 : 0].x : 0.f, 0.f);
+            d[1] = make_float4(gv[0].y, C > 1 ? gv[C > 1 ? 1 : 0].y : 0.f, C > 2 ? gv[C > 2 ? 2 : 0].y : 0.f, 0.f);
+        }
+    };
+    // the last strip's rows 2 r0 - 1 .. 2 r0 + 2 TH - 1 (it has no successor that would take its last row): pair f of the pass, general form
+    // (image edges, the strip may be short)
+    auto g_last = [&](int fp, int r0g, int nrows) {
+        const int f = fp + tid;
+        const int orow = (int)__umulhi((unsigned)f, a.magicWin);
+        const int xp = f - orow * Win, oh = 2 * r0g - 1 + orow;
+        goh = oh; gxp = xp;
+        gokm = (f < nrows * Win && oh >= 0 && oh < Hout) ? -1 : 0;
+        const int ohc = min(max(oh, 0), Hout - 1);          // (a thread without an output element reads valid slots and is discarded)
+        const int xpc = gokm ? xp : 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { gv[c].x = a.b4[c]; gv[c].y = a.b4[c]; }
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int tr = ohc + 1 - kh;            // y3 source row of tap row kh
@@ -427,114 +510,33 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
             int hs = hb + ((rv ? tr : ohc) - 2 * r0g);   // (an out-of-image source row reads a valid slot and adds zero)
             if (hs < 0) hs += RING;
             if (hs >= RING) hs -= RING;
-            const float* hq = sH + ((size_t)hs * NG + kh * C) * Wout + ox;
-            // the horizontal sum of a pixel at a tile boundary was split between two waves: the other half is in the edge array
             int lr_ = (tr >> 1) - r0g;
             if (lr_ < 0) lr_ += TH;
-            const int qq = lr_ * Win + ixx;
-            const bool needL = !(ox & 1) && (qq & 31) == 0 && ixx > 0;
-            const bool needR = (ox & 1) && (qq & 31) == 31 && ixx < Win - 1;
-            const float* eq = sE + (hs * NG + kh * C) * 8 + (needL ? (qq >> 5) - 1 : needR ? 4 + (qq >> 5) + 1 : 0);
+            const int qq = lr_ * Win + xpc;
+            const bool needL = (qq & 31) == 0 && xpc > 0;
+            const bool needR = (qq & 31) == 31 && xpc < Win - 1;
+            const int hq = hs * rowH + (sHb + kh * C * Wout * 4) + xpc * 8;
+            const int eq = hs * rowE + sEb + ((needL ? (qq >> 5) - 1 : needR ? 4 + (qq >> 5) + 1 : 4) + kh * C * 8) * 8;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const float hv = hq[c * Wout], ev = eq[c * 8];
-                gv[it][c] += rv ? hv : 0.0f;
-                gv[it][c] += (rv && (needL || needR)) ? ev : 0.0f;
+                const f32x2 hv = lds_f2(hq + c * Wout * 4), ev = lds_f2(eq + c * 64);
+                gv[c].x += rv ? hv.x : 0.0f; gv[c].y += rv ? hv.y : 0.0f;
+                gv[c].x += rv ? ev.x : 0.0f; gv[c].y += rv ? ev.y : 0.0f;
             }
         }
     };
-    // (the empty asm statements pin a piece where it is written: its results have no reader until after the strip barrier, and LLVM
-    // otherwise sinks the whole computation there -- back into the non-MFMA phase)
-    auto g_sig = [&](int it) {
+    gokm = 0; goh = 0; gxp = 0;
 #pragma unroll
-        for (int c = 0; c < C; ++c) { gv[it][c] = hw_sigmoid(gv[it][c]); asm volatile("" : "+v"(gv[it][c])); }
-    };
-    auto g_term = [&](int it) {             // branch-free: both forms are evaluated (the reward form is a few FMAs), discarded threads add zero
-        float t = 0.f;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const float pr = gv[it][c];
-            const float te = -(1.0f - pr) * hw_log(D1 - pr) - pr * hw_log(D0 + pr);
-            const float tw = reward_term(pr, goh[it], gox[it], Hout, Wout, a.reward_intent);
-            t += mode == 0 ? te : tw;
-        }
-        part += __builtin_bit_cast(float, __builtin_bit_cast(int, t) & gokm[it]);      // (every discarded thread's t is finite: its sums come from valid LDS slots)
-        asm volatile("" : "+v"(part));
-    };
-    auto g_store = [&](int it) {
-        if (po && gokm[it]) {
-            *reinterpret_cast<float4*>(po + ((size_t)goh[it] * Wout + gox[it]) * GEN_IMG_LD) =
-                make_float4(gv[it][0], C > 1 ? gv[it][C > 1 ? 1 : 0] : 0.f, C > 2 ? gv[it][C > 2 ? 2 : 0] : 0.f, 0.f);
-        }
-    };
-    // The same sums for a strip with a successor (2 TH rows = at most two passes), with everything that does not depend on the strip taken
-    // out of the loop: output element f = p * 256 + tid is always (row orow, column ox) of the strip's 2 TH output rows, its tap row kh
-    // always reads y3 row 2 r0 + (orow - kh), and whether (and where) a tile boundary splits its horizontal sum depends on
-    // (orow - kh) >> 1 and ox only.  Per strip only the ring slot remains: no predicates (a source row above the image is one of the
-    // zeroed ring rows in front of strip 0; an element without a split sum reads the zero edge entry 4).
-    int fox4[2], forow[2], feo4[2][3], m_f[2];
-#pragma unroll
-    for (int p_ = 0; p_ < 2; ++p_) {
-        const int f = p_ * 256 + tid;
-        forow[p_] = (int)__umulhi((unsigned)f, a.magicW);
-        const int fox = f - forow[p_] * Wout;
-        const int ixx = fox >> 1;
-        m_f[p_] = opaque(f < 2 * TH * Wout ? -1 : 0);
-        if (f >= 2 * TH * Wout) forow[p_] = 0;             // (a thread without an element reads the strip's first rows)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            int lr_ = (forow[p_] - kh) >> 1;              // input row of the source y3 row, relative to the strip (-1 = the previous strip's last row)
-            if (lr_ < 0) lr_ += TH;
-            const int qq = lr_ * Win + ixx;
-            const bool needL = !(fox & 1) && (qq & 31) == 0 && ixx > 0;
-            const bool needR = (fox & 1) && (qq & 31) == 31 && ixx < Win - 1;
-            feo4[p_][kh] = opaque(((needL ? (qq >> 5) - 1 : needR ? 4 + (qq >> 5) + 1 : 4) + kh * C * 8) * 4);
-        }
-        fox4[p_] = opaque((m_f[p_] ? fox : 0) * 4);
-    }
-    const int rowH = NG * Wout * 4, rowE = NG * 8 * 4;      // bytes of a ring row of the H planes / of the edge array
-    const int sHb = (int)(size_t)sH, sEb = (int)(size_t)sE;
-    auto lds_f = [](int byte_addr) -> float { return *reinterpret_cast<const float __attribute__((address_space(3)))*>((size_t)byte_addr); };
-    auto g_sum_fast = [&](int p_, int r0g) {
-        const int oh = 2 * r0g - 1 + forow[p_];
-        goh[p_] = oh; gox[p_] = fox4[p_] >> 2;
-        gokm[p_] = m_f[p_] & ~(oh >> 31);                  // (oh < Hout for every strip with a successor)
-#pragma unroll
-        for (int c = 0; c < C; ++c) gv[p_][c] = a.b4[c];
-        int hbm = hb - 2; hbm = hbm < 0 ? hbm + RING : hbm;          // uniform
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            // y3 source row = 2 r0 + (forow - kh), ring slot hb + (forow - kh) = (hb - 2) + (2 - kh) + forow, in [0, 2 RING)
-            const int hs = wrap1(hbm + (2 - kh) + forow[p_], RING);
-            const int hq = hs * rowH + (sHb + kh * C * Wout * 4) + fox4[p_];
-            const int eq = hs * rowE + sEb + feo4[p_][kh];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                gv[p_][c] += lds_f(hq + c * Wout * 4);
-                gv[p_][c] += lds_f(eq + c * 32);
-            }
-        }
-    };
-    gokm[0] = gokm[1] = 0; goh[0] = goh[1] = 0; gox[0] = gox[1] = 0;
-#pragma unroll
-    for (int c = 0; c < C; ++c) gv[0][c] = gv[1][c] = 0.f;
+    for (int c = 0; c < C; ++c) { gv[c].x = 0.f; gv[c].y = 0.f; }
     float4 pf[8];
     float4 a0 = wf(4, 0), a1 = wf(5, 0), a2 = wf(7, 0), a3 = wf(8, 0);      // a strip's first weight fragments are in flight across the barrier in front of it
     __syncthreads();
 
-    // ---- ReLU + tap contraction of one output-row parity (two column parities): T = Wt x relu(acc)
-    auto tap_mfma = [&](f32x16& A0, f32x16& A1, f32x16& T0, f32x16& T1) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { A0[e] = relu_bits(A0[e]); A1[e] = relu_bits(A1[e]); T0[e] = 0.f; T1[e] = 0.f; }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            T0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], A0[e], T0, 0, 0, 0);
-            T1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], A1[e], T1, 0, 0, 0);
-        }
-    };
-    // ---- horizontal pre-sum of row group t of lane half h (G = h ? 5 + t : t) and its stores; hpa / epa = LDS byte addresses of the
-    // lane's H pair / edge entries in the ring row of (lrow, ph)
-    auto presum = [&](auto TC, const f32x16& T0, const f32x16& T1, int hpa, int epa) {
+    // ---- horizontal pre-sum of row group t of lane half h (G = h ? 5 + t : t): ps_calc forms the lane's H pair and its boundary
+    // export in registers (DPP shifts + adds), ps_store writes them; hpa / epa = LDS byte addresses of the lane's H pair / edge entries
+    // in the ring row of (lrow, ph)
+    f32x2 eo[5]; float xe[5];
+    auto ps_calc = [&](auto TC, const f32x16& T0, const f32x16& T1) {
         constexpr int t = decltype(TC)::value;
         constexpr bool v0 = t < NG, v1 = 5 + t < NG;         // is G a row group at all, per lane half
         if constexpr (v0 || v1) {
@@ -543,18 +545,29 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
             float l = wave_shr1(T1[3 * t + 2]), rr = wave_shl1(T0[3 * t]);
             l = __builtin_bit_cast(float, __builtin_bit_cast(int, l) & m_l);       // tile boundary (the neighbour is another wave's lane: edge array) or image edge
             rr = __builtin_bit_cast(float, __builtin_bit_cast(int, rr) & m_r);
-            f32x2 eo;
-            eo.x = (T1[3 * t] + T0[3 * t + 1]) + l;
-            eo.y = (rr + T1[3 * t + 1]) + T0[3 * t + 2];
-            // a lane without a pixel, and the lane half whose G is not a row group, write to their dummy slot
-            const int mv = (v0 && v1) ? m_q : v0 ? m_q0 : m_q1;
-            const int ha = bsel(mv, hpa + t * Wout * 4, dummy), ea = bsel(mv, epa + t * 32, dummy);
-            *reinterpret_cast<f32x2 __attribute__((address_space(3)))*>((size_t)ha) = eo;
-            // exports of the tile's boundary lanes: for output column 2 (ix + 1) of the next tile's first lane / column 2 (ix - 1) + 1 of the previous tile's last lane
+            eo[t].x = (T1[3 * t] + T0[3 * t + 1]) + l;
+            eo[t].y = (rr + T1[3 * t + 1]) + T0[3 * t + 2];
+            // exports of the tile's boundary lanes: lane 31's kw = 2 value is for output column 2 (ix + 1) of the next tile's first lane, lane
+            // 0's kw = 0 value for column 2 (ix - 1) + 1 of the previous tile's last lane (tile 0 exports zero: its entry is the 'no split' one)
             // (the elements are copied to scalars first: __builtin_bit_cast on a vector-element lvalue reads element 0)
             const float e31 = T1[3 * t + 2], e00 = T0[3 * t];
-            if (j == 31) *reinterpret_cast<float __attribute__((address_space(3)))*>((size_t)ea) = e31;
-            if (j == 0) *reinterpret_cast<float __attribute__((address_space(3)))*>((size_t)(ea + 4 * (mv & 4))) = __builtin_bit_cast(float, __builtin_bit_cast(int, e00) & wmask);
+            xe[t] = __builtin_bit_cast(float, bsel(m_j31, __builtin_bit_cast(int, e31), __builtin_bit_cast(int, e00) & wmask));
+            asm volatile("" : "+v"(eo[t].x), "+v"(eo[t].y), "+v"(xe[t]));
+        }
+    };
+    auto ps_store = [&](auto TC, int hpa, int epa) {
+        constexpr int t = decltype(TC)::value;
+        constexpr bool v0 = t < NG, v1 = 5 + t < NG;
+        if constexpr (v0 || v1) {
+            // a lane without a pixel, and the lane half whose G is not a row group, write to their dummy slot
+            const int mv = (v0 && v1) ? m_q : v0 ? m_q0 : m_q1;
+            const int ha = bsel(mv, hpa + t * Wout * 4, dummy), ea = bsel(mv, epa + t * 64, dummy);
+            *reinterpret_cast<f32x2 __attribute__((address_space(3)))*>((size_t)ha) = eo[t];
+            if (j == 31 || j == 0) {
+                f32x2 x2;       // lane 31: (x, 0) for the next tile's even column; lane 0: (0, x) for the previous tile's odd column
+                x2.x = __builtin_bit_cast(float, __builtin_bit_cast(int, xe[t]) & m_j31); x2.y = __builtin_bit_cast(float, __builtin_bit_cast(int, xe[t]) & ~m_j31);
+                *reinterpret_cast<f32x2 __attribute__((address_space(3)))*>((size_t)ea) = x2;
+            }
         }
     };
     auto ring_addr = [&](int ph, int& hpa, int& epa) {      // y3 row 2 (r0 + lrow) + ph of this lane -> H-ring slot -> byte addresses
@@ -563,6 +576,13 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
         epa = hs * rowE + sEb + ep_lane;
     };
 
+    // One strip:   [barrier B]  g_load (previous strip's sums)  |  contraction: view A (+ g_add / g_sig / g_term pieces), view B, tap contraction
+    // of output rows 2 y, views C + D (+ the next strip's rows requested)  [barrier A: every wave is done reading the input ring]  tap contraction
+    // of rows 2 y + 1 with, between its MFMA groups, the pre-sums and H stores of rows 2 y, the ring writes of the new rows and the previous
+    // strip's image stores  |  pre-sums of rows 2 y + 1  [barrier B: H planes and input ring complete].  Beside a co-resident wave that streams
+    // MFMAs an instruction issued OUTSIDE the wave's own MFMA groups costs ~19 cycles: only g_load's address arithmetic
+    // and LDS requests, the last pre-sums and the loop bookkeeping are left there (the version with every H store, the gather sums and the ring
+    // writes between two barriers had ~470 such instructions per strip, this one ~230).
     for (int s = 0; s < NS; ++s) {
         const int r0 = s * TH;
         const bool more = s + 1 < NS;
@@ -575,19 +595,18 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
             pC = bsel(m_q, nC, ZP + (nC & 15)) * PS4 + h;
             pD = bsel(m_qr, nD, ZP + (nD & 15)) * PS4 + h;
         }
-        f32x16 acc[4];
+        int hbp = hb - 2 * TH; hbp = hbp < 0 ? hbp + RING : hbp;       // the previous strip's output rows 2 (r0 - TH) - 1 .. 2 r0 - 2 are complete
+        f32x16 bbv;                                          // register e holds channel (e & 3) + 8 (e >> 2) + 4 h: the bias is the chains' start value
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 bb = sb3[2 * g4 + h];          // register e holds channel (e & 3) + 8 (e >> 2) + 4 h: the bias is the start value
-#pragma unroll
-            for (int p_ = 0; p_ < 4; ++p_) { acc[p_][4 * g4] = bb.x; acc[p_][4 * g4 + 1] = bb.y; acc[p_][4 * g4 + 2] = bb.z; acc[p_][4 * g4 + 3] = bb.w; }
+            const float4 bb = sb3[2 * g4 + h];
+            bbv[4 * g4] = bb.x; bbv[4 * g4 + 1] = bb.y; bbv[4 * g4 + 2] = bb.z; bbv[4 * g4 + 3] = bb.w;
         }
+        f32x16 acc[4];
         // ---- contraction, software-pipelined one chunk ahead: view A (4 chains: taps (1,1) (1,2) (2,1) (2,2) of parities 0..3), view B
         // (taps (1,0) (2,0) of parities 1, 3), views C + D fused (taps (0,1) (0,2) of parities 2, 3; tap (0,0) of parity 3).  Parities 0
-        // and 1 (output rows 2 y) are complete after view B: their tap contraction is issued in front of the C + D section and its
-        // horizontal pre-sums and LDS stores run between that section's MFMA groups.
-        f32x16 T0, T1;
-        int hpa, epa;
+        // and 1 (output rows 2 y) are complete after view B.
+        f32x16 T0, T1, U0, U1;
         {
             float4 b = sm[pA];
 #pragma unroll
@@ -601,12 +620,17 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
                     b = sm[pB];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                MFMA4(acc[0], c0, cb) MFMA4(acc[1], c1, cb) MFMA4(acc[2], c2, cb) MFMA4(acc[3], c3, cb)
-                // the previous strip's gather (sums taken before the barrier), a piece per channel-block step
-                if (kc == 0) g_sig(0);
-                if (kc == 2) g_term(0);
-                if (kc == 4) g_sig(1);
-                if (kc == 6) g_term(1);
+                if (kc == 0) { MFMA4I(acc[0], bbv, c0, cb) MFMA4I(acc[1], bbv, c1, cb) MFMA4I(acc[2], bbv, c2, cb) MFMA4I(acc[3], bbv, c3, cb) }
+                else { MFMA4(acc[0], c0, cb) MFMA4(acc[1], c1, cb) MFMA4(acc[2], c2, cb) MFMA4(acc[3], c3, cb) }
+                // the previous strip's gather, a piece per channel-block step
+                if (s > 0) {
+                    if (kc == 0) { g_begin(r0 - TH, hbp); g_load(std::integral_constant<int, 0>{}); }
+                    if (kc == 1) { g_add(); g_load(std::integral_constant<int, 1>{}); }
+                    if (kc == 2) { g_add(); g_load(std::integral_constant<int, 2>{}); }
+                    if (kc == 3) g_add();
+                    if (kc == 4) g_sig();
+                    if (kc == 5) g_term();
+                }
             }
             float4 bd;
 #pragma unroll
@@ -624,8 +648,14 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
                 MFMA4(acc[1], c0, cb) MFMA4(acc[3], c1, cb)
             }
             __builtin_amdgcn_sched_barrier(0);
-            tap_mfma(acc[0], acc[1], T0, T1);
-            ring_addr(0, hpa, epa);
+            // ---- ReLU + tap contraction of output rows 2 y: T = Wt x relu(acc) (two column parities)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[0][e] = relu_bits(acc[0][e]); acc[1][e] = relu_bits(acc[1][e]); T0[e] = 0.f; T1[e] = 0.f; }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                T0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], acc[0][e], T0, 0, 0, 0);
+                T1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], acc[1][e], T1, 0, 0, 0);
+            }
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
                 const float4 c0 = a0, c1 = a1, c2 = a2, cb = b, cd = bd;
@@ -641,46 +671,64 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[3], c1, cb) MFMA4(acc[2], c0, cb) MFMA4(acc[3], c2, cd)
-                if (kc == 1) presum(std::integral_constant<int, 0>{}, T0, T1, hpa, epa);
-                if (kc == 2) presum(std::integral_constant<int, 1>{}, T0, T1, hpa, epa);
-                if (kc == 3) presum(std::integral_constant<int, 2>{}, T0, T1, hpa, epa);
-                if (kc == 4) presum(std::integral_constant<int, 3>{}, T0, T1, hpa, epa);
-                if (kc == 5) presum(std::integral_constant<int, 4>{}, T0, T1, hpa, epa);
+                // rows 2 y: pre-sums in registers (their LDS stores wait for barrier A: other waves still read the H rows they replace)
+                if (kc == 1) ps_calc(std::integral_constant<int, 0>{}, T0, T1);
+                if (kc == 2) ps_calc(std::integral_constant<int, 1>{}, T0, T1);
+                if (kc == 3) ps_calc(std::integral_constant<int, 2>{}, T0, T1);
+                if (kc == 4) ps_calc(std::integral_constant<int, 3>{}, T0, T1);
+                if (kc == 5) ps_calc(std::integral_constant<int, 4>{}, T0, T1);
             }
         }
-        // ---- output rows 2 y + 1 (parities 2, 3)
-        __builtin_amdgcn_sched_barrier(0);
-        tap_mfma(acc[2], acc[3], T0, T1);
+        __syncthreads();                                   // barrier A: no wave reads this strip's rows of the input ring any more
+        // ---- output rows 2 y + 1 (parities 2, 3): tap contraction in four groups of eight MFMAs, the other work between them
+        int hpa, epa;
+        ring_addr(0, hpa, epa);
+        int nb = bs + RP; nb = nb >= RPa ? nb - RPa : nb;       // uniform: slot of pixel (r0 + TH + 1, 0)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[2][e] = relu_bits(acc[2][e]); acc[3][e] = relu_bits(acc[3][e]); U0[e] = 0.f; U1[e] = 0.f; }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+            for (int e = 4 * g4; e < 4 * g4 + 4; ++e) {
+                U0 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], acc[2][e], U0, 0, 0, 0);
+                U1 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[e], acc[3][e], U1, 0, 0, 0);
+            }
+            if (g4 == 0) { ps_store(std::integral_constant<int, 0>{}, hpa, epa); ps_store(std::integral_constant<int, 1>{}, hpa, epa); }
+            if (g4 == 1) { ps_store(std::integral_constant<int, 2>{}, hpa, epa); ps_store(std::integral_constant<int, 3>{}, hpa, epa); }
+            if (g4 == 2) {
+                ps_store(std::integral_constant<int, 4>{}, hpa, epa);
+                if (more) {
+                    // the new rows take the slots behind the halo row; the pixels past the block's TH rows go to slots that no strip reads
+                    // before they are rewritten (the ring has >= 128 + Win slots)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sm[wrap1(nb + ppt + 16 * i, RPa) * PS4 + c4] = pf[i];
+                }
+            }
+            if (g4 == 3) {
+                if (more) {
+#pragma unroll
+                    for (int i = 4; i < 8; ++i) sm[wrap1(nb + ppt + 16 * i, RPa) * PS4 + c4] = pf[i];
+                }
+                g_store();                                 // the previous strip's pixels (sigmoid piece: view A section)
+                if (more) { a0 = wf(4, 0); a1 = wf(5, 0); a2 = wf(7, 0); a3 = wf(8, 0); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         ring_addr(1, hpa, epa);
-        presum(std::integral_constant<int, 0>{}, T0, T1, hpa, epa);
-        presum(std::integral_constant<int, 1>{}, T0, T1, hpa, epa);
-        presum(std::integral_constant<int, 2>{}, T0, T1, hpa, epa);
-        presum(std::integral_constant<int, 3>{}, T0, T1, hpa, epa);
-        presum(std::integral_constant<int, 4>{}, T0, T1, hpa, epa);
-        __syncthreads();
-        g_store(0); g_store(1);                            // the previous strip's pixels
+        ps_calc(std::integral_constant<int, 0>{}, U0, U1); ps_store(std::integral_constant<int, 0>{}, hpa, epa);
+        ps_calc(std::integral_constant<int, 1>{}, U0, U1); ps_store(std::integral_constant<int, 1>{}, hpa, epa);
+        ps_calc(std::integral_constant<int, 2>{}, U0, U1); ps_store(std::integral_constant<int, 2>{}, hpa, epa);
+        ps_calc(std::integral_constant<int, 3>{}, U0, U1); ps_store(std::integral_constant<int, 3>{}, hpa, epa);
+        ps_calc(std::integral_constant<int, 4>{}, U0, U1); ps_store(std::integral_constant<int, 4>{}, hpa, epa);
+        __syncthreads();                                   // barrier B: this strip's H planes and the next strip's rows are in LDS
         if (!more) {
             // the last strip has no successor: its rows (and the image's last row) are gathered in full now
             const int nrows = 2 * TH + 1;
-            for (int f0 = 0; f0 < nrows * Wout; f0 += 256) { g_sum(0, f0, r0, nrows); g_sig(0); g_term(0); g_store(0); }
+            for (int fp = 0; fp < nrows * Win; fp += 256) { g_last(fp, r0, nrows); g_sig(); g_term(); g_store(); }
             break;
-        }
-        // ---- output rows 2 r0 - 1 .. 2 r0 + 2 TH - 2 are complete: take their sums now, the rest inside the next strip
-        g_sum_fast(0, r0); g_sum_fast(1, r0);
-        // ---- the new rows take the slots behind the halo row (every wave is past the MFMA phase: barrier above); the pixels past the
-        // block's TH rows go to slots that no strip reads before they are rewritten (the ring has >= 128 + Win slots)
-        {
-            int nb = bs + RP; nb = nb >= RPa ? nb - RPa : nb;       // uniform: slot of pixel (r0 + TH + 1, 0)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int sl = wrap1(nb + ppt + 16 * i, RPa);
-                sm[sl * PS4 + c4] = pf[i];
-            }
         }
         bs += SPX; if (bs >= RPa) bs -= RPa;
         hb += 2 * TH; if (hb >= RING) hb -= RING;
-        a0 = wf(4, 0); a1 = wf(5, 0); a2 = wf(7, 0); a3 = wf(8, 0);
-        __syncthreads();
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
@@ -692,7 +740,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
 static int dec_bg_rpa(int Win) { return (128 + Win + 15) & ~15; }      // ring slots: the TH + 1 rows of a strip and the 128-pixel fetch of the next one
 static size_t dec_bg_lds(int Win, int TH, int C) {
     const int RPa = dec_bg_rpa(Win), RING = 2 * TH + 2, NG = 3 * C;
-    return (size_t)(RPa + 16) * 17 * sizeof(float4) + (size_t)RING * NG * (2 * Win + 8) * sizeof(float) + 256 * sizeof(float);
+    return (size_t)(RPa + 16) * 17 * sizeof(float4) + (size_t)RING * NG * (2 * Win + 16) * sizeof(float) + 128 * sizeof(float);
 }
 constexpr size_t DEC_BG_MAX_LDS = 96 * 1024;
 int init_generic_dec_kernels() {
@@ -716,7 +764,7 @@ int launch_dec_bg(DecBGArgs a, hipStream_t st) {
     a.TH = 128 / a.Win;
     a.RPa = dec_bg_rpa(a.Win);
     const size_t lds = dec_bg_lds(a.Win, a.TH, a.C);
-    a.magicW = (unsigned)((0x100000000ull + (unsigned)(2 * a.Win) - 1) / (unsigned)(2 * a.Win));
+    a.magicWin = (unsigned)((0x100000000ull + (unsigned)a.Win - 1) / (unsigned)a.Win);
     const dim3 grid((unsigned)a.rows), blk(256);
     if (a.C == 1) hipLaunchKernelGGL(k_dec_bg<1>, grid, blk, lds, st, a);
     else if (a.C == 2) hipLaunchKernelGGL(k_dec_bg<2>, grid, blk, lds, st, a);

@@ -246,7 +246,7 @@ struct DecBGArgs {
     const float* w3; const float* b3;   // packed [9][1][8][64][4], bias [32]
     const float* w4; float b4[4];       // [9 taps][32 ci][4 c], bias
     int rows, m0, rows_per_group, Hin, Win, C;
-    int TH, RPa; unsigned magicW;       // set by launch_dec_bg: input rows per strip, ring slots of the LDS strip, ceil(2^32 / Wout)
+    int TH, RPa; unsigned magicWin;     // set by launch_dec_bg: input rows per strip, ring slots of the LDS strip, ceil(2^32 / Win)
     GroupMap gm;
     int reward0, store0, reward_intent;
     RowMask live;

@@ -43,3 +43,23 @@ BUDGET = {
 def test_hot_kernel_fits_its_occupancy_target(kernels, name):
     assert name in kernels, sorted(kernels)
     assert kernels[name]['.vgpr_count'] <= BUDGET[name], (name, kernels[name])
+
+
+# SGPR spills go to VGPR lanes (v_writelane / v_readlane): no memory traffic, but VALU instructions inside MFMA phases (k_dec_bg carried
+# 44-47 of them through round 3: strip-invariant lane predicates hoisted as 64-bit masks).  Budget per hot kernel = what it ships with;
+# a kernel not listed here must not spill more than SSPILL_DEFAULT.
+SSPILL = {
+    'k_dec_bg<1>': 0, 'k_dec_bg<2>': 0, 'k_dec_bg<3>': 0,
+    'k_dec_b4': 4, 'k_dec_a': 0, 'k_fc4': 0, 'k_trans_fused': 0,
+    'k_convt_p<1, 4>': 0, 'k_convt_p<1, 8>': 0, 'k_convt_p<2, 4>': 0, 'k_convt_p<2, 8>': 5,
+    'k_conv_e<1, 4>': 0, 'k_conv_e<2, 16>': 0,
+    'k_enc_trunk': 22, 'k_head<16>': 15, 'k_head<32>': 22,
+    'k_final_g': 43,            # fallback of the generic decoder tail (option fuse_final_g = 0 / the resolution-32 variant)
+    'k_sim_chain': 120,         # latency-bound one-launch simulation chain (0.28 ms per planner iteration, beside the expansion)
+}
+SSPILL_DEFAULT = 0
+
+
+def test_sgpr_spill_budget(kernels):
+    over = {k: v.get('.sgpr_spill_count', 0) for k, v in kernels.items() if v.get('.sgpr_spill_count', 0) > SSPILL.get(k, SSPILL_DEFAULT)}
+    assert not over, over
