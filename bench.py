@@ -206,6 +206,84 @@ def timed_regions(step, steps, k0, rk, min_total_s=10.0, max_regions=60):
             return out, local, k
 
 
+def rank_of(rk):
+    return int(getattr(rk, 'rank', 0))
+
+
+class ClockSampler:
+    """Shader clock of this rank's GPU while the timed regions run, sampled from a SIDE THREAD that only reads the driver's sysfs file
+    (/sys/class/drm/card*/device/pp_dpm_sclk: the level marked '*'; rocm-smi --showclocks as a fallback) -- nothing is put on any HIP
+    stream.  The fp32 MFMA peak of the roofline entries assumes 2.4 GHz (MI355X_MICROARCH.md); boards in this pool hold 2.2 - 2.4 GHz under
+    this load (power), so the same binary scores 0.826 - 0.85 by lease: `frac_at_measured_clock` = frac x 2400 / sclk separates a kernel
+    regression from a slow board."""
+    NOMINAL_MHZ = 2400.0
+
+    def __init__(self, device, period=0.1):
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self.path, self.index = None, device.index or 0
+        try:
+            import glob
+            pr = torch.cuda.get_device_properties(device)
+            want = None
+            if hasattr(pr, 'pci_bus_id'):
+                want = '%04x:%02x:%02x' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, getattr(pr, 'pci_device_id', 0))
+            cards = []
+            for f in sorted(glob.glob('/sys/class/drm/card[0-9]*/device/pp_dpm_sclk')):
+                real = os.path.realpath(os.path.dirname(f))
+                if os.path.exists(os.path.join(os.path.dirname(f), 'vendor')) and open(os.path.join(os.path.dirname(f), 'vendor')).read().strip() != '0x1002':
+                    continue
+                cards.append((real, f))
+            match = [f for real, f in cards if want and want in real]
+            self.path = match[0] if match else (cards[self.index][1] if self.index < len(cards) else None)
+        except Exception:
+            self.path = None
+        self.source = 'sysfs pp_dpm_sclk' if self.path else 'rocm-smi --showclocks'
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        import re
+        if self.path:
+            for line in open(self.path).read().splitlines():
+                if line.rstrip().endswith('*'):
+                    m = re.search(r'(\d+)\s*Mhz', line, re.I)
+                    return float(m.group(1)) if m else None
+            return None
+        import subprocess
+        r = subprocess.run(['/opt/rocm/bin/rocm-smi', '-d', str(self.index), '--showclocks'], capture_output=True, text=True, timeout=5)
+        m = re.search(r'sclk clock level: \d+: \((\d+)Mhz\)', r.stdout)
+        return float(m.group(1)) if m else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                v = self._read()
+                if v:
+                    self.samples.append(v)
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=6)
+
+    def report(self, frac=None):
+        if not self.samples:
+            return {'sclk_mhz_under_load': None, 'frac_at_measured_clock': None, 'sclk_source': self.source + ' (no sample)'}
+        xs = sorted(self.samples)
+        med = xs[len(xs) // 2]
+        out = {'sclk_mhz_under_load': med, 'sclk_mhz_min': xs[0], 'sclk_mhz_max': xs[-1], 'sclk_samples': len(xs), 'sclk_source': self.source,
+               'sclk_nominal_mhz': self.NOMINAL_MHZ}
+        if frac is not None and med > 0:
+            out['frac_at_measured_clock'] = frac * self.NOMINAL_MHZ / med
+        return out
+
+
 class Ranks:
     """the process group of this run (None at one rank without --force-dist): barrier, max-over-ranks of the region times,
     per-rank figures, and the one data-path collective (all_gather of the action posteriors)"""
@@ -279,7 +357,8 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
 
     for k in range(warmup):
         step(k)
-    regions, local, _ = timed_regions(step, steps, 0, rk, min_total_s=min_total_s, max_regions=12)
+    with ClockSampler(device) as clk:
+        regions, local, _ = timed_regions(step, steps, 0, rk, min_total_s=min_total_s, max_regions=12)
     per_rank_ms = rk.per_rank(1e3 * statistics.median(local) / steps)
     dt = statistics.median(regions)
     dec = world * E * steps / dt
@@ -306,6 +385,7 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
         out['roofline'] = {'bound': 'mfma', 'kernel': 'whole decision (all kernels); k_dec_b alone under "dominant"',
                            'achieved': dec * fl / 1e12 / world, 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s',
                            'frac': dec * fl / 1e12 / world / PEAK_FP32_MFMA_TF, 'traffic': None}
+        out['roofline'].update(clk.report(out['roofline']['frac']))
         if not a.no_prof:
             # the planner's simulations run on a replica context (second stream): time the class on both contexts
             ctxs = [model] + ([model._replica] if getattr(model, '_replica', None) is not None else [])
@@ -340,7 +420,7 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
                                                         'avg_launch_ms': ms1 / max(n1, 1),
                                                         'note': 'one un-timed decision batch with the simulations on the main stream: 51 launches of '
                                                                 '7680 images + 50 of 960, each with the GPU to itself'}
-    if with_cpu:
+    if with_cpu and rank == 0:
         out['cpu_baseline'] = cpu_baseline_mcts(a.samples)
         out['speedup_vs_cpu_baseline'] = dec / out['cpu_baseline']['value']
     return out
@@ -408,7 +488,8 @@ def bench_generic(a, device, rk, steps, warmup, with_cpu, min_total_s=2.0):
         step(k)
     rk.sync()
     macs_row = model.last_call_macs() / rows
-    regions, local, _ = timed_regions(step, steps, warmup, rk, min_total_s=min_total_s, max_regions=12)
+    with ClockSampler(device) as clk:
+        regions, local, _ = timed_regions(step, steps, warmup, rk, min_total_s=min_total_s, max_regions=12)
     per_rank_ms = rk.per_rank(1e3 * statistics.median(local) / steps)
     dt = statistics.median(regions)
     value = world * rows * steps / dt
@@ -456,7 +537,8 @@ def bench_generic(a, device, rk, steps, warmup, with_cpu, min_total_s=2.0):
                            'achieved': dom.get('tflops', 0.0), 'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s',
                            'frac': dom.get('frac_of_fp32_mfma_peak', 0.0), 'traffic': None, 'launches': dom['launches'],
                            'avg_launch_ms': dom['ms'] / max(dom['launches'], 1), 'whole_step_frac': tf / world / PEAK_FP32_MFMA_TF}
-    if with_cpu:
+    out['roofline'].update(clk.report(out['roofline']['frac']))
+    if with_cpu and rank_of(rk) == 0:
         out['cpu_baseline'] = cpu_baseline_generic(A, C, R, D, S)
         out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
     return out
@@ -537,7 +619,7 @@ def main():
             dist.init_process_group('gloo')
     rk = Ranks(dist, world, rank, device, backend)
     solo = world == 1 and not use_dist
-    with_cpu = world == 1 and not a.no_cpu
+    with_cpu = not a.no_cpu                    # N > 1: rank 0 measures the headline's CPU leg after the timed regions (the extras' CPU legs are N = 1 only)
 
     def emit(out):
         if rank == 0:
@@ -578,7 +660,8 @@ def main():
         step(k)
     rk.sync()
     grows0 = model.arena_stats()['grow_count']
-    regions, local, kk = timed_regions(step, a.steps, a.warmup, rk, min_total_s=0.0 if a.single_region else a.min_seconds)
+    with ClockSampler(device) as clk:
+        regions, local, kk = timed_regions(step, a.steps, a.warmup, rk, min_total_s=0.0 if a.single_region else a.min_seconds)
     G = step(kk); kk += 1
     torch.cuda.synchronize()
     print(f'[bench] rank {rank}: {len(regions)} timed regions of {a.steps} steps, {sum(regions):.3f}s', file=sys.stderr, flush=True)
@@ -633,6 +716,7 @@ def main():
                                'traffic': None, 'launches': int(n), 'avg_launch_ms': ms / max(n, 1),
                                'flops_per_launch': 2 * MAC_DECB_ROW * rows_per_launch,
                                'timing': 'HIP events on the launch stream around the kernel, 10 un-timed steps after the timed regions'}
+            out['roofline'].update(clk.report(ach / PEAK_FP32_MFMA_TF))
             bpi, src = committed_traffic('k_dec_b')
             if bpi is not None:          # not measured in this run: PMC counters need rocprofv3 around the process
                 out['roofline']['traffic_from_profile'] = {'bytes_per_launch': bpi * rows_per_launch, 'file': 'profiles/' + src,
@@ -676,11 +760,11 @@ def main():
     if not a.no_extras:
         # every rank runs the extras (they are collective at N > 1); rank 0 attaches them
         key = 'mcts_cfg3' if world == 1 else 'mcts_cfg4_sharded'
-        mc = bench_mcts(a, model, device, rk, 3, 1, with_cpu)
+        mc = bench_mcts(a, model, device, rk, 3, 1, with_cpu and world == 1)
         mc05 = bench_mcts(a, model, device, rk, 3, 1, False, threshold=0.5, min_total_s=1.0)
         del model
         torch.cuda.empty_cache()
-        ai = bench_generic(a, device, rk, 2, 1, with_cpu)
+        ai = bench_generic(a, device, rk, 2, 1, with_cpu and world == 1)
         if rank == 0:
             out['extras'] = {key: mc, key + '_threshold_0.5': mc05, 'animalai_cfg5': ai}
             if pipelined:

@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
                 rv[nt] = m < a.n_pix;
                 const int mg = a.m0 + (rv[nt] ? m : 0);
                 const int g = mg / a.rows_per_group;
-                krow[nt] = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
+                krow[nt] = global_row(a.gm.ids, a.gm.ids_div, mg - g * a.rows_per_group, a.row_offset);
                 const uint2 key = group_key(a.gm, g);
                 kstream[nt] = key.x; kstage[nt] = key.y;
             }

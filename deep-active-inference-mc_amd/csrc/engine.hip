@@ -217,7 +217,7 @@ struct NoiseCfg {
     const uint8_t* mask = nullptr;      // liveness of the logical rows (efe_set_row_mask), entry = row / mask_div
     int mask_div = 1;
 };
-inline RowMask live_of(const NoiseCfg& nc, int m0) { return RowMask{nc.mask, nc.mask_div, m0, nc.rows_per_group}; }
+inline RowMask live_of(const NoiseCfg& nc, int m0) { return RowMask{nc.mask, nc.mask_div, m0, nc.rows_per_group, nc.mask ? nc.gm.ids : nullptr}; }
 
 void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float* Y, int ldy, int M, bool relu, bool drop,
         uint32_t tag, const NoiseCfg& nc, int m0, hipStream_t st) {
@@ -517,7 +517,8 @@ struct CoreIO {
     int R, D, S, mean_mode, carry_mean;
     uint32_t k0, k1, stage0, row_offset;
     const float* eps;         // nullable, per stage [3S][R][10]
-    const uint8_t* mask = nullptr; int mask_div = 1;        // liveness of the R logical rows (efe_set_row_mask)
+    const uint8_t* mask = nullptr; int mask_div = 1;        // liveness of the R logical rows (efe_rows.mask): entry slot = row / mask_div
+    const int32_t* ids = nullptr;                           // entry slot -> entry id (efe_rows.ids): noise keys and the mask follow the id
     // trajectory mode (D == 1, S == 1): T1 is given
     const float* given_ps1 = nullptr; const float* given_mean = nullptr; const float* given_logvar = nullptr;
     float *G = nullptr, *terms = nullptr, *ps1 = nullptr, *ps1_mean = nullptr, *po1 = nullptr, *t2parts = nullptr;
@@ -543,9 +544,11 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
             // trajectory mode: group T1 is supplied, only the loop-2 transition runs
             launch_fill_tr(io.given_mean, io.given_logvar, tr, R, st);
             nc.gm = GroupMap{1, 1, {PASS_T2, 0, 0}, io.stage0 + (uint32_t)t, 0};
+            nc.gm.ids = io.ids; nc.gm.ids_div = io.mask_div;
             if (run_mid(ctx, x, R, R, tr + (size_t)R * 32, nc, st)) return 1;
         } else {
             nc.gm = GroupMap{2 * S, S, {PASS_T1, PASS_T2, 0}, io.stage0 + (uint32_t)t, 0};
+            nc.gm.ids = io.ids; nc.gm.ids_div = io.mask_div;
             if (run_mid(ctx, x, R, 2 * S * R, tr, nc, st)) return 1;
         }
         TransPostArgs p{};
@@ -559,18 +562,21 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
         p.S = S; p.R = R; p.mean_mode = io.mean_mode; p.carry_mean = io.carry_mean;
         p.k0 = io.k0; p.k1 = io.k1; p.stage = io.stage0 + t; p.row_offset = io.row_offset; p.pi_dim = ctx->pi_dim;
         p.ctr = ctx->stage_ctr; p.ctr_mul = ctx->stage_mul;
+        p.ids = io.ids; p.ids_div = io.mask_div;
         launch_trans_post(p, st);
         x = nx;
     }
     {   // one batched decoder pass over D x 3S groups
         NoiseCfg nc; nc.k0 = io.k0; nc.k1 = io.k1; nc.rows_per_group = R; nc.row_offset = io.row_offset;
         nc.gm = GroupMap{3 * S, S, {PASS_D1, PASS_D2A, PASS_D2B}, io.stage0, 0};
+        nc.gm.ids = io.ids; nc.gm.ids_div = io.mask_div;
         nc.mask = io.mask; nc.mask_div = io.mask_div;
         if (run_decoder(ctx, dec_in, D * 3 * S * R, nc, 1, 1, val, po_store, st)) return 1;
     }
     {   // one batched encoder pass over the D x S loop-1 images
         NoiseCfg nc; nc.k0 = io.k0; nc.k1 = io.k1; nc.rows_per_group = R; nc.row_offset = io.row_offset;
         nc.gm = GroupMap{S, S, {PASS_E1, 0, 0}, io.stage0, 0};
+        nc.gm.ids = io.ids; nc.gm.ids_div = io.mask_div;
         nc.mask = io.mask; nc.mask_div = io.mask_div;
         if (run_encoder(ctx, po_store, D * S * R, nc, enc, st)) return 1;
     }
@@ -644,7 +650,7 @@ int finish(efe_ctx* ctx) {          // calls that use no engine scratch (environ
 // =====================================================================================================
 extern "C" {
 
-int efe_abi_version(void) { return 3; }
+int efe_abi_version(void) { return 4; }
 
 // efe_build_id(): the digest of the sources this library was compiled from -- a generated translation unit (build.py writes it at
 // link time, so an edit of one kernel file recompiles that file only)
@@ -1024,14 +1030,14 @@ int efe_mcts_stop_dev(efe_ctx* ctx, const efe_mcts_tree* tree, uint8_t* active, 
     return finish(ctx);
 }
 
-int efe_mcts_record(efe_ctx* ctx, const int32_t* iter_dev, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len,
+int efe_mcts_record(efe_ctx* ctx, const int32_t* iter_dev, int n_rows, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len,
                     const float* cur_g, const uint8_t* cur_active, int32_t* H_act, int32_t* H_len, float* H_g, uint8_t* H_active, void* stream) {
     if (!ctx) return 1;
     EFE_LOCK(ctx);
-    if (!iter_dev || E < 1 || max_depth < 1 || !cur_act || !cur_len || !cur_g || !cur_active || !H_act || !H_len || !H_g || !H_active)
+    if (!iter_dev || n_rows < 1 || E < 1 || max_depth < 1 || !cur_act || !cur_len || !cur_g || !cur_active || !H_act || !H_len || !H_g || !H_active)
         return ctx->fail("efe_mcts_record: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
-    launch_mcts_record(iter_dev, E, max_depth, cur_act, cur_len, cur_g, cur_active, H_act, H_len, H_g, H_active, (hipStream_t)stream);
+    launch_mcts_record(iter_dev, n_rows, E, max_depth, cur_act, cur_len, cur_g, cur_active, H_act, H_len, H_g, H_active, (hipStream_t)stream);
     return finish(ctx);
 }
 
@@ -1184,8 +1190,24 @@ int efe_reparameterize(efe_ctx* ctx, const float* mean, const float* logvar, int
 }
 
 // ---- EFE level -----------------------------------------------------------------------------------------
+// the row set of a call: argument if given, else the context's (deprecated) efe_set_row_mask state
+struct RowSet { const uint8_t* mask; const int32_t* ids; int div; };
+static int row_set(efe_ctx* ctx, const efe_rows* rows, int n_rows, int fixed_div, RowSet& out, const char* who) {
+    if (!rows) { out = RowSet{ctx->row_mask, nullptr, fixed_div > 0 ? fixed_div : ctx->row_mask_div}; return 0; }
+    const int div = fixed_div > 0 ? fixed_div : rows->rows_per_entry;
+    if (div < 1 || ((rows->mask || rows->ids) && n_rows % div != 0)) { ctx->fail((std::string(who) + ": efe_rows.rows_per_entry must divide the row count").c_str()); return 1; }
+    out = RowSet{rows->mask, rows->ids, div};
+    return 0;
+}
+
 int efe_calculate_g(efe_ctx* ctx, const float* s0, const float* pi0, int M, int samples, int mean_mode, const efe_noise* nz,
                     const float* eps, float* G, float* terms, float* ps1, float* ps1_mean, float* po1, float* t2parts, void* stream) {
+    return efe_calculate_g_rows(ctx, s0, pi0, M, samples, mean_mode, nz, eps, nullptr, G, terms, ps1, ps1_mean, po1, t2parts, stream);
+}
+
+int efe_calculate_g_rows(efe_ctx* ctx, const float* s0, const float* pi0, int M, int samples, int mean_mode, const efe_noise* nz,
+                         const float* eps, const efe_rows* rows, float* G, float* terms, float* ps1, float* ps1_mean, float* po1,
+                         float* t2parts, void* stream) {
     if (!ctx) return 1;
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
@@ -1199,7 +1221,9 @@ int efe_calculate_g(efe_ctx* ctx, const float* s0, const float* pi0, int M, int 
     io.x0 = x; io.R = M; io.D = 1; io.S = mean_mode ? 1 : samples; io.mean_mode = mean_mode; io.carry_mean = 0;
     io.k0 = (uint32_t)nz->seed; io.k1 = (uint32_t)(nz->seed >> 32); io.stage0 = nz->stage; io.row_offset = nz->row_offset;
     io.eps = eps; io.G = G; io.terms = terms; io.ps1 = ps1; io.ps1_mean = ps1_mean; io.po1 = po1; io.t2parts = t2parts;
-    io.mask = ctx->row_mask; io.mask_div = ctx->row_mask_div;
+    RowSet rs;
+    if (row_set(ctx, rows, M, 0, rs, "efe_calculate_g_rows")) return 1;
+    io.mask = rs.mask; io.ids = rs.ids; io.mask_div = rs.div;
     if (run_core(ctx, io, st)) return 1;
     return finish(ctx, st);
 }
@@ -1240,7 +1264,7 @@ int efe_rollout(efe_ctx* ctx, const float* o, const float* pi, int M, int steps,
 
 static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, const float* mean_traj, const float* lv_traj,
                            const float* pi0_traj, int T, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t row_offset,
-                           const float* eps, float* G, const uint8_t* mask, int mask_div, hipStream_t st) {
+                           const float* eps, float* G, const uint8_t* mask, const int32_t* ids, int mask_div, hipStream_t st) {
     float* x = ctx->allocT<float>((size_t)T * 16);
     if (!x) return 1;
     launch_pack_x(pi0_traj, s0_traj, x, T, ctx->pi_dim, S_DIM, st);
@@ -1248,7 +1272,7 @@ static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_
     io.x0 = x; io.R = T; io.D = 1; io.S = 1; io.mean_mode = 0; io.carry_mean = 0;
     io.k0 = k0; io.k1 = k1; io.stage0 = stage; io.row_offset = row_offset; io.eps = eps;
     io.given_ps1 = ps1_traj; io.given_mean = mean_traj; io.given_logvar = lv_traj;
-    io.G = G; io.mask = mask; io.mask_div = mask_div;
+    io.G = G; io.mask = mask; io.ids = ids; io.mask_div = mask_div;
     return run_core(ctx, io, st);
 }
 
@@ -1262,12 +1286,17 @@ int efe_trajectory(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, co
     if (!s0_traj || !ps1_traj || !ps1_mean_traj || !ps1_logvar_traj || !pi0_traj || !nz || !G || T < 1)
         return ctx->fail("efe_trajectory: bad arguments");
     if (trajectory_impl(ctx, s0_traj, ps1_traj, ps1_mean_traj, ps1_logvar_traj, pi0_traj, T, (uint32_t)nz->seed,
-                        (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, eps, G, nullptr, 1, st)) return 1;
+                        (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, eps, G, nullptr, nullptr, 1, st)) return 1;
     return finish(ctx, st);
 }
 
 int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int use_means, const efe_noise* nz,
                  const float* eps, const float* u, float* G_mean, float* pi0, float* Qpi0, void* stream) {
+    return efe_simulate_rows(ctx, starting_s, E, depth, use_means, nz, eps, u, nullptr, G_mean, pi0, Qpi0, stream);
+}
+
+int efe_simulate_rows(efe_ctx* ctx, const float* starting_s, int E, int depth, int use_means, const efe_noise* nz,
+                      const float* eps, const float* u, const efe_rows* rows, float* G_mean, float* pi0, float* Qpi0, void* stream) {
     if (!ctx) return 1;
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
@@ -1276,6 +1305,8 @@ int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int us
     if (!starting_s || !nz || !G_mean || !pi0 || E < 1 || depth < 1 || depth > 65535) return ctx->fail("efe_simulate: bad arguments");
     const uint32_t k0 = (uint32_t)nz->seed, k1 = (uint32_t)(nz->seed >> 32);
     const int T = depth;
+    RowSet rs;
+    if (row_set(ctx, rows, E, 1, rs, "efe_simulate_rows")) return 1;      // one episode = one entry
     float* s0t = ctx->allocT<float>((size_t)E * T * 10);
     float* ps1t = ctx->allocT<float>((size_t)E * T * 10);
     float* mt = ctx->allocT<float>((size_t)E * T * 10);
@@ -1286,7 +1317,7 @@ int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int us
         SimChainArgs sa{};
         sa.W = ctx->mid16; sa.H = ctx->top16; sa.s0 = starting_s; sa.E = E; sa.T = T; sa.use_means = use_means;
         sa.k0 = k0; sa.k1 = k1; sa.stage = nz->stage; sa.row_offset = nz->row_offset;
-        sa.eps_inj = eps; sa.u_inj = u; sa.ctr = ctx->stage_ctr; sa.ctr_mul = ctx->stage_mul;
+        sa.eps_inj = eps; sa.u_inj = u; sa.ctr = ctx->stage_ctr; sa.ctr_mul = ctx->stage_mul; sa.ids = rs.ids;
         sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0; sa.pi_dim = ctx->pi_dim;
         ctx->cls = PROF_MID;
         hipEvent_t e0 = ctx->prof_begin(st);
@@ -1296,7 +1327,7 @@ int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int us
         ctx->last_macs += (int64_t)E * T * (ctx->mac_trans + ctx->mac_habit);
     }
     if (trajectory_impl(ctx, s0t, ps1t, mt, lvt, pi0, E * T, k0, k1, nz->stage, nz->row_offset * (uint32_t)T,
-                        eps ? eps + (size_t)T * E * 10 : nullptr, Gt, ctx->row_mask, T, st)) return 1;     // trajectory row e * T + t belongs to episode e
+                        eps ? eps + (size_t)T * E * 10 : nullptr, Gt, rs.mask, rs.ids, T, st)) return 1;     // trajectory row e * T + t belongs to episode slot e
     launch_mean_rows(Gt, G_mean, E, T, st);
     return finish(ctx, st);
 }

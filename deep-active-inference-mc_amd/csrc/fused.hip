@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256, 2) k_trans_fused(const TransFusedArgs a) 
         const int m = min(row0 + n, a.M - 1);
         const int mg = a.m0 + m;
         const int g = mg / a.rows_per_group;
-        rk.row = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
+        rk.row = global_row(a.gm.ids, a.gm.ids_div, mg - g * a.rows_per_group, a.row_offset);
         const uint2 key = group_key(a.gm, g);
         rk.stream = key.x; rk.stage = key.y;
     }
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
             int act = 0;
             if (!bad && tot > 0.f) {
                 const float u = a.u_inj ? a.u_inj[(size_t)t * E + min(e, E - 1)]
-                                        : u01(noise_words(a.k0, a.k1, TAG_ACT, 0u, a.row_offset + e, stream_id(PASS_HABIT, (uint32_t)t), stage_).x);
+                                        : u01(noise_words(a.k0, a.k1, TAG_ACT, 0u, global_row(a.ids, 1, min(e, E - 1), a.row_offset), stream_id(PASS_HABIT, (uint32_t)t), stage_).x);
                 const float thr = u * tot;
                 float accq = 0.f; act = A - 1;
                 for (int k = 0; k < A; ++k) { accq += qq[k]; if (thr < accq) { act = k; break; } }
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
             }
             bufA[aswz(n, q)] = make_float4(v[0], v[1], v[2], v[3]);
         }
-        RowKey rk{a.row_offset + (uint32_t)(e0 + n), stream_id(PASS_SIM, (uint32_t)t), stage_};
+        RowKey rk{global_row(a.ids, 1, min(e0 + n, E - 1), a.row_offset), stream_id(PASS_SIM, (uint32_t)t), stage_};      // (rows past E: any valid key, results discarded)
         __syncthreads();
         trans_chain(a.W, bufA, bufB, w, n, q, ln, a.k0, a.k1, rk);
         // ---- reparameterise and scatter into the trajectory arrays (torchmodel.py:368-376, 382-390)
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
                 const float* o = reinterpret_cast<const float*>(bufA);
                 const float mean = o[4 * aswz(rr, k >> 2) + (k & 3)], lv = o[4 * aswz(rr, (10 + k) >> 2) + ((10 + k) & 3)];
                 const float eps = a.eps_inj ? a.eps_inj[((size_t)t * E + e) * 10 + k]
-                                            : normal_elem(a.k0, a.k1, a.row_offset + e, stream_id(PASS_SIM, (uint32_t)t), stage_, k);
+                                            : normal_elem(a.k0, a.k1, global_row(a.ids, 1, e, a.row_offset), stream_id(PASS_SIM, (uint32_t)t), stage_, k);
                 const float samp = eps * expf(lv * 0.5f) + mean;
                 const size_t oo = ((size_t)e * T + t) * 10 + k;
                 a.s0_traj[oo] = srow[rr * 16 + k];
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(256, 2) k_head(const HeadArgs a) {
         const int m = min(row0 + 16 * nb + n, a.M - 1);               // rows past the end recompute the last row (never stored)
         const int mg = a.m0 + m;
         const int g = mg / a.rows_per_group;
-        rk[nb].row = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
+        rk[nb].row = global_row(a.gm.ids, a.gm.ids_div, mg - g * a.rows_per_group, a.row_offset);
         const uint2 key = group_key(a.gm, g);
         rk[nb].stream = key.x; rk[nb].stage = key.y;
         xr[nb] = reinterpret_cast<const float4*>(a.X) + (size_t)m * (4 * a.kc0) + q;

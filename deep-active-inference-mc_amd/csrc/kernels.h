@@ -30,7 +30,16 @@ struct GroupMap {
     // optional device-side stage counter (efe_set_stage_counter): the stage of every draw is stage0 + t + *ctr * ctr_mul, so a captured
     // launch sequence (hipGraph) replays with fresh noise by bumping one device word instead of new kernel arguments
     const uint32_t* ctr = nullptr; uint32_t ctr_mul = 0;
+    // optional row identities (efe_rows.ids: the lock-step planner's compacted batches): logical row r of a group is row
+    // ids[r / ids_div] * ids_div + r % ids_div of the un-compacted batch -- the noise keys follow the episode, not its slot
+    const int32_t* ids = nullptr; int ids_div = 1;
 };
+// global noise row of logical row r of a group (counter word 1 of every Philox draw of that row)
+__device__ __forceinline__ uint32_t global_row(const int32_t* ids, int ids_div, int r, uint32_t row_offset) {
+    if (!ids) return row_offset + (uint32_t)r;
+    const int e = r / ids_div;
+    return row_offset + (uint32_t)(ids[e] * ids_div + (r - e * ids_div));
+}
 __device__ __forceinline__ uint32_t stage_bump(const uint32_t* ctr, uint32_t mul) { return ctr ? *ctr * mul : 0u; }
 __host__ __device__ inline void group_decode(const GroupMap& gm, int g, int& t, int& pidx, int& samp) {
     t = g / gm.per_stage;
@@ -50,9 +59,12 @@ __device__ __forceinline__ uint2 group_key(const GroupMap& gm, int g) {
 // per-image kernels (decoder stages, encoder trunk) skip dead images; the outputs of dead rows are unspecified.
 struct RowMask {
     const uint8_t* mask; int div, m0, rows_per_group;
+    const int32_t* ids = nullptr;       // optional: entry slot -> entry id (the mask is indexed by id)
 };
 __device__ __forceinline__ bool row_live(const RowMask& k, int m) {
-    return !k.mask || k.mask[((k.m0 + m) % k.rows_per_group) / k.div] != 0;
+    if (!k.mask) return true;
+    const int slot = ((k.m0 + m) % k.rows_per_group) / k.div;
+    return k.mask[k.ids ? k.ids[slot] : slot] != 0;
 }
 
 // One pixel's term of the reward log-likelihood log_bernoulli(x = pr, p = target) (/root/reference/src/torchutils.py:30-37):
@@ -144,6 +156,7 @@ struct TransPostArgs {
     uint32_t k0, k1, stage, row_offset;
     int pi_dim;            // x rows are [pi (pi_dim) | s (10) | zeros]
     const uint32_t* ctr; uint32_t ctr_mul;      // optional device-side stage counter (GroupMap)
+    const int32_t* ids; int ids_div;            // optional row identities (GroupMap)
 };
 void launch_trans_post(const TransPostArgs& a, hipStream_t st);
 
@@ -178,7 +191,7 @@ void launch_mcts_backprop(const MctsTree& t, const int32_t* path_nodes, const in
                           float* g_out, uint8_t* active_out, hipStream_t st);
 void launch_mcts_stop(const MctsTree& t, uint8_t* active, int32_t* stop_at, int repeat, const int32_t* repeat_dev, float threshold,
                       int32_t* n_active, hipStream_t st);          // repeat_dev != nullptr: the iteration index is read on the device
-void launch_mcts_record(const int32_t* iter, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len, const float* cur_g,
+void launch_mcts_record(const int32_t* iter, int n_rows, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len, const float* cur_g,
                         const uint8_t* cur_active, int32_t* H_act, int32_t* H_len, float* H_g, uint8_t* H_active, hipStream_t st);
 void launch_counter_add(int32_t* counter, int delta, hipStream_t st);
 
@@ -222,6 +235,7 @@ struct SimChainArgs {
     float* Qpi0;           // nullable [E][pi_dim]
     int pi_dim;
     const uint32_t* ctr; uint32_t ctr_mul;      // optional device-side stage counter (GroupMap)
+    const int32_t* ids;                         // optional episode identities: episode slot e is episode ids[e] of the un-compacted batch
 };
 void launch_sim_chain(const SimChainArgs& a, hipStream_t st);
 int init_fused_kernels();
@@ -291,12 +305,6 @@ void launch_root_post(const float* enc, const float* pi, const float* eps_inj, f
                       uint32_t k0, uint32_t k1, uint32_t pass, uint32_t sample, uint32_t stage, uint32_t row_offset, int pi_dim, hipStream_t st);
 void launch_split_enc(const float* enc, float* mean, float* logvar, int R, hipStream_t st);
 void launch_softmax4(const float* logits32, float* logits, float* q, float* logq, int R, int n, hipStream_t st);
-void launch_sample_action(const float* q, float* pi_onehot, float* q_ret, int R, int n, uint32_t k0, uint32_t k1,
-                          uint32_t sample, uint32_t stage, uint32_t row_offset, const float* u_inj, hipStream_t st);
-void launch_sim_post(const float* tr, const float* eps_inj, float* s0_traj, float* ps1_traj, float* mean_traj, float* lv_traj,
-                     float* s_next, const float* s_cur, int E, int T, int t, int use_means, uint32_t k0, uint32_t k1, uint32_t stage,
-                     uint32_t row_offset, hipStream_t st);
-void launch_scatter_pi(const float* pi_t, float* pi_traj, int E, int T, int t, int n, hipStream_t st);
 void launch_mean_rows(const float* G, float* out, int E, int T, hipStream_t st);
 void launch_fill_tr(const float* mean, const float* logvar, float* tr, int R, hipStream_t st);
 void launch_posterior(const float* sumG, float* P, float* logP, int n_groups, int n, float temperature, hipStream_t st);

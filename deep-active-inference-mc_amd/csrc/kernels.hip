@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) k_dense(const GemmArgs a) {
         if (a.dropout) {
             const int mg = a.m0 + m;
             const int g = mg / a.rows_per_group;
-            const uint32_t r = (uint32_t)(mg - g * a.rows_per_group) + a.row_offset;
+            const uint32_t r = global_row(a.gm.ids, a.gm.ids_div, mg - g * a.rows_per_group, a.row_offset);
             const uint2 key = group_key(a.gm, g);
             rnd = noise_words(a.k0, a.k1, a.tag, (uint32_t)((mt0 * 32) >> 7), r, key.x, key.y);
         }
@@ -211,7 +211,7 @@ __global__ void k_trans_post(const TransPostArgs a) {
         const float mean = tr[k], lv = tr[10 + k];
         float eps;
         if (a.eps_inj) eps = a.eps_inj[((size_t)q * R + r) * 10 + k];
-        else eps = normal_elem(a.k0, a.k1, a.row_offset + r, stream_id(pass, sample), a.stage + stage_bump(a.ctr, a.ctr_mul), k);
+        else eps = normal_elem(a.k0, a.k1, global_row(a.ids, a.ids_div, r, a.row_offset), stream_id(pass, sample), a.stage + stage_bump(a.ctr, a.ctr_mul), k);
         const float samp = eps * expf(lv * 0.5f) + mean;
         out = use_mean ? mean : samp;
         if (q == S - 1) {
@@ -392,67 +392,6 @@ __global__ void k_softmax4(const float* l32, float* logits, float* q, float* log
 }
 void launch_softmax4(const float* l32, float* logits, float* q, float* logq, int R, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_softmax4, dim3((R + 127) / 128), dim3(128), 0, st, l32, logits, q, logq, R, n);
-}
-
-// torch.multinomial(q, 1) stand-in (torchmodel.py:364,379): inverse CDF on a Philox uniform; invalid
-// probabilities -> action 0 (the reference's bare-except fallback).
-__global__ void k_sample_action(const float* q, float* pi_onehot, float* q_ret, int R, int n, uint32_t k0, uint32_t k1,
-                                uint32_t sample, uint32_t stage, uint32_t row_offset, const float* u_inj) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    float tot = 0.f; bool bad = false;
-    for (int k = 0; k < n; ++k) { const float v = q[(size_t)r * n + k]; if (!(v >= 0.f) || isinf(v)) bad = true; tot += v; }
-    int act = 0;
-    if (!bad && tot > 0.f) {
-        const float u = u_inj ? u_inj[r]
-                              : u01(noise_words(k0, k1, TAG_ACT, 0u, row_offset + r, stream_id(PASS_HABIT, sample), stage).x);
-        const float thr = u * tot;
-        float acc = 0.f; act = n - 1;
-        for (int k = 0; k < n; ++k) { acc += q[(size_t)r * n + k]; if (thr < acc) { act = k; break; } }
-    } else bad = true;
-    for (int k = 0; k < n; ++k) {
-        const float oh = (k == act) ? 1.f : 0.f;
-        pi_onehot[(size_t)r * n + k] = oh;
-        if (q_ret) q_ret[(size_t)r * n + k] = bad ? oh : q[(size_t)r * n + k];
-    }
-}
-void launch_sample_action(const float* q, float* pi_onehot, float* q_ret, int R, int n, uint32_t k0, uint32_t k1,
-                          uint32_t sample, uint32_t stage, uint32_t row_offset, const float* u_inj, hipStream_t st) {
-    hipLaunchKernelGGL(k_sample_action, dim3((R + 127) / 128), dim3(128), 0, st, q, pi_onehot, q_ret, R, n, k0, k1,
-                       sample, stage, row_offset, u_inj);
-}
-
-// mcts_step_simulate inner step (torchmodel.py:368-376,382-390): reparameterise the transition of step t and
-// scatter it into the trajectory arrays [E][T][10]; carry the next state.
-__global__ void k_sim_post(const float* tr, const float* eps_inj, float* s0_traj, float* ps1_traj, float* mean_traj, float* lv_traj,
-                           float* s_next, const float* s_cur, int E, int T, int t, int use_means, uint32_t k0, uint32_t k1,
-                           uint32_t stage, uint32_t row_offset) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= E * 10) return;
-    const int e = gid / 10, k = gid - e * 10;
-    const float mean = tr[(size_t)e * 32 + k], lv = tr[(size_t)e * 32 + 10 + k];
-    const float eps = eps_inj ? eps_inj[gid] : normal_elem(k0, k1, row_offset + e, stream_id(PASS_SIM, (uint32_t)t), stage, k);
-    const float samp = eps * expf(lv * 0.5f) + mean;
-    const size_t o = ((size_t)e * T + t) * 10 + k;
-    s0_traj[o] = s_cur[gid];
-    ps1_traj[o] = samp; mean_traj[o] = mean; lv_traj[o] = lv;
-    s_next[gid] = use_means ? mean : samp;
-}
-void launch_sim_post(const float* tr, const float* eps_inj, float* s0_traj, float* ps1_traj, float* mean_traj, float* lv_traj,
-                     float* s_next, const float* s_cur, int E, int T, int t, int use_means, uint32_t k0, uint32_t k1, uint32_t stage,
-                     uint32_t row_offset, hipStream_t st) {
-    hipLaunchKernelGGL(k_sim_post, dim3((E * 10 + 255) / 256), dim3(256), 0, st, tr, eps_inj, s0_traj, ps1_traj, mean_traj, lv_traj,
-                       s_next, s_cur, E, T, t, use_means, k0, k1, stage, row_offset);
-}
-
-__global__ void k_scatter_pi(const float* pi_t, float* pi_traj, int E, int T, int t, int n) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= E * n) return;
-    const int e = gid / n, k = gid - e * n;
-    pi_traj[((size_t)e * T + t) * n + k] = pi_t[gid];
-}
-void launch_scatter_pi(const float* pi_t, float* pi_traj, int E, int T, int t, int n, hipStream_t st) {
-    hipLaunchKernelGGL(k_scatter_pi, dim3((E * n + 255) / 256), dim3(256), 0, st, pi_t, pi_traj, E, T, t, n);
 }
 
 // torch.mean(G_traj) per episode (torchmodel.py:392)

@@ -153,10 +153,11 @@ void launch_mcts_stop(const MctsTree& t, uint8_t* active, int32_t* stop_at, int 
 
 // An iteration captured in a hipGraph writes its history row into fixed scratch rows; this copies them into row *iter of the
 // [iterations][E] history (the host-side loop passes the row pointers as kernel arguments instead)
-__global__ void k_mcts_record(const int32_t* iter, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len, const float* cur_g,
+__global__ void k_mcts_record(const int32_t* iter, int n_rows, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len, const float* cur_g,
                               const uint8_t* cur_active, int32_t* H_act, int32_t* H_len, float* H_g, uint8_t* H_active) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
+    if (*iter < 0 || *iter >= n_rows) return;          // a counter outside the history (a replayed graph run past its buffers) writes nothing
     const size_t it = (size_t)*iter;
     for (int d = 0; d < max_depth; ++d) H_act[(it * E + e) * max_depth + d] = cur_act[(size_t)e * max_depth + d];
     H_len[it * E + e] = cur_len[e];
@@ -164,9 +165,9 @@ __global__ void k_mcts_record(const int32_t* iter, int E, int max_depth, const i
     H_active[it * E + e] = cur_active[e];
 }
 __global__ void k_counter_add(int32_t* counter, int delta) { *counter += delta; }
-void launch_mcts_record(const int32_t* iter, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len, const float* cur_g,
+void launch_mcts_record(const int32_t* iter, int n_rows, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len, const float* cur_g,
                         const uint8_t* cur_active, int32_t* H_act, int32_t* H_len, float* H_g, uint8_t* H_active, hipStream_t st) {
-    hipLaunchKernelGGL(k_mcts_record, dim3((E + 63) / 64), dim3(64), 0, st, iter, E, max_depth, cur_act, cur_len, cur_g, cur_active, H_act, H_len,
+    hipLaunchKernelGGL(k_mcts_record, dim3((E + 63) / 64), dim3(64), 0, st, iter, n_rows, E, max_depth, cur_act, cur_len, cur_g, cur_active, H_act, H_len,
                        H_g, H_active);
 }
 void launch_counter_add(int32_t* counter, int delta, hipStream_t st) { hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, st, counter, delta); }

@@ -44,6 +44,25 @@ const float* optp(const OptT& t, Tensor& keep, const char* name, int64_t numel) 
     TORCH_CHECK(keep.numel() == numel, "efe: ", name, " has ", keep.numel(), " elements, expected ", numel);
     return keep.data_ptr<float>();
 }
+// the optional row set of a call (efe_rows): mask = uint8 [entries of the un-compacted batch], ids = int32 [entries of this call]
+struct RowsArg { efe_rows r{nullptr, nullptr, 1}; Tensor mk, ik; const efe_rows* ptr = nullptr; };
+void rows_arg(RowsArg& ra, const OptT& mask, const OptT& ids, int64_t rows_per_entry, int64_t n_entries) {
+    const bool hm = mask.has_value() && mask->defined(), hi = ids.has_value() && ids->defined();
+    if (!hm && !hi) return;
+    TORCH_CHECK(rows_per_entry >= 1, "efe: rows_per_entry must be >= 1");
+    ra.r.rows_per_entry = (int32_t)rows_per_entry;
+    if (hm) {
+        TORCH_CHECK(mask->is_cuda() && mask->scalar_type() == at::kByte && mask->is_contiguous(), "efe: row mask must be a contiguous uint8 HIP tensor");
+        TORCH_CHECK(hi || mask->numel() >= n_entries, "efe: row mask has ", mask->numel(), " entries, the call has ", n_entries);
+        ra.mk = *mask; ra.r.mask = ra.mk.data_ptr<uint8_t>();
+    }
+    if (hi) {
+        TORCH_CHECK(ids->is_cuda() && ids->scalar_type() == at::kInt && ids->is_contiguous(), "efe: row ids must be a contiguous int32 HIP tensor");
+        TORCH_CHECK(ids->numel() == n_entries, "efe: row ids has ", ids->numel(), " entries, the call has ", n_entries);
+        ra.ik = *ids; ra.r.ids = ra.ik.data_ptr<int32_t>();
+    }
+    ra.ptr = &ra.r;
+}
 void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 efe_noise noise(int64_t seed, int64_t stage, int64_t pass, int64_t sample, int64_t row_offset) {
     efe_noise nz;
@@ -113,7 +132,7 @@ std::tuple<Tensor, Tensor, Tensor> habit(int64_t h, const Tensor& s_) {
 // calculate_G / calculate_G_mean, torchmodel.py:270-327
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> calculate_g(int64_t h, const Tensor& s0_, const Tensor& pi0_, int64_t samples,
                                                                        bool mean_mode, int64_t seed, int64_t stage, int64_t row_offset,
-                                                                       const OptT& eps) {
+                                                                       const OptT& eps, const OptT& mask, const OptT& ids, int64_t rows_per_entry) {
     efe_ctx* c = CTX(h);
     Tensor s0 = in(s0_, "s0"), pi0 = in(pi0_, "pi0"), ek;
     const Geo gq = geo(c);
@@ -125,8 +144,11 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> calculate_g(int64_t h
     Tensor G = at::empty({M}, op), terms = at::empty({3, M}, op), ps1 = at::empty({M, 10}, op), ps1m = at::empty({M, 10}, op),
            po1 = at::empty({M, gq.C, gq.R, gq.R}, op), parts = at::empty({2, M}, op);
     efe_noise nz = noise(seed, stage, 0, 0, row_offset);
-    ok(c, efe_calculate_g(c, s0.data_ptr<float>(), pi0.data_ptr<float>(), M, S, mean_mode ? 1 : 0, &nz, optp(eps, ek, "eps", (int64_t)3 * S * M * 10),
-                          G.data_ptr<float>(), terms.data_ptr<float>(), ps1.data_ptr<float>(), ps1m.data_ptr<float>(), po1.data_ptr<float>(),
+    RowsArg ra;
+    TORCH_CHECK(rows_per_entry < 1 || M % rows_per_entry == 0, "efe: rows_per_entry must divide the row count");
+    rows_arg(ra, mask, ids, rows_per_entry, rows_per_entry >= 1 ? M / rows_per_entry : M);
+    ok(c, efe_calculate_g_rows(c, s0.data_ptr<float>(), pi0.data_ptr<float>(), M, S, mean_mode ? 1 : 0, &nz, optp(eps, ek, "eps", (int64_t)3 * S * M * 10),
+                          ra.ptr, G.data_ptr<float>(), terms.data_ptr<float>(), ps1.data_ptr<float>(), ps1m.data_ptr<float>(), po1.data_ptr<float>(),
                           parts.data_ptr<float>(), stream_of(s0)));
     return {G, terms, ps1, ps1m, po1, parts};
 }
@@ -168,7 +190,7 @@ Tensor trajectory(int64_t h, const Tensor& s0_, const Tensor& ps1_, const Tensor
 
 // mcts_step_simulate for E lock-step episodes, torchmodel.py:354-393
 std::tuple<Tensor, Tensor, Tensor> simulate(int64_t h, const Tensor& s_, int64_t depth, bool use_means, int64_t seed, int64_t stage,
-                                            int64_t row_offset, const OptT& eps, const OptT& u) {
+                                            int64_t row_offset, const OptT& eps, const OptT& u, const OptT& mask, const OptT& ids) {
     efe_ctx* c = CTX(h);
     Tensor s = in(s_, "starting_s"), ek, uk;
     const int E = rows(s, 10, "starting_s");
@@ -177,8 +199,10 @@ std::tuple<Tensor, Tensor, Tensor> simulate(int64_t h, const Tensor& s_, int64_t
     const int A = geo(c).A;
     Tensor G = at::empty({E}, op), pi0 = at::empty({E, depth, A}, op), q0 = at::empty({E, A}, op);
     efe_noise nz = noise(seed, stage, 0, 0, row_offset);
-    ok(c, efe_simulate(c, s.data_ptr<float>(), E, (int)depth, use_means ? 1 : 0, &nz, optp(eps, ek, "eps", (int64_t)4 * depth * E * 10),
-                       optp(u, uk, "u", depth * E), G.data_ptr<float>(), pi0.data_ptr<float>(), q0.data_ptr<float>(), stream_of(s)));
+    RowsArg ra;
+    rows_arg(ra, mask, ids, 1, E);
+    ok(c, efe_simulate_rows(c, s.data_ptr<float>(), E, (int)depth, use_means ? 1 : 0, &nz, optp(eps, ek, "eps", (int64_t)4 * depth * E * 10),
+                       optp(u, uk, "u", depth * E), ra.ptr, G.data_ptr<float>(), pi0.data_ptr<float>(), q0.data_ptr<float>(), stream_of(s)));
     return {G, pi0, q0};
 }
 
@@ -225,10 +249,10 @@ TORCH_LIBRARY(efe, m) {
     m.def("decoder(int ctx, Tensor s, int seed, int stage, int pass_id, int sample, int row_offset) -> Tensor");
     m.def("encoder(int ctx, Tensor o, int seed, int stage, int pass_id, int sample, int row_offset, Tensor? eps, bool want_s) -> (Tensor s, Tensor mean, Tensor logvar)");
     m.def("habit(int ctx, Tensor s) -> (Tensor logits, Tensor q, Tensor logq)");
-    m.def("calculate_g(int ctx, Tensor s0, Tensor pi0, int samples, bool mean_mode, int seed, int stage, int row_offset, Tensor? eps) -> (Tensor G, Tensor terms, Tensor ps1, Tensor ps1_mean, Tensor po1, Tensor t2parts)");
+    m.def("calculate_g(int ctx, Tensor s0, Tensor pi0, int samples, bool mean_mode, int seed, int stage, int row_offset, Tensor? eps, Tensor? mask=None, Tensor? ids=None, int rows_per_entry=1) -> (Tensor G, Tensor terms, Tensor ps1, Tensor ps1_mean, Tensor po1, Tensor t2parts)");
     m.def("rollout(int ctx, Tensor o, Tensor pi, int steps, int samples, bool calc_mean, bool per_stage_mean, int seed, int stage, int row_offset, Tensor? eps) -> (Tensor sum_G, Tensor sum_terms, Tensor po1)");
     m.def("trajectory(int ctx, Tensor s0_traj, Tensor ps1_traj, Tensor ps1_mean_traj, Tensor ps1_logvar_traj, Tensor pi0_traj, int seed, int stage, int row_offset, Tensor? eps) -> Tensor");
-    m.def("simulate(int ctx, Tensor starting_s, int depth, bool use_means, int seed, int stage, int row_offset, Tensor? eps, Tensor? u) -> (Tensor G, Tensor pi0, Tensor Qpi0)");
+    m.def("simulate(int ctx, Tensor starting_s, int depth, bool use_means, int seed, int stage, int row_offset, Tensor? eps, Tensor? u, Tensor? mask=None, Tensor? ids=None) -> (Tensor G, Tensor pi0, Tensor Qpi0)");
     m.def("action_posterior(int ctx, Tensor sum_G, int n, float temperature) -> (Tensor P, Tensor logP)");
     m.def("check_reward(int ctx, Tensor o) -> Tensor");
     m.def("reparameterize(int ctx, Tensor mean, Tensor logvar, int seed, int stage, int pass_id, int sample, int row_offset, Tensor? eps) -> Tensor");

@@ -229,7 +229,10 @@ class BatchedMCTS:
         # (a weak reference: planner objects are cached ON the model, a strong one would make a cycle and defer the engine context's
         # release to the garbage collector)
         self._model_ref = weakref.ref(model)
-        self.E, self.p = int(n_episodes), params
+        import copy
+        # (a private copy: planners are cached by the VALUE of the parameters, a caller that later mutates its object must not change a
+        # cached planner whose buffers were sized for the old values)
+        self.E, self.p = int(n_episodes), copy.copy(params)
         self.pi_dim = A = model.pi_dim
         self.ep0 = int(episode_offset)
         self.cap = cap = 1 + A * (params.repeats + 2)
@@ -271,6 +274,10 @@ class BatchedMCTS:
         self.root_nodes = torch.zeros(E, dtype=torch.int32, device=dev)
         self.plan_stream = None
         self._graph, self._graph_key = None, None
+        # expansion / simulation results of a COMPACTED call (only the live episodes, efe_rows.ids) are scattered into these full-size rows
+        self.G_full = torch.zeros(E * A, device=dev)
+        self.ps_full = torch.zeros(E * A, model.s_dim, device=dev)
+        self._ids = None                    # (int32 device tensor of live episode indices, the same as a host list, int64 copy for torch indexing)
         # The simulation of an iteration (habit rollout from the leaf + G over its trajectory: ~1 ms of small launches) is
         # independent of the expansion of the same leaf (~6 ms of large ones): with more than a few episodes it runs on a second
         # stream through a replica context, so its launch-bound chain hides under the expansion's MFMA-bound kernels.
@@ -294,17 +301,61 @@ class BatchedMCTS:
         import ctypes as C
         return C.c_void_p(t.data_ptr())
 
-    def _expand(self, nodes, mask, states_rep, stage=None, eps_stage=None):
+    def _rows(self, mask, rows_per_entry):
+        """the row set of an engine call of this iteration: the liveness mask (early-stopped / habit-decided episodes are skipped on the
+        device) and, once episodes have been lost, only the live ones as a dense batch (self._ids, refreshed by _compact)"""
+        from .model import Rows
+        if mask is None and self._ids is None:
+            return None
+        ids, ids_host = (self._ids[0], self._ids[1]) if self._ids is not None else (None, None)
+        return Rows(mask=mask, ids=ids, rows_per_entry=rows_per_entry, ids_host=ids_host)
+
+    def _compact(self, n_live):
+        """gather the live episodes into a dense batch for the following iterations (called where the host has just read the active count:
+        no extra synchronisation).  Worth it from ~8 % lost episodes: the dense layers, which cannot skip single rows, shrink too."""
+        cur = self.E if self._ids is None else len(self._ids[1])
+        if n_live <= 0 or n_live > 0.92 * cur:
+            return
+        idx = torch.nonzero(self.active).flatten()
+        self._ids = (idx.to(torch.int32).contiguous(), idx.cpu().tolist(), idx)
+
+    def _expand(self, nodes, mask, states_rep, stage=None, eps_stage=None, use_mask=True):
         """ONE engine call over E x pi_dim rows (Node.expand, mcts.py:64-86); tree bookkeeping only where mask[e]"""
-        m, p_ = self.model, self._p
-        ro = self.ep0 * self.pi_dim
+        m, p_, A = self.model, self._p, self.pi_dim
+        ro = self.ep0 * A
+        rows = self._rows(mask if use_mask else None, A)
+        pi_hot = self.pi_hot
+        if self._ids is not None:
+            idx = self._ids[2]
+            states_rep = states_rep.view(self.E, A, -1).index_select(0, idx).reshape(idx.numel() * A, -1)
+            pi_hot = self.pi_hot[:idx.numel() * A]
         if self.p.use_means:
-            G, _, ps_next, _ = m.calculate_G_mean(states_rep, self.pi_hot, row_offset=ro, stage=stage, eps_stage=eps_stage)
+            G, _, ps_next, _ = m.calculate_G_mean(states_rep, pi_hot, row_offset=ro, stage=stage, eps_stage=eps_stage, rows=rows)
         else:
-            G, _, ps_next, _, _ = m.calculate_G(states_rep, self.pi_hot, samples=getattr(self.p, 'samples', 1), row_offset=ro, stage=stage,
-                                                eps_stage=eps_stage)
+            G, _, ps_next, _, _ = m.calculate_G(states_rep, pi_hot, samples=getattr(self.p, 'samples', 1), row_offset=ro, stage=stage,
+                                                eps_stage=eps_stage, rows=rows)
+        if self._ids is not None:
+            idx = self._ids[2]
+            self.G_full.view(self.E, A).index_copy_(0, idx, G.view(-1, A))
+            self.ps_full.view(self.E, A, -1).index_copy_(0, idx, ps_next.view(idx.numel(), A, -1))
+            G, ps_next = self.G_full, self.ps_full
         G, ps_next = G.contiguous(), ps_next.contiguous()
         self._call(m._engine.lib.efe_mcts_expand, p_(self.n_nodes), p_(nodes), p_(mask), p_(G), p_(ps_next))
+
+    def _simulate(self, model, mask, stage_of, eps_stage_of=lambda r: None):
+        """the iteration's simulations from the selected leaves (mcts.py:186-189) -> self.sims, self.q0"""
+        p = self.p
+        rows = self._rows(mask, 1)
+        leaf_s = self.leaf_s if self._ids is None else self.leaf_s.index_select(0, self._ids[2])
+        for r in range(p.simulation_repeats):
+            G, _, q0 = model.simulate_batch(leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0, stage=stage_of(r),
+                                            eps_stage=eps_stage_of(r), rows=rows)
+            if self._ids is None:
+                self.sims[r].copy_(G)
+                self.q0.copy_(q0)
+            else:
+                self.sims[r].index_copy_(0, self._ids[2], G)
+                self.q0.index_copy_(0, self._ids[2], q0)
 
     def action_selection(self, e, N=None, child=None):
         N = self.N.cpu().numpy() if N is None else np.asarray(N)
@@ -333,9 +384,6 @@ class BatchedMCTS:
             return self._run(frames, o_shape)
         finally:
             torch.set_num_threads(prev)
-            self.model.set_row_mask(None)
-            if self.overlap:
-                self.sim_model.set_row_mask(None)
 
     def _run(self, frames, o_shape):
         m, E, p, A, p_ = self.model, self.E, self.p, self.pi_dim, self._p
@@ -352,17 +400,25 @@ class BatchedMCTS:
                 if calc_threshold(q_cpu[e], axis=0) > p.threshold:
                     res[e] = ([int(torch.multinomial(q_cpu[e], 1))], 0, 0, [], [])
                     active_h[e] = False
+        # noise stages in the reference's call order (the root expansion takes one stage, then per iteration the expansion one and each
+        # simulation one), reserved up front and indexed by the iteration: what a later call draws does not depend on E, on which episodes
+        # share this planner / rank, or on when the loop ended -- also when every episode is decided by the habit shortcut below
+        per_it = 1 + p.simulation_repeats
+        st_root = m._take_stage(None, 1)
+        st0 = m._take_stage(None, p.repeats * per_it)
         if not bool(active_h.any()):        # every episode was decided by the habit shortcut (mcts.py:166-169): nothing to plan
             return res
         self.active.copy_(active_h.to(torch.uint8))
         active = self.active
-        # early-stopped (and habit-decided) episodes stop costing flops: the engine's per-image kernels read `active` on the device
-        # and skip their rows (efe_set_row_mask; efe_mcts_stop clears entries as the loop runs, no host round trip involved)
-        if getattr(p, 'skip_stopped', True):
-            m.set_row_mask(active, A)
-            if self.overlap:
-                self.sim_model.set_row_mask(active, 1)
-        self._expand(self.root_nodes, active, self.S[:, 0].repeat_interleave(A, dim=0).contiguous())
+        # early-stopped (and habit-decided) episodes stop costing flops: every engine call of the loop carries `active` as its row mask
+        # (efe_rows.mask: the per-image kernels read it on the device and skip dead rows; efe_mcts_stop clears entries as the loop runs, no
+        # host round trip involved), and where the host learns the active count anyway the live episodes are compacted into a dense batch
+        skip = bool(getattr(p, 'skip_stopped', True))
+        compact = skip and bool(getattr(p, 'compact_stopped', True)) and not bool(getattr(p, 'use_graph', False))      # (a captured iteration has fixed launch sizes)
+        self._ids = None
+        if compact and not bool(active_h.all()):
+            self._compact(int(active_h.sum()))
+        self._expand(self.root_nodes, active, self.S[:, 0].repeat_interleave(A, dim=0).contiguous(), stage=st_root, use_mask=skip)
         n_iter = 0
         # The per-episode early stop (mcts.py:176) is applied on the device every iteration (stopped episodes are masked out of
         # every tree update); the host only needs to know when ALL episodes have stopped, to end the loop early.  It looks at
@@ -370,17 +426,17 @@ class BatchedMCTS:
         # threshold cannot be exceeded (max - mean of a distribution over A actions is below 1 - 1/A).
         CHECK = 8
         can_stop = float(p.threshold) < 1.0 - 1.0 / A
-        # noise stages in the reference's call order (the expansion of an iteration takes one stage, then each simulation one),
-        # reserved up front and indexed by the iteration: what a later call draws does not depend on E or on when the loop ended
-        per_it = 1 + p.simulation_repeats
-        st0 = m._take_stage(None, p.repeats * per_it)
         use_graph = bool(getattr(p, 'use_graph', False))
         if use_graph and p.repeats > 0:
             n_iter = self._loop_graph(st0, per_it, can_stop, CHECK)
         for repeat in range(0 if not use_graph else p.repeats, p.repeats):
             self._call(lib.efe_mcts_stop, p_(active), p_(self.stop_at), repeat, float(p.threshold), p_(self.n_active))
-            if can_stop and (repeat % CHECK == 0 or E == 1) and int(self.n_active.item()) == 0:
-                break
+            if can_stop and (repeat % CHECK == 0 or E == 1):
+                n_live = int(self.n_active.item())
+                if n_live == 0:
+                    break
+                if compact:
+                    self._compact(n_live)
             self._call(lib.efe_mcts_select, p_(active), float(p.C), 1 if p.using_prior_for_exploration else 0, self.max_depth,
                        p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))
             st_exp = st0 + repeat * per_it
@@ -389,20 +445,13 @@ class BatchedMCTS:
                 self.ev_sel.record(cur)
                 with torch.cuda.stream(self.sim_stream):
                     self.sim_stream.wait_event(self.ev_sel)              # leaf_s is ready; the previous back-propagation has read sims / q0
-                    for r in range(p.simulation_repeats):
-                        G, _, q0 = self.sim_model.simulate_batch(self.leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0,
-                                                                 stage=st_exp + 1 + r)
-                        self.sims[r].copy_(G)
-                        self.q0.copy_(q0)
+                    self._simulate(self.sim_model, active if skip else None, lambda r: st_exp + 1 + r)
                     self.ev_sim.record(self.sim_stream)
-                self._expand(self.leaf, active, self.leaf_rep, stage=st_exp)
+                self._expand(self.leaf, active, self.leaf_rep, stage=st_exp, use_mask=skip)
                 cur.wait_event(self.ev_sim)
             else:
-                self._expand(self.leaf, active, self.leaf_rep, stage=st_exp)
-                for r in range(p.simulation_repeats):
-                    G, _, q0 = m.simulate_batch(self.leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0, stage=st_exp + 1 + r)
-                    self.sims[r].copy_(G)
-                    self.q0.copy_(q0)
+                self._expand(self.leaf, active, self.leaf_rep, stage=st_exp, use_mask=skip)
+                self._simulate(m, active if skip else None, lambda r: st_exp + 1 + r)
             self._call(lib.efe_mcts_backprop, p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(active),
                        p_(self.sims), int(p.simulation_repeats), p_(self.q0), self.max_depth, p_(self.H_g[repeat]), p_(self.H_active[repeat]))
             n_iter += 1
@@ -460,11 +509,11 @@ class BatchedMCTS:
                    p_(self.path_nodes), p_(self.cur_act), p_(self.cur_len), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))
         es = (lambda k: None) if eps_stage is None else (lambda k: eps_stage + k)
 
+        skip = bool(getattr(p, 'skip_stopped', True))
+        mask = self.active if skip else None
+
         def simulate(model):
-            for r in range(p.simulation_repeats):
-                G, _, q0 = model.simulate_batch(self.leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0, stage=1 + r, eps_stage=es(1 + r))
-                self.sims[r].copy_(G)
-                self.q0.copy_(q0)
+            self._simulate(model, mask, lambda r: 1 + r, lambda r: es(1 + r))
         if self.overlap:
             cur = torch.cuda.current_stream(m.device)
             self.ev_sel.record(cur)
@@ -472,14 +521,14 @@ class BatchedMCTS:
                 self.sim_stream.wait_event(self.ev_sel)
                 simulate(self.sim_model)
                 self.ev_sim.record(self.sim_stream)
-            self._expand(self.leaf, self.active, self.leaf_rep, stage=0, eps_stage=es(0))
+            self._expand(self.leaf, self.active, self.leaf_rep, stage=0, eps_stage=es(0), use_mask=skip)
             cur.wait_event(self.ev_sim)
         else:
-            self._expand(self.leaf, self.active, self.leaf_rep, stage=0, eps_stage=es(0))
+            self._expand(self.leaf, self.active, self.leaf_rep, stage=0, eps_stage=es(0), use_mask=skip)
             simulate(m)
         self._call(lib.efe_mcts_backprop, p_(self.path_nodes), p_(self.cur_act), p_(self.cur_len), p_(self.leaf), p_(self.active),
                    p_(self.sims), int(p.simulation_repeats), p_(self.q0), self.max_depth, p_(self.cur_g), p_(self.cur_active))
-        e.check(lib.efe_mcts_record(e.ctx, p_(self.it), self.E, self.max_depth, p_(self.cur_act), p_(self.cur_len), p_(self.cur_g),
+        e.check(lib.efe_mcts_record(e.ctx, p_(self.it), int(self.H_g.shape[0]), self.E, self.max_depth, p_(self.cur_act), p_(self.cur_len), p_(self.cur_g),
                                     p_(self.cur_active), p_(self.H_act), p_(self.H_len), p_(self.H_g), p_(self.H_active), e.stream()))
         e.check(lib.efe_counter_add(e.ctx, p_(self.it), 1, e.stream()))
         e.check(lib.efe_counter_add(e.ctx, p_(self.stg), 1 + p.simulation_repeats, e.stream()))
@@ -504,7 +553,13 @@ class BatchedMCTS:
                     mm.set_stage_counter(self.stg, 1)
                 self._body(eps_stage=st0 if injected else None)
                 n_iter = 1
-                key = (getattr(m, '_weights_version', 0),) + tuple(tuple(sorted(mm.arena_stats().items())) for mm in models)
+                # everything a captured launch bakes in: weights (buffer addresses), scratch layout, the Philox key words and row offset
+                # (kernel arguments), every engine option (launch paths), the mask setting
+                key = (getattr(m, '_weights_version', 0), int(m.seed), int(m.row_offset), tuple(sorted(getattr(m, '_opts', {}).items())),
+                       bool(getattr(p, 'skip_stopped', True))) + tuple(tuple(sorted(mm.arena_stats().items())) for mm in models)
+                if not injected and any(getattr(mm, '_prof_on', False) for mm in models):
+                    raise RuntimeError('MCTS_Params.use_graph: disable profiling (prof_enable(False)) before planning with a captured '
+                                       'iteration -- HIP events recorded inside a capture can never be read')
                 if not injected and (self._graph is None or self._graph_key != key):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=self.plan_stream):

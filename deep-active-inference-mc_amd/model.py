@@ -225,6 +225,28 @@ class ModelDown(_Module):
         return e.ops.decoder(e.h, s, m._seed64(), nz.stage, pass_, sample, nz.row_offset)
 
 
+class Rows:
+    """The row set of ONE calculate_G / calculate_G_mean / simulate_batch call (efe_rows, include/efe_engine.h): the rows of the call are
+    entries of `rows_per_entry` consecutive rows (the pi_dim action rows of an episode; simulate_batch: one episode = one entry).
+      mask : uint8 device tensor indexed by entry ID, read when the kernels run -- dead entries are skipped, their outputs unspecified
+      ids  : int32 device tensor, entry slot -> entry ID: a COMPACTED call (only the live episodes) that still draws the noise of the
+             episodes it holds; `ids_host` (the same indices as a host sequence) is needed only with injected noise (eps_source)."""
+
+    def __init__(self, mask=None, ids=None, rows_per_entry=1, ids_host=None):
+        for t, dt, nm in ((mask, torch.uint8, 'mask'), (ids, torch.int32, 'ids')):
+            if t is not None and (t.dtype != dt or not t.is_cuda or not t.is_contiguous()):
+                raise ValueError(f'Rows.{nm}: a contiguous {dt} tensor on the model device is required')
+        self.mask, self.ids, self.rows_per_entry = mask, ids, int(rows_per_entry)
+        self.ids_host = None if ids_host is None else [int(i) for i in ids_host]
+
+    def host_rows(self, div):
+        """global-within-rank row index of every row of the call, for injected noise"""
+        if self.ids is None:
+            return None
+        ids = self.ids_host if self.ids_host is not None else self.ids.cpu().tolist()
+        return np.array([i * div + k for i in ids for k in range(div)], dtype=np.int64)
+
+
 class ActiveInferenceModel:
     """Drop-in for the reference class on the EFE hot path.  Extra keyword-only arguments
     (`device`, `seed`, `row_offset`) configure the engine; everything else follows torchmodel.py:150."""
@@ -323,6 +345,8 @@ class ActiveInferenceModel:
                                  row_offset=self.row_offset, init_weights=False)
         r.load_state_dicts(self.model_top._sd, self.model_mid._sd, self.model_down._sd)
         r.eps_source, r.u_source = self.eps_source, self.u_source
+        for name, value in getattr(self, '_opts', {}).items():        # engine options are per context: the replica computes what this model computes
+            r.set_option(name, value)
         return r
 
     def cached_replica(self):
@@ -335,6 +359,10 @@ class ActiveInferenceModel:
             self._replica, self._replica_version = r, ver
         r.seed, r.row_offset = self.seed, self.row_offset
         r.eps_source, r.u_source = self.eps_source, self.u_source
+        mine, theirs = getattr(self, '_opts', {}), getattr(r, '_opts', {})
+        for name, value in mine.items():
+            if theirs.get(name) != value:
+                r.set_option(name, value)
         return r
 
     def reserve(self, rows, steps, samples):
@@ -345,7 +373,8 @@ class ActiveInferenceModel:
         return need
 
     def set_row_mask(self, mask, rows_per_entry=1):
-        """Liveness mask for the following calculate_G / simulate_batch calls (efe_set_row_mask): `mask` is a uint8 tensor on this
+        """DEPRECATED (context state: every following call on this model sees the mask) -- pass rows=Rows(mask=...) to the call instead.
+        Liveness mask for the following calculate_G / simulate_batch calls (efe_set_row_mask): `mask` is a uint8 tensor on this
         device, one byte per entry, read when the kernels run; calculate_G row r belongs to entry r // rows_per_entry,
         simulate_batch episode e to entry e.  Dead rows are skipped by the decoder / encoder kernels and return unspecified
         values; live rows are bit-identical to an unmasked call.  None clears the mask.  The caller keeps `mask` alive."""
@@ -387,6 +416,11 @@ class ActiveInferenceModel:
         e = self._engine
         e.check(e.lib.efe_set_option(e.ctx, name.encode(), int(value)))
         self._opts = dict(getattr(self, '_opts', {}), **{name: int(value)})
+        r = getattr(self, '_replica', None)
+        if r is not None:                   # the planner's simulation context follows (one tree must not mix two reward definitions)
+            r.set_option(name, value)
+        for planner in getattr(self, '_planners', {}).values():        # captured iteration graphs bake the option's launch paths in
+            planner._graph = None
 
     def save_weights(self, folder_chp):
         """torchmodel.py:167-171"""
@@ -480,8 +514,8 @@ class ActiveInferenceModel:
         _, Qpi, _ = self.model_top.encode_s(qs_mean)
         return Qpi
 
-    def calculate_G(self, s0, pi0, samples=10, *, stage=None, eps=None, row_offset=None, _mean_mode=False, _parts=None, eps_stage=None):
-        """torchmodel.py:270-300 -> (G, [term0, term1, term2], ps1, ps1_mean, po1)"""
+    def calculate_G(self, s0, pi0, samples=10, *, stage=None, eps=None, row_offset=None, _mean_mode=False, _parts=None, eps_stage=None, rows=None):
+        """torchmodel.py:270-300 -> (G, [term0, term1, term2], ps1, ps1_mean, po1); rows: optional Rows (liveness mask / compacted batch)"""
         e = self._ready()
         s0 = e.tensor(s0, (-1, self.s_dim)); pi0 = e.tensor(pi0, (-1, self.pi_dim))
         M = s0.shape[0]
@@ -490,19 +524,25 @@ class ActiveInferenceModel:
         if S < 1:
             raise RuntimeError('efe engine: samples must be >= 1')
         if eps is None and self.eps_source is not None:       # (eps_stage: the stage the injected normals belong to when a device-side
-            eps = self._src_eps_calcG(M, S, nz.stage if eps_stage is None else int(eps_stage), row_offset)      # stage counter supplies part of it)
+            src_stage = nz.stage if eps_stage is None else int(eps_stage)                                       # stage counter supplies part of it)
+            hr = rows.host_rows(rows.rows_per_entry) if rows is not None else None
+            if hr is None:
+                eps = self._src_eps_calcG(M, S, src_stage, row_offset)
+            else:                                               # a compacted call: the normals of the rows it holds
+                eps = self._src_eps_calcG(int(hr.max()) + 1, S, src_stage, row_offset)[:, hr]
         eps_t = e.tensor(eps, (3 * S, M, 10)) if eps is not None else None
+        rm, ri, rpe = (rows.mask, rows.ids, rows.rows_per_entry) if rows is not None else (None, None, 1)
         G, terms, ps1, ps1_mean, po1, parts = e.ops.calculate_g(e.h, s0, pi0, S, bool(_mean_mode), self._seed64(), nz.stage,
-                                                                nz.row_offset, eps_t)
+                                                                nz.row_offset, eps_t, rm, ri, rpe)
         if _parts is not None:
             _parts.append(parts)
         if _mean_mode:
             return G, [terms[0], terms[1], terms[2]], ps1_mean, po1
         return G, [terms[0], terms[1], terms[2]], ps1, ps1_mean, po1
 
-    def calculate_G_mean(self, s0, pi0, *, stage=None, eps=None, row_offset=None, _parts=None, eps_stage=None):
+    def calculate_G_mean(self, s0, pi0, *, stage=None, eps=None, row_offset=None, _parts=None, eps_stage=None, rows=None):
         """torchmodel.py:302-327 -> (G, terms, ps1_mean, po1)"""
-        return self.calculate_G(s0, pi0, 1, stage=stage, eps=eps, row_offset=row_offset, _mean_mode=True, _parts=_parts, eps_stage=eps_stage)
+        return self.calculate_G(s0, pi0, 1, stage=stage, eps=eps, row_offset=row_offset, _mean_mode=True, _parts=_parts, eps_stage=eps_stage, rows=rows)
 
     def _rollout(self, o, pi, steps, calc_mean, samples, per_stage_mean, stage, eps, row_offset):
         e = self._ready()
@@ -553,27 +593,37 @@ class ActiveInferenceModel:
         eps_t = e.tensor(eps, (3, T, 10)) if eps is not None else None
         return e.ops.trajectory(e.h, s0, ps1, mean, lv, pi0, self._seed64(), nz.stage, nz.row_offset, eps_t)
 
-    def simulate_batch(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None, eps=None, u=None, eps_stage=None):
+    def simulate_batch(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None, eps=None, u=None, eps_stage=None, rows=None):
         """mcts_step_simulate for E lock-step episodes -> (G[E], pi0[E,depth,4], Qpi0[E,4]).
         eps: optional injected normals, flat [depth*E*10 (step transitions)] + [3*E*depth*10 (trajectory T1/T2/D2B)];
-        u: optional injected action uniforms [depth, E]."""
+        u: optional injected action uniforms [depth, E]; rows: optional Rows (entry = episode)."""
         e = self._ready()
         s = e.tensor(starting_s, (-1, 10))
         E, T = s.shape[0], int(depth)
         nz = self._noise(stage, 0, 0, row_offset)
         ro = self.row_offset if row_offset is None else int(row_offset)
         src_stage = nz.stage if eps_stage is None else int(eps_stage)
+        he = rows.host_rows(1) if rows is not None else None          # a compacted call: the episodes it holds
         if eps is None and self.eps_source is not None:
-            parts = [self._src_eps(E, 10, PASS_SIM, t, src_stage, ro).reshape(-1) for t in range(T)]
-            parts.append(self._src_eps_calcG(E * T, 1, src_stage, ro * T).reshape(-1))
+            if he is None:
+                parts = [self._src_eps(E, 10, PASS_SIM, t, src_stage, ro).reshape(-1) for t in range(T)]
+                parts.append(self._src_eps_calcG(E * T, 1, src_stage, ro * T).reshape(-1))
+            else:
+                n, ht = int(he.max()) + 1, (he[:, None] * T + np.arange(T)[None]).reshape(-1)
+                parts = [self._src_eps(n, 10, PASS_SIM, t, src_stage, ro)[he].reshape(-1) for t in range(T)]
+                parts.append(self._src_eps_calcG(n * T, 1, src_stage, ro * T)[:, ht].reshape(-1))
             eps = np.concatenate(parts)
         if u is None and self.u_source is not None:
-            u = np.stack([np.asarray(self.u_source(self.seed, E, PASS_HABIT, t, src_stage, ro), dtype=np.float32) for t in range(T)], 0)
+            n = E if he is None else int(he.max()) + 1
+            u = np.stack([np.asarray(self.u_source(self.seed, n, PASS_HABIT, t, src_stage, ro), dtype=np.float32) for t in range(T)], 0)
+            if he is not None:
+                u = u[:, he]
         eps_t = e.tensor(eps).reshape(-1) if eps is not None else None
         if eps_t is not None and eps_t.numel() != 4 * T * E * 10:
             raise ValueError(f'eps has {eps_t.numel()} elements, efe_simulate expects depth*E*10 + 3*E*depth*10 = {4 * T * E * 10}')
         u_t = e.tensor(u, (T, E)) if u is not None else None
-        return e.ops.simulate(e.h, s, T, bool(use_means), self._seed64(), nz.stage, nz.row_offset, eps_t, u_t)
+        rm, ri = (rows.mask, rows.ids) if rows is not None else (None, None)
+        return e.ops.simulate(e.h, s, T, bool(use_means), self._seed64(), nz.stage, nz.row_offset, eps_t, u_t, rm, ri)
 
     def mcts_step_simulate(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None, eps=None, u=None):
         """torchmodel.py:354-393 -> (float G, pi0[depth,4], Qpi[4])"""
@@ -595,7 +645,7 @@ class ActiveInferenceModel:
         names = {'dec_dense_16384': 'k_fc4 (Linear 256 -> 64 base^2)', 'convT1_generic': 'k_convt_p<1> (ConvT 64->64 s1)',
                  'dec_a_convT1_convT2': 'k_convt_p<2> (ConvT 64->64 s2)', 'dec_b_convT3_final_reduce': 'k_convt_p<2> (ConvT 64->32 s2)',
                  'final_layer_generic': 'k_final_g (ConvT 32->C + sigmoid + reductions)', 'encoder': 'encoder (k_conv_e layers 1-2, k_conv_g layers 3-4, dense head)',
-                 'transition_mlp': 'k_trans_fused', 'dec_dense_small': 'decoder head (3 x k_dense)'}
+                 'transition_mlp': 'k_trans_fused', 'dec_dense_small': 'k_head (decoder head 10 -> 256 -> 256 -> 256, one launch)'}
         if getattr(self, '_opts', {}).get('fuse_final_g', 1) and self.resolution != 32:
             names['dec_b_convT3_final_reduce'] = 'k_dec_bg (ConvT 64->32 s2 + ReLU + ConvT 32->C + sigmoid + per-image sums, fused)'
             del names['final_layer_generic']
@@ -609,6 +659,7 @@ class ActiveInferenceModel:
         if on:
             mask = -1 if classes is None else sum(1 << self.PROF_CLASSES.index(c) for c in classes)
         e.check(e.lib.efe_prof_enable(e.ctx, mask))
+        self._prof_on = bool(mask)
 
     def prof_read(self):
         """-> {class name: (milliseconds, launches)} since the last read (synchronises)."""

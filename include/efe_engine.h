@@ -81,13 +81,23 @@ int efe_reserve(efe_ctx* ctx, int64_t bytes);
 int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples);
 int efe_arena_stats(efe_ctx* ctx, int64_t* capacity_bytes, int64_t* high_water_bytes, int64_t* grow_count);
 
-/* Liveness mask of the logical rows of the following efe_calculate_g / efe_simulate calls on this context -- the lock-step planner's
- * early-stopped episodes (the per-episode break of /root/reference/src/mcts.py:176).  `mask` is a DEVICE array, one byte per entry,
- * read when the kernels run (earlier work on the same stream may update it): efe_calculate_g row r belongs to entry
- * r / rows_per_entry, efe_simulate episode e to entry e.  The per-image kernels (decoder stages, encoder trunk: ~90 % of the work)
- * skip dead rows, whose outputs are then unspecified; live rows are bit-identical to an unmasked call.  NULL clears the mask; the
- * other entry points ignore it. */
-int efe_set_row_mask(efe_ctx* ctx, const uint8_t* mask, int rows_per_entry);
+/* The row set of ONE efe_calculate_g_rows / efe_simulate_rows call (ABI 4) -- the lock-step planner's early-stopped episodes (the
+ * per-episode break of /root/reference/src/mcts.py:176).  The rows of a call are grouped into ENTRIES of rows_per_entry consecutive rows
+ * (efe_calculate_g_rows: the pi_dim action rows of an episode; efe_simulate_rows: one episode = one entry, rows_per_entry ignored).
+ *   mask : DEVICE array, one byte per entry ID, read when the kernels run (earlier work on the same stream may update it); the per-image
+ *          kernels (decoder stages, encoder trunk: ~90 % of the work) skip dead entries, whose outputs are then unspecified; live rows
+ *          are bit-identical to an unmasked call.  NULL = all live.
+ *   ids  : DEVICE array, entry slot -> entry ID: the call's entry i IS entry ids[i] of the un-compacted batch -- its noise keys are those of
+ *          rows ids[i] * rows_per_entry + k (plus efe_noise.row_offset) and the mask is read at ids[i].  A planner that has lost episodes
+ *          passes only the live ones (a dense, smaller call) and still draws exactly what the full batch would.  NULL = identity.
+ * A NULL efe_rows* means "all rows, identity" -- except that a mask installed with the DEPRECATED efe_set_row_mask (context state: every
+ * efe_calculate_g / efe_simulate on the context sees it until cleared; kept as a shim for ABI 3 callers) then applies. */
+typedef struct efe_rows {
+    const uint8_t* mask;
+    const int32_t* ids;
+    int32_t rows_per_entry;
+} efe_rows;
+int efe_set_row_mask(efe_ctx* ctx, const uint8_t* mask, int rows_per_entry);      /* deprecated: pass efe_rows to the _rows entry points */
 
 typedef struct efe_noise {
     uint64_t seed;
@@ -125,6 +135,11 @@ int efe_reparameterize(efe_ctx*, const float* mean, const float* logvar, int M, 
 int efe_calculate_g(efe_ctx*, const float* s0, const float* pi0, int M, int samples, int mean_mode,
                     const efe_noise* nz, const float* eps,
                     float* G, float* terms, float* ps1, float* ps1_mean, float* po1, float* t2parts, void* stream);
+/* the same over the row set `rows` (Node.expand of the lock-step planner, /root/reference/src/mcts.py:64-86 for every live episode at
+ * once): M rows = M / rows_per_entry entries; inputs, eps and outputs are in the call's (compact) row order.  rows == NULL: as above. */
+int efe_calculate_g_rows(efe_ctx*, const float* s0, const float* pi0, int M, int samples, int mean_mode,
+                         const efe_noise* nz, const float* eps, const efe_rows* rows,
+                         float* G, float* terms, float* ps1, float* ps1_mean, float* po1, float* t2parts, void* stream);
 
 /* calculate_G_repeated (torchmodel.py:227-245) when per_stage_mean == 0;
  * calculate_G_4_repeated (torchmodel.py:247-268) semantics when per_stage_mean == 1 (calc_mean then
@@ -149,6 +164,9 @@ int efe_trajectory(efe_ctx*, const float* s0_traj, const float* ps1_traj, const 
  * outputs: G_mean[E], pi0[E,depth,4] one-hot, Qpi0[E,4] (habit posterior of the first step). */
 int efe_simulate(efe_ctx*, const float* starting_s, int E, int depth, int use_means, const efe_noise* nz,
                  const float* eps, const float* u, float* G_mean, float* pi0, float* Qpi0, void* stream);
+/* the same over the row set `rows` (entry = episode): episode slot e draws the noise of episode ids[e]; rows == NULL: as above. */
+int efe_simulate_rows(efe_ctx*, const float* starting_s, int E, int depth, int use_means, const efe_noise* nz,
+                      const float* eps, const float* u, const efe_rows* rows, float* G_mean, float* pi0, float* Qpi0, void* stream);
 
 /* softmax_multi_with_log(-sum_G, n) (/root/reference/src/util.py:46-53,68): action posterior. */
 int efe_action_posterior(efe_ctx*, const float* sum_G /*[n_groups*n]*/, int n_groups, int n, float temperature,
@@ -207,8 +225,9 @@ int efe_mcts_stop(efe_ctx*, const efe_mcts_tree* tree, uint8_t* active, int32_t*
 int efe_set_stage_counter(efe_ctx* ctx, const uint32_t* counter_dev, uint32_t mul);
 int efe_mcts_stop_dev(efe_ctx*, const efe_mcts_tree* tree, uint8_t* active, int32_t* stop_at, const int32_t* repeat_dev, float threshold,
                       int32_t* n_active, void* stream);
-int efe_mcts_record(efe_ctx*, const int32_t* iter_dev, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len, const float* cur_g,
-                    const uint8_t* cur_active, int32_t* H_act, int32_t* H_len, float* H_g, uint8_t* H_active, void* stream);
+int efe_mcts_record(efe_ctx*, const int32_t* iter_dev, int n_rows /* rows of H_*: an index beyond them is dropped */, int E, int max_depth,
+                    const int32_t* cur_act, const int32_t* cur_len, const float* cur_g, const uint8_t* cur_active, int32_t* H_act, int32_t* H_len,
+                    float* H_g, uint8_t* H_active, void* stream);
 int efe_counter_add(efe_ctx*, int32_t* counter_dev, int delta, void* stream);
 
 /* introspection for benches: algorithmic MACs of the last EFE-level call. */

@@ -45,7 +45,7 @@ static int conv(efe_ctx* ctx, const char* name, int d0, int d1, int nbias, float
 
 int main(void) {
     efe_ctx* ctx = NULL;
-    if (efe_abi_version() != 3) { fprintf(stderr, "abi version\n"); return 1; }
+    if (efe_abi_version() != 4) { fprintf(stderr, "abi version\n"); return 1; }
     if (efe_create(&ctx, 0)) { fprintf(stderr, "efe_create failed (no HIP device?)\n"); return 2; }
     CHECK(lin(ctx, "top.qpi_net.0", 128, 10)); CHECK(lin(ctx, "top.qpi_net.2", 128, 128)); CHECK(lin(ctx, "top.qpi_net.4", 4, 128));
     CHECK(lin(ctx, "mid.ps_net.0", 512, 14)); CHECK(lin(ctx, "mid.ps_net.3", 512, 512)); CHECK(lin(ctx, "mid.ps_net.6", 512, 512));
@@ -91,12 +91,32 @@ int main(void) {
         for (int g = 0; g < M / 4; ++g) hmask[g] = g != 0;
         HIP(hipMalloc((void**)&dmask, M / 4));
         HIP(hipMemcpy(dmask, hmask, M / 4, hipMemcpyHostToDevice));
-        CHECK(efe_set_row_mask(ctx, dmask, 4));
-        CHECK(efe_calculate_g(ctx, ds, dpi, M, S, 0, &nz, NULL, dG, dT, dps1, dmean, dpo1, NULL, NULL));
-        CHECK(efe_set_row_mask(ctx, NULL, 1));
+        efe_rows rows = {dmask, NULL, 4};           /* the mask is an ARGUMENT of the call (ABI 4) ... */
+        CHECK(efe_calculate_g_rows(ctx, ds, dpi, M, S, 0, &nz, NULL, &rows, dG, dT, dps1, dmean, dpo1, NULL, NULL));
         float hGm[M];
         HIP(hipMemcpy(hGm, dG, M * 4, hipMemcpyDeviceToHost));
         for (int i = 4; i < M; ++i) if (hGm[i] != hG[0][i]) { fprintf(stderr, "row mask changed a live row\n"); return 1; }
+        /* ... so a plain call on the same context right after it sees no mask: row 0 is computed again */
+        CHECK(efe_calculate_g(ctx, ds, dpi, M, S, 0, &nz, NULL, dG, dT, dps1, dmean, dpo1, NULL, NULL));
+        HIP(hipMemcpy(hGm, dG, M * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < M; ++i) if (hGm[i] != hG[0][i]) { fprintf(stderr, "an unmasked call saw the previous call's mask\n"); return 1; }
+        {   /* a compacted call: entries 1 .. M/4-1 as a dense batch that still draws the noise of the rows it holds (efe_rows.ids) */
+            int hids[M / 4], *dids;
+            for (int g = 1; g < M / 4; ++g) hids[g - 1] = g;
+            HIP(hipMalloc((void**)&dids, sizeof(hids)));
+            HIP(hipMemcpy(dids, hids, sizeof(hids), hipMemcpyHostToDevice));
+            efe_rows crows = {NULL, dids, 4};
+            CHECK(efe_calculate_g_rows(ctx, ds + 4 * 10, dpi + 4 * 4, M - 4, S, 0, &nz, NULL, &crows, dG, dT, dps1, dmean, dpo1, NULL, NULL));
+            HIP(hipMemcpy(hGm, dG, (M - 4) * 4, hipMemcpyDeviceToHost));
+            for (int i = 0; i < M - 4; ++i) if (hGm[i] != hG[0][i + 4]) { fprintf(stderr, "compacted rows differ from the full batch\n"); return 1; }
+            HIP(hipFree(dids));
+        }
+        /* the deprecated context-state form still works */
+        CHECK(efe_set_row_mask(ctx, dmask, 4));
+        CHECK(efe_calculate_g(ctx, ds, dpi, M, S, 0, &nz, NULL, dG, dT, dps1, dmean, dpo1, NULL, NULL));
+        CHECK(efe_set_row_mask(ctx, NULL, 1));
+        HIP(hipMemcpy(hGm, dG, M * 4, hipMemcpyDeviceToHost));
+        for (int i = 4; i < M; ++i) if (hGm[i] != hG[0][i]) { fprintf(stderr, "efe_set_row_mask changed a live row\n"); return 1; }
         CHECK(efe_calculate_g(ctx, ds, dpi, M, S, 0, &nz, NULL, dG, dT, dps1, dmean, dpo1, NULL, NULL));     /* dG complete again for the posterior */
         HIP(hipFree(dmask));
     }

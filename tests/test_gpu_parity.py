@@ -177,6 +177,98 @@ def test_simulate_vs_golden(golden, models, name):
     assert np.array_equal(c(pi02), g['pi0']) and abs(G2 - float(g['G'])) < 5e-3
 
 
+@pytest.mark.parametrize('name', ['simulate_invalid_nan', 'simulate_invalid_inf'])
+def test_simulate_invalid_habit_posterior_vs_reference(golden, weights_cache, name):
+    """the reference's bare-except fallback (/root/reference/src/torchmodel.py:362-367, 378-381) on the device: a habit network whose
+    posterior torch.multinomial rejects (NaN everywhere / [0, 0, NaN, 0]) -> k_sim_chain takes action 0 on EVERY step and returns that
+    one-hot as Qpi; fixtures captured from the reference with the poisoned output bias (oracle/make_golden_invalid.py).  Checked through
+    the single-episode API, through the batched call beside healthy neighbours' rows, and in device-noise mode."""
+    import daimc_amd
+    g = golden(name)
+    w = dict(weights_cache(int(g['wseed']), float(g['gain'])))
+    b = np.array(w['top.qpi_net.4.bias'], copy=True)
+    b[int(g['bias_index'])] = g['bias_value']
+    w['top.qpi_net.4.bias'] = b
+    seed, st, ep, T = int(g['nseed']), int(g['stage']), int(g['episode']), int(g['depth'])
+    m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=seed, init_weights=False)
+    m.load_flat_weights(w)
+    eps = np.concatenate([PX.normals(seed, 1, 10, PX.PASS_SIM, t, st, ep).reshape(-1) for t in range(T)]
+                         + [eps_calcG(seed, T, 1, st, ep * T).reshape(-1)])
+    u = np.stack([PX.uniforms(seed, 1, PX.PASS_HABIT, t, st, ep) for t in range(T)])
+    G, pi0, q = m.mcts_step_simulate(g['start'], T, use_means=False, stage=st, row_offset=ep, eps=eps, u=u)
+    onehot0 = np.eye(4, dtype=np.float32)[[0] * T]
+    assert np.array_equal(c(pi0), g['pi0']) and np.array_equal(c(pi0), onehot0)
+    assert np.array_equal(c(q), g['Qpi']) and np.array_equal(c(q), [1, 0, 0, 0])
+    assert abs(G - float(g['G'])) < gtol(np.array([2800.0]))
+    # device-generated noise: the fallback does not consume the uniform, the normals differ by Box-Muller's libm
+    G2, pi02, q2 = m.mcts_step_simulate(g['start'], T, use_means=False, stage=st, row_offset=ep)
+    assert np.array_equal(c(pi02), onehot0) and np.array_equal(c(q2), [1, 0, 0, 0]) and abs(G2 - float(g['G'])) < 5e-3
+    # the batched call (the lock-step planner's form): episode `ep` of a batch of ep + 2 starts at global rows
+    starts = np.tile(np.asarray(g['start'], dtype=np.float32)[None], (ep + 2, 1))
+    Gb, pib, qb = m.simulate_batch(starts, T, use_means=False, stage=st, row_offset=0)
+    assert np.array_equal(c(pib).reshape(ep + 2, T, 4), np.tile(onehot0[None], (ep + 2, 1, 1)))
+    assert np.array_equal(c(qb), np.tile(np.array([[1, 0, 0, 0]], dtype=np.float32), (ep + 2, 1)))
+    assert abs(float(c(Gb)[ep]) - float(g['G'])) < 5e-3 and np.isfinite(c(Gb)).all()
+    # a whole planner on this model: the prior is the one-hot at every node, the planner finishes and its visit counts are a distribution
+    p = daimc_amd.MCTS_Params()
+    p.repeats, p.simulation_depth, p.use_means, p.threshold, p.samples = 6, 3, False, 2.0, 2
+    out, visits = daimc_amd.active_inference_mcts_batch(m, torch.from_numpy(synth.make_frames(5, 2)[:, 0][:, None]), p, o_shape=(1, 64, 64))
+    np.testing.assert_allclose(visits.sum(1).numpy(), 1.0, rtol=1e-6)
+    assert all(np.isfinite(o_[4]).all() for o_ in out)
+
+
+def test_lockstep_batch_at_benchmark_size_contains_the_reference_episodes(golden, models):
+    """BASELINE configs[2] at its benchmarked batch: 64 episodes planned in lock-step (256-row x 10-sample expansions, simulations
+    forked onto the second stream through the replica context, node capacity 1 + A (repeats + 2) at E = 64).  The noise keys are
+    global, so episodes 0-2 of the batch -- the three frames of mcts_deep_s10 -- must reproduce the reference planner's capture
+    whatever the other 61 episodes are; every episode's root visit distribution is a distribution."""
+    import daimc_amd
+    g = golden('mcts_deep_s10')
+    m = inject(_model(g, models))
+    p = _deep_params(g)
+    E, E0 = 64, int(g['episodes'])
+    frames = torch.cat([torch.from_numpy(g['frames']), torch.from_numpy(synth.make_frames(77, E - E0))], 0)
+    m._stage = int(g['stage'])
+    out, visits = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
+    planner = next(pl for pl in m._planners.values() if pl.E == E)
+    assert planner.overlap and planner.sim_model is not m          # the second stream / replica context was in use
+    assert planner.cap == 1 + 4 * (p.repeats + 2)
+    for e in range(E0):
+        _check_deep(g, e, out[e], visits[e])
+    np.testing.assert_allclose(visits.sum(1).numpy(), 1.0, rtol=1e-6)
+    assert all(len(o_[3]) == o_[1] == p.repeats for o_ in out)       # threshold 2.0 in the fixture: every iteration of every episode ran
+    assert int(planner.n_nodes.max()) <= planner.cap
+
+
+def test_planner_replica_follows_engine_options(models):
+    """engine options are per context: the replica the lock-step planner simulates on must compute with the options of the model it
+    mirrors (reward_upstream_intent changes term0 / G) -- a planner with the simulations on the second stream equals the same planner
+    with them on the main context, with the option set BEFORE and AFTER the replica exists"""
+    import daimc_amd
+    m = models(1234, 1.15, 23)
+    frames = torch.from_numpy(synth.make_frames(58, 8)[:, 0][:, None])
+
+    def plan(overlap):
+        p = daimc_amd.MCTS_Params()
+        p.repeats, p.simulation_depth, p.use_means, p.threshold, p.samples = 8, 3, False, 2.0, 2
+        p.overlap_simulate = overlap
+        m._stage = 300
+        out, visits = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
+        return [o_[3] for o_ in out], np.array([o_[4] for o_ in out]), visits
+    try:
+        base = plan(True)                              # creates the replica with default options
+        m.set_option('reward_upstream_intent', 1)      # ... which must follow
+        a_paths, a_G, a_v = plan(True)
+        b_paths, b_G, b_v = plan(False)
+        assert a_paths == b_paths and np.array_equal(a_G, b_G) and torch.equal(a_v, b_v)
+        assert not np.array_equal(a_G, base[1])        # the option does change G
+        m.__dict__.pop('_replica', None)               # a replica created AFTER the option was set
+        c_paths, c_G, c_v = plan(True)
+        assert c_paths == b_paths and np.array_equal(c_G, b_G)
+    finally:
+        m.set_option('reward_upstream_intent', 0)
+
+
 @pytest.mark.parametrize('name', ['mcts_means', 'mcts_samples', 'mcts_prior'])
 def test_mcts_vs_golden(golden, models, name):
     import daimc_amd
@@ -774,6 +866,13 @@ def test_full_size_cfg2_vs_oracle(models, weights_cache):
     P, _ = m.action_posterior(G)
     oP, _ = EO.softmax_multi_with_log(-oG.numpy(), 4)
     np.testing.assert_allclose(c(P), oP, atol=2e-3)
+    # the same call in PRODUCTION noise mode (normals generated on the device from the same Philox stream, nothing injected): the only
+    # difference from the mirror is Box-Muller's libm (an ulp on each normal), a few 1e-3 on G per stage -- at the benchmark's size
+    Gd, Td, po1d = m.calculate_G_repeated(o, pi, steps=D, samples=S, stage=st)
+    np.testing.assert_allclose(c(Td[0]), oT[0].numpy(), atol=2e-3)
+    np.testing.assert_allclose(c(Td[1]), oT[1].numpy(), atol=2e-3)
+    np.testing.assert_allclose(c(Gd), oG.numpy(), atol=D * (gtol(np.array([2800.0])) + 4e-3))
+    np.testing.assert_allclose(c(po1d), opo1.numpy(), rtol=1e-4, atol=2e-4)
 
 
 def test_reserve_no_growth(models):
@@ -915,6 +1014,84 @@ def test_batched_mcts_skipping_stopped_episodes_changes_nothing(models):
             mixed = True
             break
     assert mixed, 'no threshold stopped some episodes early: the fixture does not exercise the skip'
+
+
+def test_rows_are_an_argument_of_the_call_not_context_state(models):
+    """ABI 4 (efe_rows): the liveness mask and the row identities belong to ONE call.  A masked call leaves the next plain call on the same
+    context untouched (with efe_set_row_mask it saw the mask until someone cleared it); a COMPACTED call -- only the live entries, as a
+    dense batch with their ids -- returns bit for bit the rows of the full batch (noise keys follow the entry id, not the slot), for
+    calculate_G, calculate_G_mean and simulate_batch, with device noise and with injected noise."""
+    from daimc_amd.model import Rows
+    m = models(1234, 1.15, 33)
+    A, Eps, T = 4, 7, 3
+    M = A * Eps
+    s0 = torch.from_numpy(PX.uniform_fill(2, (M, 10), 77, -1, 1)).to(m.device)
+    pi0 = torch.from_numpy(np.eye(4, dtype=np.float32)[np.arange(M) % 4]).to(m.device)
+    starts = torch.from_numpy(PX.uniform_fill(9, (Eps, 10), 78, -1, 1)).to(m.device)
+    alive = torch.tensor([1, 0, 1, 1, 0, 0, 1], dtype=torch.uint8, device=m.device)
+    keep = torch.nonzero(alive).flatten()
+    ids = keep.to(torch.int32)
+    krows = (keep[:, None] * A + torch.arange(A, device=m.device)[None]).reshape(-1)
+    for inj in (False, True):
+        m.eps_source, m.u_source = (PX.normals, PX.uniforms) if inj else (None, None)
+        ref = m.calculate_G(s0, pi0, samples=3, stage=4)
+        refm = m.calculate_G_mean(s0, pi0, stage=5)
+        rsim = m.simulate_batch(starts, T, use_means=False, stage=9)
+        # mask as an argument; the next plain call is complete
+        out = m.calculate_G(s0, pi0, samples=3, stage=4, rows=Rows(mask=alive, rows_per_entry=A))
+        assert torch.equal(out[0][krows], ref[0][krows]) and torch.equal(out[4][krows], ref[4][krows])
+        again = m.calculate_G(s0, pi0, samples=3, stage=4)
+        assert torch.equal(again[0], ref[0]) and torch.equal(again[2], ref[2])
+        # compacted calls
+        rc = Rows(ids=ids, rows_per_entry=A, ids_host=keep.tolist())
+        cmp_ = m.calculate_G(s0[krows], pi0[krows], samples=3, stage=4, rows=rc)
+        assert torch.equal(cmp_[0], ref[0][krows])
+        for k in range(3):
+            assert torch.equal(cmp_[1][k], ref[1][k][krows])
+        assert torch.equal(cmp_[2], ref[2][krows]) and torch.equal(cmp_[3], ref[3][krows]) and torch.equal(cmp_[4], ref[4][krows])
+        cmpm = m.calculate_G_mean(s0[krows], pi0[krows], stage=5, rows=rc)
+        assert torch.equal(cmpm[0], refm[0][krows]) and torch.equal(cmpm[2], refm[2][krows])
+        csim = m.simulate_batch(starts[keep], T, use_means=False, stage=9, rows=Rows(ids=ids, ids_host=keep.tolist()))
+        assert torch.equal(csim[0], rsim[0][keep]) and torch.equal(csim[1], rsim[1][keep]) and torch.equal(csim[2], rsim[2][keep])
+        # compacted AND masked: the mask is read at the entry id
+        alive2 = alive.clone(); alive2[2] = 0
+        cm = m.calculate_G(s0[krows], pi0[krows], samples=3, stage=4, rows=Rows(mask=alive2, ids=ids, rows_per_entry=A, ids_host=keep.tolist()))
+        live2 = (alive2[keep] != 0).repeat_interleave(A)
+        assert torch.equal(cm[0][live2], ref[0][krows][live2])
+    m.eps_source, m.u_source = None, None
+    with pytest.raises(ValueError):
+        Rows(mask=torch.ones(5, dtype=torch.float32, device=m.device))
+    with pytest.raises(RuntimeError):
+        m.calculate_G(s0[:6], pi0[:6], samples=1, stage=0, rows=Rows(mask=alive, rows_per_entry=A))      # 6 rows are not whole entries
+
+
+def test_batched_mcts_compaction_changes_nothing(models):
+    """the lock-step planner gathering the live episodes into a dense batch as they stop (efe_rows.ids) == masking them == evaluating
+    every episode: identical paths, iteration counts, G histories and visit distributions -- with the simulations on the second stream"""
+    import daimc_amd
+    m = models(1234, 1.15, 21)
+    frames = torch.from_numpy(synth.make_frames(56, 24)[:, 0][:, None])
+    found = False
+    for thr in (0.3, 0.25, 0.2, 0.15):
+        res, compacted = [], []
+        for skip, comp in ((True, True), (True, False), (False, False)):
+            p = daimc_amd.MCTS_Params()
+            p.repeats, p.simulation_depth, p.use_means, p.samples, p.threshold = 26, 3, False, 2, thr
+            p.skip_stopped, p.compact_stopped = skip, comp
+            m._stage = 0
+            res.append(daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64)))
+            pl = [q for q in m._planners.values() if q.E == 24 and q.p.compact_stopped == comp and q.p.skip_stopped == skip and q.p.threshold == thr][-1]
+            compacted.append(pl._ids is not None and len(pl._ids[1]) < 24)
+        for (out_b, dist_b) in res[1:]:
+            for e in range(24):
+                assert res[0][0][e][0] == out_b[e][0] and res[0][0][e][1] == out_b[e][1] and res[0][0][e][3] == out_b[e][3] and res[0][0][e][4] == out_b[e][4]
+            assert torch.equal(res[0][1], dist_b)
+        assert not compacted[1] and not compacted[2]
+        stops = [o[1] for o in res[0][0]]
+        if compacted[0] and max(stops) == 26:          # some episodes were compacted away while others ran to the end
+            found = True
+            break
+    assert found, 'no threshold made the planner compact its batch: the fixture does not exercise efe_rows.ids'
 
 
 def test_cached_simulation_replica_follows_the_weights(models, weights_cache):

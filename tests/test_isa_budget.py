@@ -53,9 +53,9 @@ SSPILL = {
     'k_dec_b4': 4, 'k_dec_a': 0, 'k_fc4': 0, 'k_trans_fused': 0,
     'k_convt_p<1, 4>': 0, 'k_convt_p<1, 8>': 0, 'k_convt_p<2, 4>': 0, 'k_convt_p<2, 8>': 5,
     'k_conv_e<1, 4>': 0, 'k_conv_e<2, 16>': 0,
-    'k_enc_trunk': 22, 'k_head<16>': 15, 'k_head<32>': 22,
-    'k_final_g': 43,            # fallback of the generic decoder tail (option fuse_final_g = 0 / the resolution-32 variant)
-    'k_sim_chain': 120,         # latency-bound one-launch simulation chain (0.28 ms per planner iteration, beside the expansion)
+    'k_enc_trunk': 26, 'k_head<16>': 25, 'k_head<32>': 22,      # (+4 / +10 with the row-identity pointer of ABI 4 among the kernel arguments)
+    'k_final_g': 47,            # fallback of the generic decoder tail (option fuse_final_g = 0 / the resolution-32 variant)
+    'k_sim_chain': 126,         # latency-bound one-launch simulation chain (0.28 ms per planner iteration, beside the expansion)
 }
 SSPILL_DEFAULT = 0
 

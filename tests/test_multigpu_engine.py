@@ -103,3 +103,38 @@ def test_two_rank_engine_equals_single_process_and_reference(tmp_path):
         np.testing.assert_allclose(np.array(all_G), g['all_paths_G'][e][:n], atol=5e-6 * 2800 + 1e-3)
         assert [int(a) for a in path] == [int(a) for a in g['final_path'][e] if a >= 0]
         np.testing.assert_array_equal(got['V'][e].numpy(), g['root_N'][e] / g['root_N'][e].sum())
+
+
+def _bench_line(args, timeout):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                        # ONE JSON line on stdout, whatever the rank count
+    return json.loads(lines[0])
+
+
+def test_bench_rccl_path_at_one_rank():
+    """the N > 1 code path of bench.py through RCCL itself on a 1-GPU box: `--force-dist` initialises the "nccl" process group with one
+    rank, so the device-tensor all_gather of the action posteriors, the max-over-ranks timing and the collective fields of the line run
+    through the library the 8-GPU line will use"""
+    d = _bench_line(['--force-dist', '--no-extras', '--steps', '3', '--warmup', '2', '--min-seconds', '0.5'], 600)
+    assert d['n_gpus'] == 1 and d['rccl_ranks'] == 1 and d['backend'] == 'nccl'
+    assert len(d['per_rank_ms_per_step']) == 1 and d['all_gather_ms'] > 0
+    assert d['roofline']['frac'] > 0.3 and d['roofline']['bound'] == 'mfma' and 'sclk_mhz_under_load' in d['roofline']
+    assert d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['kind'] == 'port'
+    assert d['value'] > 1000 and d['config']['rows_per_gpu'] == 128
+
+
+def test_bench_launcher_at_four_ranks_on_one_device():
+    """`python bench.py --gpus 4 --share-device`: the self-launcher (torch.distributed.run on 127.0.0.1), episode sharding with global row
+    offsets, region-count agreement across ranks, rank 0's single JSON line with the per-rank figures and the CPU leg -- every rank on
+    cuda:0 over gloo (a rehearsal of the 8-GPU line, which needs a multi-GPU node; the 8-rank form runs in tools/rehearse_8gpu.sh)"""
+    d = _bench_line(['--gpus', '4', '--share-device', '--no-extras', '--no-prof', '--steps', '2', '--warmup', '1', '--min-seconds', '0.5'], 900)
+    assert d['n_gpus'] == 4 and d['rccl_ranks'] == 4 and d['backend'] == 'gloo' and d.get('share_device') is True
+    assert len(d['per_rank_ms_per_step']) == 4 and d['all_gather_ms'] > 0 and d['scaling'] == 'weak'
+    assert d['cpu_baseline']['value'] > 0
+    assert d['config']['rows_per_gpu'] == 128 and d['value'] > 1000

@@ -113,6 +113,23 @@ def test_simulate_vs_reference(golden, weights_cache):
         np.testing.assert_allclose(q.numpy(), g['Qpi'], rtol=1e-6)
 
 
+def test_simulate_invalid_posterior_vs_reference(golden, weights_cache):
+    """the bare-except fallback of mcts_step_simulate (/root/reference/src/torchmodel.py:362-367, 378-381), captured from the reference
+    with a habit network whose posterior is NaN / [0, 0, NaN, 0] (oracle/make_golden_invalid.py): action 0 on every step, Qpi = one-hot"""
+    for name in ('simulate_invalid_nan', 'simulate_invalid_inf'):
+        g = golden(name)
+        w = dict(weights_cache(int(g['wseed']), float(g['gain'])))
+        b = np.array(w['top.qpi_net.4.bias'], copy=True)
+        b[int(g['bias_index'])] = g['bias_value']
+        w['top.qpi_net.4.bias'] = b
+        m = EO.OracleModel(w, EO.PhiloxNoise(int(g["nseed"])))
+        with torch.no_grad():
+            G, pi0, q = m.mcts_step_simulate(torch.from_numpy(g['start']), int(g['depth']), False, int(g['stage']), episode=int(g['episode']))
+        assert abs(G - float(g['G'])) < 1e-3
+        assert np.array_equal(pi0.numpy(), g['pi0']) and np.array_equal(pi0.numpy(), np.eye(4, dtype=np.float32)[[0] * int(g['depth'])])
+        assert np.array_equal(q.numpy(), g['Qpi'])
+
+
 def test_convtranspose_subpixel_restatement():
     """independent numpy restatement of ConvTranspose2d(k3,s2,p1,op1) in the 4-parity form the HIP kernel
     uses against torch's conv_transpose2d."""
