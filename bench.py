@@ -426,6 +426,39 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
     return out
 
 
+def bench_single_episode(model, device, samples):
+    """the reference's own call shape (/root/reference/src/mcts.py:150-195, 64-86): ONE episode -- active_inference_mcts with 4-row
+    expansions and batch-1 simulations -- as host-observed latency: milliseconds per 50-iteration decision (use_means, S = 1; and the
+    benchmark's S MC samples per expansion, through the lock-step planner at E = 1, launched and replayed from the captured hipGraph) and per
+    calculate_G / calculate_G_mean call on the 4 action rows of one state.  Latency-bound (dependent launches of a few images each): a
+    per-call figure, not a roofline entry."""
+    import daimc_amd
+    frame = synth_frames(1, device, seed=300)
+
+    def ms(fn, n):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+    s4 = torch.randn(4, 10, device=device) * 0.3
+    out = {'unit': 'ms', 'what': 'one episode, host-observed latency per call (mean of repeated calls, device noise)',
+           'calculate_G_mean_4rows': ms(lambda: model.calculate_G_mean(s4, model.pi_one_hot), 30),
+           'calculate_G_4rows_S%d' % samples: ms(lambda: model.calculate_G(s4, model.pi_one_hot, samples=samples), 30),
+           'mcts_step_simulate_depth5': ms(lambda: model.mcts_step_simulate(s4[0], 5), 30)}
+    p = daimc_amd.MCTS_Params()
+    p.repeats, p.simulation_depth, p.threshold, p.use_means = 50, 5, 2.0, True
+    out['decision_use_means_S1_reference_api'] = ms(lambda: daimc_amd.active_inference_mcts(model, frame[0], p, o_shape=(1, 64, 64)), 3)
+    for mode in (False, True):
+        q = daimc_amd.MCTS_Params()
+        q.repeats, q.simulation_depth, q.threshold, q.use_means, q.samples, q.use_graph = 50, 5, 2.0, False, samples, mode
+        key = 'decision_S%d_lockstep_E1_%s' % (samples, 'graph' if mode else 'launched')
+        out[key] = ms(lambda: daimc_amd.active_inference_mcts_batch(model, frame, q, o_shape=(1, 64, 64)), 4)
+        out[key.replace('decision', 'iteration')] = out[key] / 51.0          # root expansion + 50 iterations
+    return out
+
+
 def cpu_baseline_generic(A, C, R, depth, samples):
     """configs[4] on the CPU: the build-defined oracle restatement (parity unpinned), 3 bounded passes of >= 3 s each;
     rollouts/s extrapolated by (depth x samples) -- every (stage, sample) costs the same"""
@@ -762,6 +795,7 @@ def main():
         key = 'mcts_cfg3' if world == 1 else 'mcts_cfg4_sharded'
         mc = bench_mcts(a, model, device, rk, 3, 1, with_cpu and world == 1)
         mc05 = bench_mcts(a, model, device, rk, 3, 1, False, threshold=0.5, min_total_s=1.0)
+        single = bench_single_episode(model, device, a.samples) if world == 1 else None
         del model
         torch.cuda.empty_cache()
         ai = bench_generic(a, device, rk, 2, 1, with_cpu and world == 1)
@@ -769,6 +803,8 @@ def main():
             out['extras'] = {key: mc, key + '_threshold_0.5': mc05, 'animalai_cfg5': ai}
             if pipelined:
                 out['extras']['rollout_two_streams'] = pipelined
+            if single:
+                out['extras']['single_episode'] = single
     emit(out)
 
 
