@@ -214,6 +214,7 @@ void launch_dec_a(const DecAArgs& a, hipStream_t st) {
 // being gathered; the next strip's input is requested behind the contraction's last weight-fragment request (the tap phase covers
 // its latency instead of the gather); the images of the deferred rows are stored after the strip barrier.  Per-thread summation
 // order is the same as when every strip is gathered between its own barriers (0.812 of the fp32 MFMA peak in that form, 0.843 in this one).
+template <int PARTS>        // 1 = one workgroup per image, 4 = four (small launches)
 __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     constexpr int SR = 4, NW = 4, NTHR = 256;
     constexpr int DB_ZERO = (SR + 1) * 32;
@@ -227,14 +228,23 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     constexpr int NS = 32 / SR;
     extern __shared__ __attribute__((aligned(16))) float4 sm[];
     float* sH = reinterpret_cast<float*>(sm + DB_IN_F4);       // [ring row][kh][64 output columns]
-    __shared__ float sred[NW];
     __shared__ float4 sb3[8];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int img = blockIdx.x;
+    // Small launches (a.parts == 4: <= 128 images, the one-episode planner's expansions and simulations) split an image over four
+    // workgroups: quarter k owns the output rows gathered from strips 2k and 2k + 1 (their H planes need the last y3 row pair of strip
+    // 2k - 1, so a quarter contracts that strip again as a halo) -- 3 of the 8 strips of latency instead of 8.  The per-image sum is
+    // DEFINED quarter-wise, ((Q0 + Q1) + (Q2 + Q3)) with Q_k reduced over the workgroup on its own, so that one workgroup walking all
+    // eight strips (a.parts == 1) and four workgroups walking three each produce the same bits: results stay a function of the noise
+    // keys alone, whatever the launch size.
+    constexpr int parts = PARTS;
+    const int img = parts == 1 ? (int)blockIdx.x : (int)(blockIdx.x >> 2);
+    const int qtr = parts == 1 ? 0 : (int)(blockIdx.x & 3);
     if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    const int s_lo = parts == 1 ? 0 : (qtr ? 2 * qtr - 1 : 0);          // first strip contracted (the halo strip of quarters 1..3)
+    const int s_hi = parts == 1 ? NS : 2 * qtr + 2;
 
     const int mg = a.m0 + img;
     const int g = mg / a.rows_per_group;
@@ -245,6 +255,8 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     const int slot = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
     float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + r) * 4096 : nullptr;
 
+    __shared__ float sq[4 * NTHR];       // [quarter][thread]: the threads' partial sums of a quarter, reduced once per image
+    __shared__ float sQ[4];
     if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];
     // 16-block 4x4x1 form of the tap contraction: block = 4 consecutive lanes = 4 pixels of one channel half, A row i = lane & 3 = kw,
     // one instruction per (kh, accumulator register): 3 x 16 A values per lane, 12 tap rows (9 used) instead of 16.  The 48 values depend
@@ -270,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     const f32x4* Xv = reinterpret_cast<const f32x4*>(X);
     auto y2_at = [&](int iy, int idx) -> size_t { return (size_t)(((iy & 1) * 16 + ((idx & 511) >> 5)) * 512 + (iy >> 1) * 32 + (idx & 31)); };
 #pragma unroll
-    for (int it = 0; it < NPF; ++it) { const int idx = it * NTHR + tid; pf[it] = Xv[y2_at(min(idx >> 9, 31), idx)]; }
+    for (int it = 0; it < NPF; ++it) { const int idx = it * NTHR + tid; pf[it] = Xv[y2_at(min(SR * s_lo + (idx >> 9), 31), idx)]; }
 
     // the four shifted B views of this wave's row: LDS float4 base and swizzle key
     const int spA = w * 32 + j;                                   // (row w,     col j)
@@ -312,8 +324,13 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
         gpr[q] = hw_sigmoid(v);
     };
     auto g_term = [&](int oh, int q) {          // branch-free: both forms are evaluated (the reward form is four FMAs), rows above the image add zero
+        // (the products are contracted EXPLICITLY: this lambda is inlined at several places -- deferred pieces, strip epilogues, both
+        // template instances -- and a row must get the same bits whichever copy evaluates it; left to the compiler, a b - c d may
+        // become fma(a, b, -(c d)) in one copy and fma(-c, d, a b) in another)
+#pragma clang fp contract(off)
         const float pr = gpr[q];
-        const float te = -(1.0f - pr) * hw_log(D1 - pr) - pr * hw_log(D0 + pr);
+        const float l1 = hw_log(D1 - pr), l0 = hw_log(D0 + pr);
+        const float te = __builtin_fmaf(pr - 1.0f, l1, -(pr * l0));          // -(1 - p) ln((1e-5 + 1) - p) - p ln(1e-5 + p)
         const float tw = reward_term(pr, oh, lane, 64, 64, a.reward_intent);
         const float t = mode == 0 ? te : tw;
         part += oh >= 0 ? t : 0.0f;
@@ -333,9 +350,12 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
         }
     };
 
+    // a quarter is complete: park the thread's partial sum (one LDS write; the reductions of all quarters run once, behind the last strip)
+    auto fold = [&](int k) { sq[k * NTHR + tid] = part; part = 0.f; };
     int hb = 0, hbp = 0;                                   // H-ring slots of y3 rows 2 SR s (this strip's first) and 2 SR (s - 1)
-    for (int s = 0; s < NS; ++s) {
+    for (int s = s_lo; s < s_hi; ++s) {
         const int tl = tid;
+        const bool gq = parts == 1 ? true : s == 2 * qtr + 1;   // (uniform) the previous strip's rows are this workgroup's to gather
         const int oh0 = 2 * SR * (s - 1) - 1 + w, oh1 = oh0 + NW;         // this wave's two output rows of the previous strip        // (laundering the index per strip frees ~20 VGPRs -- 168, three waves per SIMD, 4 spills -- for no gain: 0.814 vs 0.812)
 #pragma unroll
         for (int it = 0; it < NPF; ++it) {
@@ -373,10 +393,12 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 if (kc == 0) { MFMA4I(acc[0], bias16, c0, cb) MFMA4I(acc[1], bias16, c1, cb) MFMA4I(acc[2], bias16, c2, cb) MFMA4I(acc[3], bias16, c3, cb) }
                 else { MFMA4(acc[0], c0, cb) MFMA4(acc[1], c1, cb) MFMA4(acc[2], c2, cb) MFMA4(acc[3], c3, cb) }
                 // the previous strip's gather, a piece per channel-block step
-                if (kc == 0) { g_load(oh0, 0, 2 * SR * (s - 1), hbp); g_load(oh1, 1, 2 * SR * (s - 1), hbp); }
-                if (kc == 2) g_sig(oh0, 0);
-                if (kc == 4) g_term(oh0, 0);
-                if (kc == 6) g_sig(oh1, 1);
+                if (gq) {
+                    if (kc == 0) { g_load(oh0, 0, 2 * SR * (s - 1), hbp); g_load(oh1, 1, 2 * SR * (s - 1), hbp); }
+                    if (kc == 2) g_sig(oh0, 0);
+                    if (kc == 4) g_term(oh0, 0);
+                    if (kc == 6) g_sig(oh1, 1);
+                }
             }
             float4 bd;
 #pragma unroll
@@ -392,7 +414,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 MFMA4(acc[1], c0, cb) MFMA4(acc[3], c1, cb)
-                if (kc == 1) g_term(oh1, 1);
+                if (kc == 1 && gq) g_term(oh1, 1);
             }
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
@@ -446,11 +468,12 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
             }
         }
         __syncthreads();
-        g_store(oh0, 0); g_store(oh1, 1);                  // the deferred rows' pixels (stores behind the prefetch loads)
-        if (s == NS - 1) {                                  // the last strip has no successor: its rows (and row 63) now
+        if (gq) { g_store(oh0, 0); g_store(oh1, 1); }     // the deferred rows' pixels (stores behind the prefetch loads)
+        if (parts == 1 && (s == 2 || s == 4 || s == 6)) fold(s / 2 - 1);       // quarter s / 2 - 1 is complete (its second gather ran inside this strip)
+        if (s == s_hi - 1) {                                // no successor in this workgroup: the strip's own rows now (and row 63 behind the last strip)
 #pragma unroll
             for (int q = 0; q <= RWG; ++q) {
-                if (q == RWG && w != 0) break;
+                if (q == RWG && (w != 0 || s != NS - 1)) break;
                 const int oh = 2 * SR * s - 1 + q * NW + w;
                 g_load(oh, 0, 2 * SR * s, hb); g_sig(oh, 0); g_term(oh, 0); g_store(oh, 0);
             }
@@ -459,21 +482,33 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
         hb += 2 * SR;
         hb = hb >= DB_YROWS ? hb - DB_YROWS : hb;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    if (lane == 0) sred[w] = part;
+    fold(parts == 1 ? 3 : 0);
     __syncthreads();
-    if (tid == 0) a.val[mg] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    // Q_k = the xor-tree sum over the 64 lanes of ((wave 0 + wave 1) + (wave 2 + wave 3)) of the parked partials: wave k reduces quarter k
+    if (w < (parts == 1 ? 4 : 1)) {
+        const float* qk = sq + w * NTHR + lane;
+        float v = (qk[0] + qk[64]) + (qk[128] + qk[192]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) sQ[w] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (parts == 1) a.val[mg] = (sQ[0] + sQ[1]) + (sQ[2] + sQ[3]);
+        else a.valq[(size_t)mg * 4 + qtr] = sQ[0];          // summed in the same association by the consumer (k_terms)
+    }
 }
 
 constexpr size_t DB_LDS4D = ((5 * 32 + 1) * 17) * sizeof(float4) + 18 * 2 * 3 * 64 * sizeof(float);  // input strip + H planes per channel half (4 SR + 2 rows)
 int init_dec_b_kernels() {
-    if (hipFuncSetAttribute((const void*)k_dec_b4, hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4D) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_dec_b4<1>, hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4D) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_dec_b4<4>, hipFuncAttributeMaxDynamicSharedMemorySize, DB_LDS4D) != hipSuccess) return 1;
     return 0;
 }
 
 void launch_dec_b(const DecBArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_dec_b4, dim3(a.rows), dim3(256), DB_LDS4D, st, a);
+    if (a.parts == 4) hipLaunchKernelGGL(k_dec_b4<4>, dim3(a.rows * 4), dim3(256), DB_LDS4D, st, a);
+    else hipLaunchKernelGGL(k_dec_b4<1>, dim3(a.rows), dim3(256), DB_LDS4D, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -87,6 +87,7 @@ struct efe_ctx {
     int64_t arena_align = 256;
     int64_t reward_intent = 0;     // option "reward_upstream_intent": 1 = the reward target the upstream NHWC code means (kernels.h reward_term), 0 = the shipped port's
     int64_t enc_tiled = 1;         // generic path: LDS-tiled encoder layers 1 and 2 (k_conv_e); 0 = k_conv_g for every layer (A/B, parity of the fallback)
+    int64_t dec_split = 1;         // dSprites path: decoder launches of <= 128 images run k_dec_b4 with four workgroups per image (0 = never: A/B)
     int64_t fuse_final_g = 1;      // generic path: last two decoder layers in one kernel (k_dec_bg); 0 = separate launches (A/B, parity tests of k_final_g)
     int64_t last_macs = 0;
     const uint8_t* row_mask = nullptr; int row_mask_div = 1;      // efe_set_row_mask
@@ -423,9 +424,14 @@ int run_encoder_g(efe_ctx* ctx, const float* o8, int N, const NoiseCfg& nc, floa
 // ModelDown.po_net over N rows ([group][row] batch): the three small dense layers run once over all rows, then per
 // chunk: dense 256->16384 (+dropout) -> k_dec_a (two transposed convs through LDS) -> k_dec_b (third transposed conv,
 // final conv, sigmoid and the per-image reduction, all on chip).
+// launches of at most this many images split every image over four workgroups in k_dec_b4 (per-image sums as quarters, valq)
+constexpr int DEC_SPLIT_MAX = 128;
+inline bool dec_split(const efe_ctx* ctx, int N) { return !ctx->generic && ctx->dec_split && N <= DEC_SPLIT_MAX; }
+
 int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const NoiseCfg& nc, int reward0, int store0,
-                float* val /*[N]*/, float* po_store, hipStream_t st) {
+                float* val /*[N], or [N][4] quarter sums when dec_split(ctx, N)*/, float* po_store, hipStream_t st) {
     if (ctx->generic) return run_decoder_g(ctx, dec_in, N, nc, reward0, store0, val, po_store, st);
+    const bool split = dec_split(ctx, N);
     const int C = (int)std::min<int64_t>(ctx->dec_chunk, N);
     float* hA = ctx->allocT<float>((size_t)N * 256);
     float* hB = ctx->allocT<float>((size_t)N * 256);
@@ -458,7 +464,7 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         DecBArgs db{};
         db.y2 = y2; db.w3 = ctx->dec_ct[2].Wp; db.b3 = ctx->dec_ct[2].bias; db.w4 = ctx->dec_wf; db.b4 = ctx->dec_bf;
         db.rows = c; db.live = live_of(nc, m0); db.m0 = m0; db.rows_per_group = nc.rows_per_group; db.gm = nc.gm; db.reward0 = reward0; db.store0 = store0;
-        db.val = val; db.po = po_store; db.reward_intent = (int)ctx->reward_intent;
+        db.val = val; db.parts = split ? 4 : 1; db.valq = split ? val : nullptr; db.po = po_store; db.reward_intent = (int)ctx->reward_intent;
         e0 = ctx->prof_begin(st);
         launch_dec_b(db, st);
         ctx->prof_end(e0, st);
@@ -521,16 +527,18 @@ struct CoreIO {
     const int32_t* ids = nullptr;                           // entry slot -> entry id (efe_rows.ids): noise keys and the mask follow the id
     // trajectory mode (D == 1, S == 1): T1 is given
     const float* given_ps1 = nullptr; const float* given_mean = nullptr; const float* given_logvar = nullptr;
+    float* pre_tr = nullptr;  // trajectory mode: both transition groups [2][R][32] already computed (k_sim_chain)
     float *G = nullptr, *terms = nullptr, *ps1 = nullptr, *ps1_mean = nullptr, *po1 = nullptr, *t2parts = nullptr;
 };
 
 // calculate_G for D chained stages (torchmodel.py:236-243, 270-300)
 int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
     const int R = io.R, D = io.D, S = io.S;
-    float* tr_all = ctx->allocT<float>((size_t)D * 2 * S * R * 32);
+    float* tr_all = io.pre_tr ? io.pre_tr : ctx->allocT<float>((size_t)D * 2 * S * R * 32);
     float* dec_in = ctx->allocT<float>((size_t)D * 3 * S * R * 16);
     float* xbuf = ctx->allocT<float>((size_t)2 * R * 16);
-    float* val = ctx->allocT<float>((size_t)D * 3 * S * R);
+    const bool vsplit = dec_split(ctx, D * 3 * S * R);          // small decoder launch: per-image sums arrive as four quarter sums
+    float* val = ctx->allocT<float>((size_t)D * 3 * S * R * (vsplit ? 4 : 1));
     float* po_store = ctx->allocT<float>((size_t)D * S * R * ctx->img_store);
     float* enc = ctx->allocT<float>((size_t)D * S * R * 32);
     float* terms_tmp = io.terms ? nullptr : ctx->allocT<float>((size_t)3 * R);
@@ -540,7 +548,9 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
     for (int t = 0; t < D; ++t) {
         float* tr = tr_all + (size_t)t * 2 * S * R * 32;
         NoiseCfg nc; nc.k0 = io.k0; nc.k1 = io.k1; nc.rows_per_group = R; nc.row_offset = io.row_offset;
-        if (io.given_mean) {
+        if (io.pre_tr) {
+            // trajectory mode behind k_sim_chain: it has written both groups
+        } else if (io.given_mean) {
             // trajectory mode: group T1 is supplied, only the loop-2 transition runs
             launch_fill_tr(io.given_mean, io.given_logvar, tr, R, st);
             nc.gm = GroupMap{1, 1, {PASS_T2, 0, 0}, io.stage0 + (uint32_t)t, 0};
@@ -581,7 +591,7 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
         if (run_encoder(ctx, po_store, D * S * R, nc, enc, st)) return 1;
     }
     TermsArgs ta{};
-    ta.val = val; ta.tr = tr_all; ta.enc = enc; ta.D = D; ta.S = S; ta.R = R;
+    ta.val = val; ta.valq = vsplit ? val : nullptr; ta.tr = tr_all; ta.enc = enc; ta.D = D; ta.S = S; ta.R = R;
     // term0 of an image = 10 * mean over the pixels that count (torchmodel.py:212: all 4096, or the 192 bar pixels of the
     // upstream-intent variant); the generic geometries use the sum form of the reference's resolution-32 branch (torchmodel.py:214)
     ta.reward_div = ctx->generic ? 0.0f : (ctx->reward_intent ? 192.0f : 4096.0f);
@@ -738,6 +748,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "reward_upstream_intent")) { ctx->reward_intent = value ? 1 : 0; return 0; }
     if (!strcmp(name, "enc_tiled")) { ctx->enc_tiled = value ? 1 : 0; return 0; }
     if (!strcmp(name, "fuse_final_g")) { ctx->fuse_final_g = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "dec_split")) { ctx->dec_split = value ? 1 : 0; return 0; }
     if (!strcmp(name, "dec_budget_g")) { if (value < (1 << 20)) return ctx->fail("dec_budget_g < 1 MiB"); ctx->dec_budget_g = value; return 0; }
     if (!strcmp(name, "dec_chunk_g")) { if (value < 1) return ctx->fail("dec_chunk_g < 1"); ctx->dec_chunk_g = value; return 0; }
     if (!strcmp(name, "poison")) { ctx->poison = value; return 0; }
@@ -1115,7 +1126,7 @@ int efe_decoder(efe_ctx* ctx, const float* s, int M, const efe_noise* nz, float*
     CallGuard guard_{ctx, st};
     if (!s || !nz || !po || M < 1) return ctx->fail("efe_decoder: bad arguments");
     float* x = ctx->allocT<float>((size_t)M * 16);
-    float* val = ctx->allocT<float>((size_t)M);
+    float* val = ctx->allocT<float>((size_t)M * 4);        // (quarter sums when the launch is split; unused by this entry point)
     if (!x || !val) return 1;
     launch_pad16(s, x, M, S_DIM, st);
     NoiseCfg nc; nc.k0 = (uint32_t)nz->seed; nc.k1 = (uint32_t)(nz->seed >> 32); nc.rows_per_group = M; nc.row_offset = nz->row_offset;
@@ -1264,7 +1275,7 @@ int efe_rollout(efe_ctx* ctx, const float* o, const float* pi, int M, int steps,
 
 static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, const float* mean_traj, const float* lv_traj,
                            const float* pi0_traj, int T, uint32_t k0, uint32_t k1, uint32_t stage, uint32_t row_offset,
-                           const float* eps, float* G, const uint8_t* mask, const int32_t* ids, int mask_div, hipStream_t st) {
+                           const float* eps, float* G, const uint8_t* mask, const int32_t* ids, int mask_div, float* pre_tr, hipStream_t st) {
     float* x = ctx->allocT<float>((size_t)T * 16);
     if (!x) return 1;
     launch_pack_x(pi0_traj, s0_traj, x, T, ctx->pi_dim, S_DIM, st);
@@ -1272,7 +1283,7 @@ static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_
     io.x0 = x; io.R = T; io.D = 1; io.S = 1; io.mean_mode = 0; io.carry_mean = 0;
     io.k0 = k0; io.k1 = k1; io.stage0 = stage; io.row_offset = row_offset; io.eps = eps;
     io.given_ps1 = ps1_traj; io.given_mean = mean_traj; io.given_logvar = lv_traj;
-    io.G = G; io.mask = mask; io.ids = ids; io.mask_div = mask_div;
+    io.G = G; io.mask = mask; io.ids = ids; io.mask_div = mask_div; io.pre_tr = pre_tr;
     return run_core(ctx, io, st);
 }
 
@@ -1286,7 +1297,7 @@ int efe_trajectory(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, co
     if (!s0_traj || !ps1_traj || !ps1_mean_traj || !ps1_logvar_traj || !pi0_traj || !nz || !G || T < 1)
         return ctx->fail("efe_trajectory: bad arguments");
     if (trajectory_impl(ctx, s0_traj, ps1_traj, ps1_mean_traj, ps1_logvar_traj, pi0_traj, T, (uint32_t)nz->seed,
-                        (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, eps, G, nullptr, nullptr, 1, st)) return 1;
+                        (uint32_t)(nz->seed >> 32), nz->stage, nz->row_offset, eps, G, nullptr, nullptr, 1, nullptr, st)) return 1;
     return finish(ctx, st);
 }
 
@@ -1312,22 +1323,23 @@ int efe_simulate_rows(efe_ctx* ctx, const float* starting_s, int E, int depth, i
     float* mt = ctx->allocT<float>((size_t)E * T * 10);
     float* lvt = ctx->allocT<float>((size_t)E * T * 10);
     float* Gt = ctx->allocT<float>((size_t)E * T);
-    if (!s0t || !ps1t || !mt || !lvt || !Gt) return 1;
+    float* trp = ctx->allocT<float>((size_t)2 * E * T * 32);        // the trajectory core's transition rows, written by the chain kernel
+    if (!s0t || !ps1t || !mt || !lvt || !Gt || !trp) return 1;
     {   // the whole habit-policy rollout (depth x (encode_s, sample, transition, reparameterise)) is one launch (fused.hip)
         SimChainArgs sa{};
         sa.W = ctx->mid16; sa.H = ctx->top16; sa.s0 = starting_s; sa.E = E; sa.T = T; sa.use_means = use_means;
         sa.k0 = k0; sa.k1 = k1; sa.stage = nz->stage; sa.row_offset = nz->row_offset;
         sa.eps_inj = eps; sa.u_inj = u; sa.ctr = ctx->stage_ctr; sa.ctr_mul = ctx->stage_mul; sa.ids = rs.ids;
-        sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0; sa.pi_dim = ctx->pi_dim;
+        sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0; sa.pi_dim = ctx->pi_dim; sa.tr = trp;
         ctx->cls = PROF_MID;
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_sim_chain(sa, st);
         ctx->prof_end(e0, st);
         ctx->cls = PROF_OTHER;
-        ctx->last_macs += (int64_t)E * T * (ctx->mac_trans + ctx->mac_habit);
+        ctx->last_macs += (int64_t)E * T * (2 * ctx->mac_trans + ctx->mac_habit);      // the rollout's transition and the trajectory's loop-2 transition
     }
     if (trajectory_impl(ctx, s0t, ps1t, mt, lvt, pi0, E * T, k0, k1, nz->stage, nz->row_offset * (uint32_t)T,
-                        eps ? eps + (size_t)T * E * 10 : nullptr, Gt, rs.mask, rs.ids, T, st)) return 1;     // trajectory row e * T + t belongs to episode slot e
+                        eps ? eps + (size_t)T * E * 10 : nullptr, Gt, rs.mask, rs.ids, T, trp, st)) return 1;     // trajectory row e * T + t belongs to episode slot e
     launch_mean_rows(Gt, G_mean, E, T, st);
     return finish(ctx, st);
 }

@@ -176,33 +176,41 @@ void launch_trans_fused(const TransFusedArgs& a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_sim_chain: the habit-policy rollout of mcts_step_simulate for 16 episodes per workgroup, all `T` steps in one launch:
+// k_sim_chain: the habit-policy rollout of mcts_step_simulate for 8 episodes per workgroup, all `T` steps in one launch:
 //   q = softmax(qpi_net(s_t));  a_t ~ q (inverse CDF on a Philox / injected uniform; invalid q -> action 0, the reference's bare
 //   except);  (mean, logvar) = ps_net([onehot(a_t) | s_t]) with MC-dropout;  ps1 = eps * exp(logvar / 2) + mean;
 //   s_{t+1} = use_means ? mean : ps1.   Trajectory arrays are [E][T][...] (rows of the trajectory batch that follows).
+// The 16-row MFMA tile carries every episode TWICE: rows 0..7 are the rollout's own transition (pass SIM, sample t, row = episode),
+// rows 8..15 the loop-2 transition of calculate_G_given_trajectory on the same input (/root/reference/src/torchmodel.py:339-341:
+// pass T2, row = episode * T + t) -- the same weight stream, different dropout keys.  Both land in `tr` in the layout of the
+// trajectory core ([2 groups][E * T rows][32]: group 0 = the given (mean, logvar), group 1 = the T2 transition), which then needs no
+// transition launch of its own (one-episode decisions: 39 us of a 0.6 ms iteration, on the critical path).
 // ---------------------------------------------------------------------------------------------------------
+constexpr int SIM_FE = 8;              // episodes per workgroup
 __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 sm[];
     float4* bufA = sm;
     float4* bufB = sm + ACT_F4;
-    float* srow = reinterpret_cast<float*>(sm + 2 * ACT_F4);        // [16 rows][16]: current state s_t (10 used)
-    float* sact = srow + FR * 16;                                   // [16 rows][8]: one-hot action of the step
+    float* srow = reinterpret_cast<float*>(sm + 2 * ACT_F4);        // [8 episodes][16]: current state s_t (10 used)
+    float* sact = srow + SIM_FE * 16;                               // [8 episodes][8]: one-hot action of the step
     const int A = a.pi_dim;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
+    const int ne = n & 7, second = n >> 3;                          // tile row n = (episode slot ne, pass: 0 = SIM, 1 = T2)
     const unsigned ln = (unsigned)lane * 16u;
-    const int e0 = blockIdx.x * FR;
+    const int e0 = blockIdx.x * SIM_FE;
     const int E = a.E, T = a.T;
     const uint32_t stage_ = a.stage + stage_bump(a.ctr, a.ctr_mul);
-    if (tid < FR * 16) {
+    const uint32_t erow = global_row(a.ids, 1, min(e0 + ne, E - 1), a.row_offset);      // (episodes past E: any valid key, results discarded)
+    if (tid < SIM_FE * 16) {
         const int rr = tid >> 4, k = tid & 15, e = e0 + rr;
         srow[tid] = (k < 10 && e < E) ? a.s0[(size_t)e * 10 + k] : 0.f;
     }
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         // ---- habit net (no dropout): x = [s | 0] -> 128 -> 128 -> 4
-        if (tid < 64) bufA[aswz(n, q)] = reinterpret_cast<const float4*>(srow + n * 16)[q];
+        if (tid < 64) bufA[aswz(n, q)] = reinterpret_cast<const float4*>(srow + ne * 16)[q];
         __syncthreads();
         RowKey none{0u, 0u, 0u};
         hidden16<2, true, false>(a.H.w[0], a.H.b[0], 2 * w, 1, bufA, bufB, n, q, ln, 0u, 0u, 0u, none);
@@ -211,8 +219,8 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
         __syncthreads();
         if (w == 0) hidden16<1, false, false>(a.H.w[2], a.H.b[2], 0, 8, bufA, bufB, n, q, ln, 0u, 0u, 0u, none);
         __syncthreads();
-        // ---- softmax (torchmodel.py:28-29), categorical sample (torchmodel.py:364,379), one thread per episode row
-        if (tid < FR) {
+        // ---- softmax (torchmodel.py:28-29), categorical sample (torchmodel.py:364,379), one thread per episode
+        if (tid < SIM_FE) {
             const int e = e0 + tid;
             const float4 lg = bufB[aswz(tid, 0)], lg2 = bufB[aswz(tid, 1)];
             const float l[8] = {lg.x, lg.y, lg.z, lg.w, lg2.x, lg2.y, lg2.z, lg2.w};
@@ -240,21 +248,28 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
             }
         }
         __syncthreads();
-        // ---- transition: x = [pi | s | 0 0] (torchmodel.py:59)
+        // ---- transition: x = [pi | s | 0 0] (torchmodel.py:59), the same input on the episode's two tile rows
         if (tid < 64) {
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = 4 * q + i;
-                v[i] = k < A ? sact[n * 8 + k] : k < A + 10 ? srow[n * 16 + (k - A)] : 0.f;
+                v[i] = k < A ? sact[ne * 8 + k] : k < A + 10 ? srow[ne * 16 + (k - A)] : 0.f;
             }
             bufA[aswz(n, q)] = make_float4(v[0], v[1], v[2], v[3]);
         }
-        RowKey rk{global_row(a.ids, 1, min(e0 + n, E - 1), a.row_offset), stream_id(PASS_SIM, (uint32_t)t), stage_};      // (rows past E: any valid key, results discarded)
+        const RowKey rk = second ? RowKey{erow * (uint32_t)T + (uint32_t)t, stream_id(PASS_T2, 0u), stage_}
+                                 : RowKey{erow, stream_id(PASS_SIM, (uint32_t)t), stage_};
         __syncthreads();
         trans_chain(a.W, bufA, bufB, w, n, q, ln, a.k0, a.k1, rk);
+        // ---- both transitions into the trajectory core's tr rows: [pass][e * T + t][32] (mean 0..9, logvar 10..19, zero padding)
+        if (tid < 64 && e0 + ne < E && a.tr) {
+            float4* dst = reinterpret_cast<float4*>(a.tr + ((size_t)second * E * T + (size_t)(e0 + ne) * T + t) * 32);
+            dst[q] = bufA[aswz(n, q)];
+            dst[4 + q] = bufA[aswz(n, 4 + q)];
+        }
         // ---- reparameterise and scatter into the trajectory arrays (torchmodel.py:368-376, 382-390)
-        if (tid < FR * 10) {
+        if (tid < SIM_FE * 10) {
             const int rr = tid / 10, k = tid - rr * 10, e = e0 + rr;
             if (e < E) {
                 const float* o = reinterpret_cast<const float*>(bufA);
@@ -273,8 +288,8 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
 }
 
 void launch_sim_chain(const SimChainArgs& a, hipStream_t st) {
-    const size_t lds = 2 * ACT_F4 * sizeof(float4) + (FR * 16 + FR * 8) * sizeof(float);
-    hipLaunchKernelGGL(k_sim_chain, dim3((a.E + FR - 1) / FR), dim3(256), lds, st, a);
+    const size_t lds = 2 * ACT_F4 * sizeof(float4) + (SIM_FE * 16 + SIM_FE * 8) * sizeof(float);
+    hipLaunchKernelGGL(k_sim_chain, dim3((a.E + SIM_FE - 1) / SIM_FE), dim3(256), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

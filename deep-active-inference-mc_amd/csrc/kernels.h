@@ -73,9 +73,11 @@ __device__ __forceinline__ bool row_live(const RowMask& k, int m) {
 //   intent 1: what the upstream NHWC code means -- only the top three rows (the reward bar) count, with target 1
 //             on their left half and 0 on the right half.
 __device__ __forceinline__ float reward_term(float pr, int oh, int ow, int H, int W, int intent) {
+#pragma clang fp contract(off)
     const float D1 = 1.00001f, D0 = 0.00001f;
     const bool one = intent ? (ow < W / 2) : (oh < H / 2);
-    const float t = one ? pr * logf(D1) + (1.0f - pr) * logf(D1 - 1.0f) : pr * logf(D0) + (1.0f - pr) * logf(D1);
+    // (explicit contraction: the same bits from every inlined copy)
+    const float t = one ? __builtin_fmaf(pr, logf(D1), (1.0f - pr) * logf(D1 - 1.0f)) : __builtin_fmaf(pr, logf(D0), (1.0f - pr) * logf(D1));
     return (intent && oh >= 3) ? 0.0f : t;
 }
 
@@ -123,6 +125,8 @@ struct DecBArgs {
     int reward0;          // groups with pidx == 0: 1 = reward log-likelihood, 0 = Bernoulli entropy sum (others: entropy)
     int store0;           // groups with pidx == 0 store their image at slot t*S + sample
     float* val;           // [batch] per-image pixel sum (entropy sum, or log-likelihood sum)
+    int parts;            // 1 = one workgroup per image; 4 = four (small launches): quarter sums go to valq [batch][4]
+    float* valq;
     float* po;            // [slots][rows_per_group][4096] stored images
     int reward_intent;    // 0 = the shipped port's NCHW-broadcast reward target, 1 = the upstream-intent variant (reward_term below)
 };
@@ -162,6 +166,7 @@ void launch_trans_post(const TransPostArgs& a, hipStream_t st);
 
 struct TermsArgs {
     const float* val;      // [D][3S][R] decoder per-image pixel sums (D1_i reward log-lik, D2A_j / D2B_j entropy)
+    const float* valq;     // nullable [D][3S][R][4]: the same as quarter sums (k_dec_b4 with four workgroups per image): val = (q0 + q1) + (q2 + q3)
     const float* tr;       // [D][2S][R][32]
     const float* enc;      // [D][S][R][32]
     int D, S, R;
@@ -233,6 +238,7 @@ struct SimChainArgs {
     float *s0_traj, *ps1_traj, *mean_traj, *lv_traj;   // [E][T][10]
     float* pi0;            // [E][T][pi_dim] one-hot
     float* Qpi0;           // nullable [E][pi_dim]
+    float* tr;             // nullable [2][E * T][32]: the trajectory core's transition rows (given T1 | T2 of the same input)
     int pi_dim;
     const uint32_t* ctr; uint32_t ctr_mul;      // optional device-side stage counter (GroupMap)
     const int32_t* ids;                         // optional episode identities: episode slot e is episode ids[e] of the un-compacted batch

@@ -255,16 +255,21 @@ __global__ void __launch_bounds__(256) k_terms(const TermsArgs a) {
         const int t = ti / S, i = ti - t * S;
         const int r = r0 + rr;
         if (r >= R) continue;
-        const float* val = a.val + (size_t)t * 3 * S * R;
+        const size_t vb = (size_t)t * 3 * S * R;
+        auto val = [&](size_t i) -> float {
+            if (!a.valq) return a.val[vb + i];
+            const float4 qv = reinterpret_cast<const float4*>(a.valq)[vb + i];
+            return (qv.x + qv.y) + (qv.z + qv.w);
+        };
         const float* tr = a.tr + (((size_t)t * 2 * S + i) * R + r) * 32 + 10;
         const float* en = a.enc + (((size_t)t * S + i) * R + r) * 32 + 10;
         float h = 0.f;
         for (int k = 0; k < 10; ++k) h += 0.5f * (C + tr[k]) + 0.5f * (C + en[k]);
-        p1s[idx * 4 + 0] = a.reward_div == 0.0f ? val[(size_t)i * R + r]
-                                                : val[(size_t)i * R + r] / a.reward_div * 10.0f;          // mean over the counted pixels * 10 (torchmodel.py:212)
+        p1s[idx * 4 + 0] = a.reward_div == 0.0f ? val((size_t)i * R + r)
+                                                : val((size_t)i * R + r) / a.reward_div * 10.0f;          // mean over the counted pixels * 10 (torchmodel.py:212)
         p1s[idx * 4 + 1] = -h;
-        p1s[idx * 4 + 2] = val[(size_t)(S + i) * R + r];
-        p1s[idx * 4 + 3] = val[(size_t)(2 * S + i) * R + r];
+        p1s[idx * 4 + 2] = val((size_t)(S + i) * R + r);
+        p1s[idx * 4 + 3] = val((size_t)(2 * S + i) * R + r);
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < D * TERMS_RB; idx += blockDim.x) {

@@ -281,7 +281,7 @@ class BatchedMCTS:
         # The simulation of an iteration (habit rollout from the leaf + G over its trajectory: ~1 ms of small launches) is
         # independent of the expansion of the same leaf (~6 ms of large ones): with more than a few episodes it runs on a second
         # stream through a replica context, so its launch-bound chain hides under the expansion's MFMA-bound kernels.
-        self.overlap = E >= 8 and getattr(params, 'overlap_simulate', True)
+        self.overlap = E >= int(getattr(params, 'overlap_min_episodes', 1)) and getattr(params, 'overlap_simulate', True)
         if self.overlap:
             self.sim_model = model.cached_replica()
             self.sim_stream = torch.cuda.Stream(device=dev)

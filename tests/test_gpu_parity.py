@@ -1016,6 +1016,35 @@ def test_batched_mcts_skipping_stopped_episodes_changes_nothing(models):
     assert mixed, 'no threshold stopped some episodes early: the fixture does not exercise the skip'
 
 
+def test_small_launch_image_split_is_bit_identical(models):
+    """k_dec_b4 with four workgroups per image (decoder launches of <= 128 images: the one-episode planner) == one workgroup per image,
+    bit for bit: the per-image sum is defined quarter-wise in both forms.  Checked on calculate_G (24 and 120 images), on a rollout and
+    on simulate_batch, with the images that are stored, and against a launch above the threshold that contains the same rows."""
+    m = models(1234, 1.15, 41)
+    s4 = torch.from_numpy(PX.uniform_fill(5, (4, 10), 91, -1, 1)).to(m.device)
+    starts = torch.from_numpy(PX.uniform_fill(6, (3, 10), 92, -1, 1)).to(m.device)
+    o = np.repeat(synth.make_frames(42, 1), 4, axis=0)
+    res = {}
+    try:
+        for split in (1, 0):
+            m.set_option('dec_split', split)
+            res[split] = (m.calculate_G(s4, m.pi_one_hot, samples=2, stage=3), m.calculate_G(s4, m.pi_one_hot, samples=10, stage=4),
+                          m.calculate_G_repeated(o, np.eye(4, dtype=np.float32), steps=2, samples=3, stage=6),
+                          m.simulate_batch(starts, 5, use_means=False, stage=9))
+    finally:
+        m.set_option('dec_split', 1)
+    for a_, b_ in zip(res[1], res[0]):
+        for x, y in zip(a_, b_):
+            if isinstance(x, (list, tuple)):
+                assert all(torch.equal(u, v) for u, v in zip(x, y))
+            else:
+                assert torch.equal(x, y)
+    # the same four rows inside a 40-row call (400 images: one workgroup per image) -- rows are keyed globally, so rows 0..3 are the same draws
+    big = torch.cat([s4, torch.from_numpy(PX.uniform_fill(7, (36, 10), 93, -1, 1)).to(m.device)], 0)
+    Gb = m.calculate_G(big, m.pi_one_hot.repeat(10, 1), samples=10, stage=4)
+    assert torch.equal(Gb[0][:4], res[1][1][0]) and torch.equal(Gb[4][:4], res[1][1][4])
+
+
 def test_rows_are_an_argument_of_the_call_not_context_state(models):
     """ABI 4 (efe_rows): the liveness mask and the row identities belong to ONE call.  A masked call leaves the next plain call on the same
     context untouched (with efe_set_row_mask it saw the mask until someone cleared it); a COMPACTED call -- only the live entries, as a

@@ -50,12 +50,12 @@ def test_hot_kernel_fits_its_occupancy_target(kernels, name):
 # a kernel not listed here must not spill more than SSPILL_DEFAULT.
 SSPILL = {
     'k_dec_bg<1>': 0, 'k_dec_bg<2>': 0, 'k_dec_bg<3>': 0,
-    'k_dec_b4': 4, 'k_dec_a': 0, 'k_fc4': 0, 'k_trans_fused': 0,
+    'k_dec_b4': 2, 'k_dec_a': 0, 'k_fc4': 0, 'k_trans_fused': 0,
     'k_convt_p<1, 4>': 0, 'k_convt_p<1, 8>': 0, 'k_convt_p<2, 4>': 0, 'k_convt_p<2, 8>': 5,
     'k_conv_e<1, 4>': 0, 'k_conv_e<2, 16>': 0,
     'k_enc_trunk': 26, 'k_head<16>': 25, 'k_head<32>': 22,      # (+4 / +10 with the row-identity pointer of ABI 4 among the kernel arguments)
     'k_final_g': 47,            # fallback of the generic decoder tail (option fuse_final_g = 0 / the resolution-32 variant)
-    'k_sim_chain': 126,         # latency-bound one-launch simulation chain (0.28 ms per planner iteration, beside the expansion)
+    'k_sim_chain': 131,         # latency-bound one-launch simulation chain (0.28 ms per planner iteration, beside the expansion)
 }
 SSPILL_DEFAULT = 0
 
