@@ -448,7 +448,7 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
     const int nchunks = (N + C - 1) / C;
     int* queues = ctx->allocT<int>((size_t)nchunks);        // one image-ticket counter per k_dec_a launch
     if (!queues) return 1;
-    if (hipMemsetAsync(queues, 0, (size_t)nchunks * sizeof(int), st) != hipSuccess) return ctx->fail("hipMemsetAsync failed");
+    if (!split && hipMemsetAsync(queues, 0, (size_t)nchunks * sizeof(int), st) != hipSuccess) return ctx->fail("hipMemsetAsync failed");      // (k_dec_a_s takes no tickets)
     for (int m0 = 0; m0 < N; m0 += C) {
         const int c = std::min(C, N - m0);
         ctx->cls = PROF_DEC_FC4;
@@ -456,7 +456,7 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         ctx->cls = PROF_CT2;
         DecAArgs da{};
         da.x4 = x4; da.y2 = y2; da.w1 = ctx->dec_ct[0].Wp; da.b1 = ctx->dec_ct[0].bias; da.w2 = ctx->dec_ct[1].Wp;
-        da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.live = live_of(nc, m0); da.queue = queues + m0 / C;
+        da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.live = live_of(nc, m0); da.queue = queues + m0 / C; da.parts = split ? 8 : 1;
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_dec_a(da, st);
         ctx->prof_end(e0, st);

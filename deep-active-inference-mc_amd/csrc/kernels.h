@@ -110,6 +110,7 @@ struct DecAArgs {
     const float* w2; const float* b2;
     int rows;
     RowMask live;
+    int parts;            // 1 = persistent, one image per workgroup pass; 8 = small launches, an image over eight workgroups (k_dec_a_s)
     int* queue;           // zero-initialised ticket counter of this launch: images beyond the first two per workgroup are claimed dynamically
 };
 // fused decoder, stage B: y2 -> ConvT(64,32,s2)+ReLU -> ConvT(32,1,s1)+Sigmoid -> per-image reduction (+ image store)
