@@ -450,6 +450,8 @@ def bench_single_episode(model, device, samples):
     p = daimc_amd.MCTS_Params()
     p.repeats, p.simulation_depth, p.threshold, p.use_means = 50, 5, 2.0, True
     out['decision_use_means_S1_reference_api'] = ms(lambda: daimc_amd.active_inference_mcts(model, frame[0], p, o_shape=(1, 64, 64)), 3)
+    p.host_tree = True            # the host-side Node tree (what a caller of Node.expand / select / backpropagate drives)
+    out['decision_use_means_S1_host_node_tree'] = ms(lambda: daimc_amd.active_inference_mcts(model, frame[0], p, o_shape=(1, 64, 64)), 3)
     for mode in (False, True):
         q = daimc_amd.MCTS_Params()
         q.repeats, q.simulation_depth, q.threshold, q.use_means, q.samples, q.use_graph = 50, 5, 2.0, False, samples, mode

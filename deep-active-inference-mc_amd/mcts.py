@@ -157,7 +157,13 @@ def _frames_nchw(model, frames, n, o_shape):
 
 
 def active_inference_mcts(model, frame, params, o_shape=(64, 64, 1)):
-    """One planning decision (mcts.py:150-195) -> (path, repeats_done, states_explored, all_paths, all_paths_G)."""
+    """One planning decision (mcts.py:150-195) -> (path, repeats_done, states_explored, all_paths, all_paths_G).
+    The decision runs on the device-resident planner (BatchedMCTS with one episode: tree statistics, selection, back-propagation and
+    the early stop are kernels, the simulation runs beside the expansion on a second stream) -- the same draws and the same results as
+    the host-side Node tree below, which `params.host_tree = True` selects (it is what Node.expand / select / backpropagate users get)."""
+    if not getattr(params, 'host_tree', False) and not (frame is None or (isinstance(frame, (list, tuple)) and len(frame) == 0)):
+        out, _ = active_inference_mcts_batch(model, torch.as_tensor(frame)[None], params, o_shape=o_shape)
+        return out[0]
     prev = torch.get_num_threads()
     torch.set_num_threads(1)        # pi_dim-sized host tensors: keep torch's intra-op pool out of it
     try:

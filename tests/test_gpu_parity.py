@@ -277,13 +277,15 @@ def test_mcts_vs_golden(golden, models, name):
     p = daimc_amd.MCTS_Params()
     p.repeats, p.simulation_depth, p.use_means, p.threshold = int(g['repeats']), int(g['simulation_depth']), bool(g['use_means']), float(g['threshold'])
     p.using_prior_for_exploration = (name == 'mcts_prior')
-    m._stage = int(g['stage'])
-    path, reps, explored, all_paths, all_G = daimc_amd.active_inference_mcts(m, torch.from_numpy(g['frame']), p, o_shape=(1, 64, 64))
-    assert reps == int(g['repeats_done']) and explored == int(g['states_explored'])
-    ref_paths = [[int(a) for a in row if a >= 0] for row in g['all_paths']]
-    assert [[int(a) for a in pth] for pth in all_paths] == ref_paths
-    np.testing.assert_allclose(np.array(all_G), g['all_paths_G'], atol=gtol(np.array([2800.0])))
-    assert [int(a) for a in path] == [int(a) for a in g['final_path']]
+    for host_tree in (False, True):          # the device-resident planner (default) and the host-side Node tree of the reference's API
+        p.host_tree = host_tree
+        m._stage = int(g['stage'])
+        path, reps, explored, all_paths, all_G = daimc_amd.active_inference_mcts(m, torch.from_numpy(g['frame']), p, o_shape=(1, 64, 64))
+        assert reps == int(g['repeats_done']) and explored == int(g['states_explored'])
+        ref_paths = [[int(a) for a in row if a >= 0] for row in g['all_paths']]
+        assert [[int(a) for a in pth] for pth in all_paths] == ref_paths
+        np.testing.assert_allclose(np.array(all_G), g['all_paths_G'], atol=gtol(np.array([2800.0])))
+        assert [int(a) for a in path] == [int(a) for a in g['final_path']]
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -468,7 +470,9 @@ def test_planners_at_benchmark_depth_vs_reference(golden, models, name):
         _check_deep(g, e, out[e], visits[e])
     # episode 0 through the reference-shaped single-episode API (Node / active_inference_mcts: all its noise rows start at 0) ...
     m._stage = int(g['stage'])
+    p.host_tree = True
     _check_deep(g, 0, daimc_amd.active_inference_mcts(m, frames[0], p, o_shape=(1, 64, 64)))
+    p.host_tree = False
     # ... and every episode planned alone by the lock-step planner at its global episode offset
     for e in range(E):
         m._stage = int(g['stage'])
