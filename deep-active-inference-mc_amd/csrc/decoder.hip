@@ -7,12 +7,13 @@
 //   k_dec_a :  x4[16x16x64] --LDS--> ConvT(64,64,s1)+ReLU --LDS (in place)--> ConvT(64,64,s2)+ReLU --> y2[32x32x64] (HBM)
 //   k_dec_b4:  y2 strips --LDS--> ConvT(64,32,s2)+ReLU (registers) --MFMA--> tap values of the 32->1 conv, horizontal sums in registers
 //              --LDS ring of H planes--> vertical gather + sigmoid + entropy / reward reduction (+ optional image store)
-// (the superseded forms of these kernels and their timing-experiment switches live under tools/ubench/variants/)
+//   k_dec_a_s / k_dec_b4<4>: the same kernels with an image over eight / four workgroups, for launches of <= 128 images
 //
-// LDS images are [pixel][64 ch] with the 16-byte channel-quad index XOR-swizzled by (pixel & 15), so the
-// ds_read_b128 of an MFMA B fragment (32 pixels x same quad) is bank-conflict free without padding
-// (cdna_hip_programming.md T2).  Weights are read as pre-packed A fragments straight from L2 (1 KiB coalesced
-// per wave-load, shared by all workgroups).  fp32 MFMA (v_mfma_f32_32x32x2_f32): exact fp32 numerics.
+// LDS images are [pixel][17 float4 slots]: the 16 channel quads of a pixel plus one slot of padding, so that the ds_read_b128 of an
+// MFMA B fragment (32 pixels x same quad) is bank-conflict free (16 consecutive pixels cover the 16 bank quads: 17 p mod 16 = p) and a
+// fragment address is pixel base + an immediate (k_fc4's batch tile alone is still XOR-swizzled).  Weights are read as pre-packed A
+// fragments straight from L2 (1 KiB coalesced per wave-load, shared by all workgroups).  fp32 MFMA (v_mfma_f32_32x32x2_f32 and the
+// 4x4x1 16-block form): exact fp32 numerics.
 #include "mfma_pipe.h"
 
 namespace efe {

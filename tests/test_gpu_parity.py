@@ -332,7 +332,7 @@ def test_chunking_invariance(models):
 
 
 def test_no_experiment_switches_in_the_product_library(models):
-    """the wrong-result timing switches and superseded kernel forms live under tools/ubench/variants/: the shipped library has no
+    """the wrong-result timing switches are patches under tools/ubench/patches/ (tools/ubench/build_alt.py): the shipped library has no
     option that reaches them"""
     m = models(1234, 1.15, 13)
     for opt in ('dbg_a', 'dbg_b', 'tl_buf'):
