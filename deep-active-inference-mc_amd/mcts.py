@@ -320,7 +320,7 @@ class BatchedMCTS:
         """gather the live episodes into a dense batch for the following iterations (called where the host has just read the active count:
         no extra synchronisation).  Worth it from ~8 % lost episodes: the dense layers, which cannot skip single rows, shrink too."""
         cur = self.E if self._ids is None else len(self._ids[1])
-        if n_live <= 0 or n_live > 0.92 * cur:
+        if n_live <= 0 or n_live > (1.0 - float(getattr(self.p, 'compact_min_dead', 0.08))) * cur:
             return
         idx = torch.nonzero(self.active).flatten()
         self._ids = (idx.to(torch.int32).contiguous(), idx.cpu().tolist(), idx)
@@ -430,7 +430,7 @@ class BatchedMCTS:
         # every tree update); the host only needs to know when ALL episodes have stopped, to end the loop early.  It looks at
         # the active count every CHECK iterations instead of synchronising with the GPU in each one -- and never when the
         # threshold cannot be exceeded (max - mean of a distribution over A actions is below 1 - 1/A).
-        CHECK = 8
+        CHECK = int(getattr(p, 'check_every', 8))
         can_stop = float(p.threshold) < 1.0 - 1.0 / A
         use_graph = bool(getattr(p, 'use_graph', False))
         if use_graph and p.repeats > 0:

@@ -23,4 +23,4 @@ def run(th, skip, n=3, **kw):
     its = [o[1] for o in out]
     print(f'threshold {th} skip {skip} {kw}: {1e3 * dt:.1f} ms per batch = {E / dt:.1f} decisions/s; iterations mean {np.mean(its):.1f} min {min(its)} max {max(its)}; '
           f'work fraction {np.sum(its) / (50.0 * E):.3f}', flush=True)
-run(2.0, True); run(0.5, True); run(0.5, False); run(2.0, True); run(0.5, True)
+run(2.0, True); run(0.5, True); run(0.5, True, compact_stopped=False); run(0.5, True, check_every=4, compact_min_dead=0.03); run(0.5, True, check_every=2, compact_min_dead=0.015); run(0.5, True, check_every=1, compact_min_dead=0.015); run(2.0, True); run(0.5, True)
