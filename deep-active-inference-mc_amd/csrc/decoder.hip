@@ -612,8 +612,10 @@ void launch_dec_b(const DecBArgs& a, hipStream_t st) {
 // features.  The feature steps (ceil(mtiles / 8)) are dealt to 8 groups of SPG = ceil(steps / 8) consecutive steps (8 x 8 for 16384).
 // ---------------------------------------------------------------------------------------------------------
 __host__ __device__ inline int fc4_spg(int mtiles) { return ((mtiles + 7) / 8 + 7) / 8; }
+template <int NT>          // 32-row batch tiles per workgroup tile: 2 (64 rows), or 1 for launches of <= 32 rows (the one-episode planner's trajectories)
 __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float4 sm[];        // [64 rows][64 quads], quad ^= row & 15
+    constexpr int RT = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) float4 sm[];        // [RT rows][64 quads], quad ^= row & 15
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -625,14 +627,14 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
     const int fgrp = blockIdx.x & 7;
     const int nper = gridDim.x >> 3, k = blockIdx.x >> 3;
     const int SPG = fc4_spg(a.mtiles);
-    const int nsteps = ((a.n_pix + 63) / 64) * SPG;                    // (row tile, step) pairs of this feature group
+    const int nsteps = ((a.n_pix + RT - 1) / RT) * SPG;                // (row tile, step) pairs of this feature group
     const int q0 = (int)(((long)nsteps * k) / nper), q1 = (int)(((long)nsteps * (k + 1)) / nper);
     f32x4* smv = reinterpret_cast<f32x4*>(sm);
     const float4* Wl = reinterpret_cast<const float4*>(a.Wp);
-    auto xaddr = [&](int t, int (&bs)[2], int (&sw)[2], int& wt) {
+    auto xaddr = [&](int t, int (&bs)[NT], int (&sw)[NT], int& wt) {
         wt = t;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) { bs[nt] = (nt * 32 + j) * 64 + t * 16; sw[nt] = j & 15; }
+        for (int nt = 0; nt < NT; ++nt) { bs[nt] = (nt * 32 + j) * 64 + t * 16; sw[nt] = j & 15; }
     };
     int cur_rt = -1;
     uint32_t krow[2] = {0, 0}, kstream[2] = {0, 0}, kstage[2] = {0, 0};
@@ -640,14 +642,14 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
 #pragma unroll 1
     for (int q = q0; q < q1; ++q) {
         const int rt = q / SPG, fs = q - rt * SPG;
-        const int row0 = rt * 64;
+        const int row0 = rt * RT;
         if (rt != cur_rt) {                                            // (re)stage the 64-row tile: at most twice more than once per workgroup
             if (cur_rt >= 0) __syncthreads();                          // every wave is done reading the previous tile
             cur_rt = rt;
             const f32x4* X = reinterpret_cast<const f32x4*>(a.X);
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int idx = it * 256 + tid;                        // 64 rows x 64 quads
+            for (int it = 0; it < 8 * NT; ++it) {
+                const int idx = it * 256 + tid;                        // RT rows x 64 quads
                 const int r = idx >> 6, c4 = idx & 63;
                 const int gr = row0 + r;
                 smv[r * 64 + (c4 ^ (r & 15))] = (gr < a.n_pix) ? X[(size_t)gr * 64 + c4] : (f32x4)(0.f);
@@ -655,7 +657,7 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
             __syncthreads();
             // dropout keys of this lane's two rows
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 const int m = row0 + nt * 32 + j;
                 rv[nt] = m < a.n_pix;
                 const int mg = a.m0 + (rv[nt] ? m : 0);
@@ -667,11 +669,11 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
         }
         const int mt0 = (fgrp * SPG + fs) * 8 + 2 * w;                 // this wave's first 32-feature tile
         if (mt0 >= a.mtiles) continue;                                 // wave-uniform: past the last feature tile (mtiles is even)
-        f32x16 acc[2][2];
+        f32x16 acc[2][NT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
         // the step's bias quads are requested BEFORE the contraction: a load placed between the stores would need
@@ -681,9 +683,9 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) bq[mt][g4] = *reinterpret_cast<const float4*>(a.bias + (mt0 + mt) * 32 + 8 * g4 + 4 * h);
-        tap_loop<2, 2>(acc, 4, Wl, sm, h, xaddr, DenseWIdx{mt0});
+        tap_loop<2, NT>(acc, 4, Wl, sm, h, xaddr, DenseWIdx{mt0});
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             if (!rv[nt]) continue;
             const uint4 rnd = noise_words(a.k0, a.k1, a.tag, (uint32_t)((mt0 * 32) >> 7), krow[nt], kstream[nt], kstage[nt]);
             float* yp = a.Y + (size_t)(row0 + nt * 32 + j) * a.ldy;
@@ -706,9 +708,14 @@ __global__ void __launch_bounds__(256, 2) k_fc4(const GemmArgs a) {
 
 void launch_fc4(const GemmArgs& a, hipStream_t st) {
     // persistent: 2 workgroups per CU (64 KiB LDS each), 8 feature groups x (up to) 64 workgroups, each with >= 1 (row tile, step) pair
+    if (a.n_pix <= 32) {               // one 32-row tile: half the MFMA work of a 64-row tile whose second half would be padding
+        const int nsteps = fc4_spg(a.mtiles);
+        hipLaunchKernelGGL(k_fc4<1>, dim3(8 * (nsteps < 64 ? nsteps : 64)), dim3(256), 32 * 64 * sizeof(float4), st, a);
+        return;
+    }
     const int nsteps = ((a.n_pix + 63) / 64) * fc4_spg(a.mtiles);
     const int nper = nsteps < 64 ? nsteps : 64;
-    hipLaunchKernelGGL(k_fc4, dim3(8 * nper), dim3(256), 64 * 64 * sizeof(float4), st, a);
+    hipLaunchKernelGGL(k_fc4<2>, dim3(8 * nper), dim3(256), 64 * 64 * sizeof(float4), st, a);
 }
 
 }  // namespace efe

@@ -1017,6 +1017,24 @@ int efe_mcts_backprop(efe_ctx* ctx, const efe_mcts_tree* tree, const int32_t* pa
     return finish(ctx);
 }
 
+int efe_mcts_step(efe_ctx* ctx, const efe_mcts_tree* tree, const int32_t* prev_path_act, const int32_t* prev_path_len, const float* sims, int n_sims,
+                  const float* q0, float* prev_g_out, uint8_t* prev_active_out, uint8_t* active, int32_t* stop_at, int repeat, float threshold,
+                  int32_t* n_active, float C, int use_prior, int max_depth, int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf,
+                  float* leaf_s, float* leaf_s_rep, void* stream) {
+    if (!ctx) return 1;
+    EFE_LOCK(ctx);
+    MctsTree t;
+    if (mcts_tree(ctx, tree, t)) return 1;
+    if (!active || !stop_at || !n_active || !path_nodes || !path_act || !path_len || !leaf || !leaf_s || !leaf_s_rep || max_depth < 1 ||
+        (prev_path_len && (!prev_path_act || !sims || n_sims < 1 || !q0 || !prev_g_out || !prev_active_out)))
+        return ctx->fail("efe_mcts_step: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    MctsStepArgs a{prev_path_act, prev_path_len, sims, n_sims, q0, prev_g_out, prev_active_out, active, stop_at, repeat, threshold, n_active,
+                   C, use_prior, max_depth, path_nodes, path_act, path_len, leaf, leaf_s, leaf_s_rep};
+    launch_mcts_step(t, a, (hipStream_t)stream);
+    return finish(ctx);
+}
+
 int efe_mcts_stop(efe_ctx* ctx, const efe_mcts_tree* tree, uint8_t* active, int32_t* stop_at, int repeat, float threshold,
                   int32_t* n_active, void* stream) {
     if (!ctx) return 1;
@@ -1278,7 +1296,7 @@ static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_
                            const float* eps, float* G, const uint8_t* mask, const int32_t* ids, int mask_div, float* pre_tr, hipStream_t st) {
     float* x = ctx->allocT<float>((size_t)T * 16);
     if (!x) return 1;
-    launch_pack_x(pi0_traj, s0_traj, x, T, ctx->pi_dim, S_DIM, st);
+    if (!pre_tr) launch_pack_x(pi0_traj, s0_traj, x, T, ctx->pi_dim, S_DIM, st);       // (the transition input: not needed when k_sim_chain has run both transitions)
     CoreIO io{};
     io.x0 = x; io.R = T; io.D = 1; io.S = 1; io.mean_mode = 0; io.carry_mean = 0;
     io.k0 = k0; io.k1 = k1; io.stage0 = stage; io.row_offset = row_offset; io.eps = eps;

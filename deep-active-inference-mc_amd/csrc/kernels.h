@@ -197,6 +197,16 @@ void launch_mcts_backprop(const MctsTree& t, const int32_t* path_nodes, const in
                           float* g_out, uint8_t* active_out, hipStream_t st);
 void launch_mcts_stop(const MctsTree& t, uint8_t* active, int32_t* stop_at, int repeat, const int32_t* repeat_dev, float threshold,
                       int32_t* n_active, hipStream_t st);          // repeat_dev != nullptr: the iteration index is read on the device
+struct MctsStepArgs {
+    // back-propagation of the previous iteration (prev_path_len == nullptr: none); path_nodes / leaf still hold that iteration's selection
+    const int32_t* prev_path_act; const int32_t* prev_path_len; const float* sims; int n_sims; const float* q0; float* prev_g_out; uint8_t* prev_active_out;
+    // early stop of this iteration
+    uint8_t* active; int32_t* stop_at; int repeat; float threshold; int32_t* n_active;
+    // selection
+    float C; int use_prior, max_depth;
+    int32_t *path_nodes, *path_act, *path_len, *leaf; float *leaf_s, *leaf_s_rep;
+};
+void launch_mcts_step(const MctsTree& t, const MctsStepArgs& a, hipStream_t st);
 void launch_mcts_record(const int32_t* iter, int n_rows, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len, const float* cur_g,
                         const uint8_t* cur_active, int32_t* H_act, int32_t* H_len, float* H_g, uint8_t* H_active, hipStream_t st);
 void launch_counter_add(int32_t* counter, int delta, hipStream_t st);

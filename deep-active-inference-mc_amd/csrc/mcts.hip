@@ -22,11 +22,9 @@ __device__ __forceinline__ int argmax_nan_first(const float* v, int n) {        
     return best;
 }
 
-__global__ void k_mcts_select(const MctsTree t, const uint8_t* active, float C, int use_prior, int max_depth,
-                              int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf,
-                              float* leaf_s /*[E][s_dim]*/, float* leaf_s_rep /*[E*A][s_dim]*/) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= t.E) return;
+__device__ __forceinline__ void mcts_select_one(const MctsTree& t, int e, const uint8_t* active, float C, int use_prior, int max_depth,
+                                                int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf,
+                                                float* leaf_s /*[E][s_dim]*/, float* leaf_s_rep /*[E*A][s_dim]*/) {
     const int A = t.A;
     int cur = 0, len = 0;
     for (int d = 0; d < max_depth; ++d) { path_nodes[(size_t)e * max_depth + d] = 0; path_act[(size_t)e * max_depth + d] = 0; }
@@ -65,6 +63,13 @@ __global__ void k_mcts_select(const MctsTree t, const uint8_t* active, float C, 
         for (int a = 0; a < A; ++a) leaf_s_rep[((size_t)e * A + a) * t.s_dim + k] = v;
     }
 }
+__global__ void k_mcts_select(const MctsTree t, const uint8_t* active, float C, int use_prior, int max_depth,
+                              int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf,
+                              float* leaf_s, float* leaf_s_rep) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= t.E) return;
+    mcts_select_one(t, e, active, C, use_prior, max_depth, path_nodes, path_act, path_len, leaf, leaf_s, leaf_s_rep);
+}
 
 // Node.expand bookkeeping (mcts.py:64-86): W -= G, N += 1, pi_dim children with the predicted states
 __global__ void k_mcts_expand(const MctsTree t, int32_t* n_nodes, const int32_t* nodes, const uint8_t* mask, const float* G,
@@ -87,11 +92,9 @@ __global__ void k_mcts_expand(const MctsTree t, int32_t* n_nodes, const int32_t*
 
 // after the simulations: habit prior of the leaf, g = mean of the simulated G (left to right), back-propagation along the
 // selected path (mcts.py:91-99, 186-191), and the iteration's history row
-__global__ void k_mcts_backprop(const MctsTree t, const int32_t* path_nodes, const int32_t* path_act, const int32_t* path_len,
-                                const int32_t* leaf, const uint8_t* active, const float* sims /*[R][E]*/, int R, const float* q0 /*[E][A]*/,
-                                int max_depth, float* g_out /*[E]*/, uint8_t* active_out /*[E]*/) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= t.E) return;
+__device__ __forceinline__ void mcts_backprop_one(const MctsTree& t, int e, const int32_t* path_nodes, const int32_t* path_act, const int32_t* path_len,
+                                                  const int32_t* leaf, const uint8_t* active, const float* sims /*[R][E]*/, int R, const float* q0 /*[E][A]*/,
+                                                  int max_depth, float* g_out /*[E]*/, uint8_t* active_out /*[E]*/) {
     float g = 0.f;
     for (int r = 0; r < R; ++r) g = (r == 0) ? sims[(size_t)r * t.E + e] : g + sims[(size_t)r * t.E + e];
     g = g / (float)R;
@@ -107,12 +110,18 @@ __global__ void k_mcts_backprop(const MctsTree t, const int32_t* path_nodes, con
         t.N[o] += 1.0f;
     }
 }
+__global__ void k_mcts_backprop(const MctsTree t, const int32_t* path_nodes, const int32_t* path_act, const int32_t* path_len,
+                                const int32_t* leaf, const uint8_t* active, const float* sims, int R, const float* q0,
+                                int max_depth, float* g_out, uint8_t* active_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= t.E) return;
+    mcts_backprop_one(t, e, path_nodes, path_act, path_len, leaf, active, sims, R, q0, max_depth, g_out, active_out);
+}
 
 // early stop (mcts.py:130-131, 176): an episode is done when max(N/sum N) - mean(N/sum N) at the root exceeds the threshold
-__global__ void k_mcts_stop(const MctsTree t, uint8_t* active, int32_t* stop_at, int repeat, const int32_t* repeat_dev, float threshold,
-                            int32_t* n_active) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= t.E || !active[e]) return;
+__device__ __forceinline__ void mcts_stop_one(const MctsTree& t, int e, uint8_t* active, int32_t* stop_at, int repeat, const int32_t* repeat_dev,
+                                              float threshold, int32_t* n_active) {
+    if (!active[e]) return;
     const int A = t.A;
     const float* n = t.N + (size_t)e * t.cap * A;            // root = node 0
     float sum = 0.f;
@@ -128,6 +137,27 @@ __global__ void k_mcts_stop(const MctsTree t, uint8_t* active, int32_t* stop_at,
     const float crit = dmax - dsum / (float)A;
     if (crit > threshold) { active[e] = 0; stop_at[e] = repeat_dev ? *repeat_dev : repeat; }
     else atomicAdd(n_active, 1);
+}
+__global__ void k_mcts_stop(const MctsTree t, uint8_t* active, int32_t* stop_at, int repeat, const int32_t* repeat_dev, float threshold,
+                            int32_t* n_active) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= t.E) return;
+    mcts_stop_one(t, e, active, stop_at, repeat, repeat_dev, threshold, n_active);
+}
+// One launch for the tree work between two iterations' engine calls: back-propagation of the previous iteration (skipped for the
+// first), early-stop test, selection of the next leaf -- the three one-thread-per-episode kernels above, in that order, per episode.
+// n_active is a zero-initialised word of its own per iteration (no memset launch).
+__global__ void k_mcts_step(const MctsTree t, MctsStepArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= t.E) return;
+    if (a.prev_path_len)
+        mcts_backprop_one(t, e, a.path_nodes, a.prev_path_act, a.prev_path_len, a.leaf, a.active, a.sims, a.n_sims, a.q0, a.max_depth, a.prev_g_out,
+                          a.prev_active_out);
+    mcts_stop_one(t, e, a.active, a.stop_at, a.repeat, nullptr, a.threshold, a.n_active);
+    mcts_select_one(t, e, a.active, a.C, a.use_prior, a.max_depth, a.path_nodes, a.path_act, a.path_len, a.leaf, a.leaf_s, a.leaf_s_rep);
+}
+void launch_mcts_step(const MctsTree& t, const MctsStepArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_mcts_step, dim3((t.E + 63) / 64), dim3(64), 0, st, t, a);
 }
 
 void launch_mcts_select(const MctsTree& t, const uint8_t* active, float C, int use_prior, int max_depth, int32_t* path_nodes,

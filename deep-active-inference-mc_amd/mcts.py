@@ -267,6 +267,7 @@ class BatchedMCTS:
         self.sims = torch.zeros(max(1, params.simulation_repeats), E, device=dev)
         self.stop_at = torch.full((E,), -1, dtype=torch.int32, device=dev)
         self.n_active = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.n_active_it = torch.zeros(R + 1, dtype=torch.int32, device=dev)       # efe_mcts_step: one word per iteration
         self.q0 = torch.zeros(E, A, device=dev)
         # graph form of the loop (see _loop_graph): the iteration index / noise stage live in device words, the iteration's history row
         # is written to fixed scratch rows and copied into the history by a kernel, every buffer an iteration touches is persistent
@@ -283,6 +284,7 @@ class BatchedMCTS:
         # expansion / simulation results of a COMPACTED call (only the live episodes, efe_rows.ids) are scattered into these full-size rows
         self.G_full = torch.zeros(E * A, device=dev)
         self.ps_full = torch.zeros(E * A, model.s_dim, device=dev)
+        self._sim_out = None
         self._ids = None                    # (int32 device tensor of live episode indices, the same as a host list, int64 copy for torch indexing)
         # The simulation of an iteration (habit rollout from the leaf + G over its trajectory: ~1 ms of small launches) is
         # independent of the expansion of the same leaf (~6 ms of large ones): with more than a few episodes it runs on a second
@@ -348,15 +350,19 @@ class BatchedMCTS:
         G, ps_next = G.contiguous(), ps_next.contiguous()
         self._call(m._engine.lib.efe_mcts_expand, p_(self.n_nodes), p_(nodes), p_(mask), p_(G), p_(ps_next))
 
-    def _simulate(self, model, mask, stage_of, eps_stage_of=lambda r: None):
-        """the iteration's simulations from the selected leaves (mcts.py:186-189) -> self.sims, self.q0"""
+    def _simulate(self, model, mask, stage_of, eps_stage_of=lambda r: None, direct=False):
+        """the iteration's simulations from the selected leaves (mcts.py:186-189) -> self.sims, self.q0 (direct: with one simulation per
+        iteration and an un-compacted batch the engine's own output tensors are handed to the back-propagation: self._sim_out, no copies)"""
         p = self.p
         rows = self._rows(mask, 1)
         leaf_s = self.leaf_s if self._ids is None else self.leaf_s.index_select(0, self._ids[2])
+        self._sim_out = None
         for r in range(p.simulation_repeats):
             G, _, q0 = model.simulate_batch(leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0, stage=stage_of(r),
                                             eps_stage=eps_stage_of(r), rows=rows)
-            if self._ids is None:
+            if direct and p.simulation_repeats == 1 and self._ids is None:
+                self._sim_out = (G, q0)          # (kept until the next iteration's simulation, which starts behind this one's back-propagation)
+            elif self._ids is None:
                 self.sims[r].copy_(G)
                 self.q0.copy_(q0)
             else:
@@ -435,32 +441,46 @@ class BatchedMCTS:
         use_graph = bool(getattr(p, 'use_graph', False))
         if use_graph and p.repeats > 0:
             n_iter = self._loop_graph(st0, per_it, can_stop, CHECK)
+        # The tree work between two iterations' engine calls is ONE launch (efe_mcts_step): back-propagation of the previous iteration, early
+        # stop, selection -- per episode in the reference's order (mcts.py:176-191).  The active count of iteration r lands in its own
+        # zero-initialised word (no memset launch); the last iteration's back-propagation follows the loop.
+        self.n_active_it.zero_()
+        pending = None                                   # (iteration, sims, q0) whose back-propagation is still to run
         for repeat in range(0 if not use_graph else p.repeats, p.repeats):
-            self._call(lib.efe_mcts_stop, p_(active), p_(self.stop_at), repeat, float(p.threshold), p_(self.n_active))
+            if pending is None:
+                prev = (None, None, None, 1, None, None, None)
+            else:
+                pr, sims_t, q0_t = pending
+                prev = (p_(self.H_act[pr]), p_(self.H_len[pr]), p_(sims_t), int(p.simulation_repeats), p_(q0_t), p_(self.H_g[pr]), p_(self.H_active[pr]))
+            self._call(lib.efe_mcts_step, prev[0], prev[1], prev[2], prev[3], prev[4], prev[5], prev[6], p_(active), p_(self.stop_at), repeat,
+                       float(p.threshold), p_(self.n_active_it[repeat:]), float(p.C), 1 if p.using_prior_for_exploration else 0, self.max_depth,
+                       p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))
+            pending = None
             if can_stop and (repeat % CHECK == 0 or E == 1):
-                n_live = int(self.n_active.item())
+                n_live = int(self.n_active_it[repeat].item())
                 if n_live == 0:
                     break
                 if compact:
                     self._compact(n_live)
-            self._call(lib.efe_mcts_select, p_(active), float(p.C), 1 if p.using_prior_for_exploration else 0, self.max_depth,
-                       p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))
             st_exp = st0 + repeat * per_it
             if self.overlap:
                 cur = torch.cuda.current_stream(m.device)
                 self.ev_sel.record(cur)
                 with torch.cuda.stream(self.sim_stream):
                     self.sim_stream.wait_event(self.ev_sel)              # leaf_s is ready; the previous back-propagation has read sims / q0
-                    self._simulate(self.sim_model, active if skip else None, lambda r: st_exp + 1 + r)
+                    self._simulate(self.sim_model, active if skip else None, lambda r: st_exp + 1 + r, direct=True)
                     self.ev_sim.record(self.sim_stream)
                 self._expand(self.leaf, active, self.leaf_rep, stage=st_exp, use_mask=skip)
                 cur.wait_event(self.ev_sim)
             else:
                 self._expand(self.leaf, active, self.leaf_rep, stage=st_exp, use_mask=skip)
-                self._simulate(m, active if skip else None, lambda r: st_exp + 1 + r)
-            self._call(lib.efe_mcts_backprop, p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(active),
-                       p_(self.sims), int(p.simulation_repeats), p_(self.q0), self.max_depth, p_(self.H_g[repeat]), p_(self.H_active[repeat]))
+                self._simulate(m, active if skip else None, lambda r: st_exp + 1 + r, direct=True)
+            pending = (repeat,) + (self._sim_out if self._sim_out is not None else (self.sims, self.q0))
             n_iter += 1
+        if pending is not None:
+            pr, sims_t, q0_t = pending
+            self._call(lib.efe_mcts_backprop, p_(self.path_nodes), p_(self.H_act[pr]), p_(self.H_len[pr]), p_(self.leaf), p_(active),
+                       p_(sims_t), int(p.simulation_repeats), p_(q0_t), self.max_depth, p_(self.H_g[pr]), p_(self.H_active[pr]))
         # read the history back once, then plain Python lists on the host: per-element torch indexing here cost ~30 ms per 64-episode
         # decision, per-element numpy indexing 2.6 ms (during which the GPU has nothing queued); whole-array tolist() + list slicing 1.0 ms
         H_act, H_len = self.H_act[:n_iter].cpu().numpy(), self.H_len[:n_iter].cpu().numpy()
