@@ -349,16 +349,21 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
     frames = synth_frames(E, device, seed=200 + rank)
     last = {}
 
+    work = []                                        # per decision batch: fraction of the 50 x E episode-iterations that ran
+
     def step(_k):
         out, distn = daimc_amd.active_inference_mcts_batch(model, frames, p, o_shape=(1, 64, 64), episode_offset=rank * E)
+        work.append(sum(o[1] for o in out) / (50.0 * E))
         last['out'], last['P'] = out, distn.to(device)
         rk.gather(last['P'], world * E)
         return out
 
     for k in range(warmup):
         step(k)
+    del work[:]
     with ClockSampler(device) as clk:
         regions, local, _ = timed_regions(step, steps, 0, rk, min_total_s=min_total_s, max_regions=12)
+    work_timed = list(work)
     per_rank_ms = rk.per_rank(1e3 * statistics.median(local) / steps)
     dt = statistics.median(regions)
     dec = world * E * steps / dt
@@ -371,7 +376,8 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
                                   f'early-stop threshold {threshold} (BASELINE configs[{2 if world == 1 else 3}])'
                                   + (' + all_gather of the root visit distributions' if rk.on else ''),
                       'episodes_per_gpu': E, 'threshold': threshold},
-           'iterations_done_mean': float(np.mean(iters)), 'iterations_done_min': int(min(iters))}
+           'iterations_done_mean': float(np.mean(iters)), 'iterations_done_min': int(min(iters)),
+           'work_fraction_mean': float(np.mean(work_timed)), 'work_fraction_per_decision_batch': [round(x, 4) for x in work_timed]}
     out.update(rk.info())
     if rk.on:
         out['per_rank_ms_per_step'] = [round(x, 3) for x in per_rank_ms]
