@@ -802,11 +802,11 @@ def main():
         # every rank runs the extras (they are collective at N > 1); rank 0 attaches them
         key = 'mcts_cfg3' if world == 1 else 'mcts_cfg4_sharded'
         mc = bench_mcts(a, model, device, rk, 3, 1, with_cpu and world == 1)
-        mc05 = bench_mcts(a, model, device, rk, 3, 1, False, threshold=0.5, min_total_s=1.0)
+        mc05 = bench_mcts(a, model, device, rk, 3, 2, False, threshold=0.5, min_total_s=2.5)
         # the same batch with every iteration run again RIGHT BEHIND it: the board slows by 3 - 5 % over the first minute of planner legs
         # (clock / temperature), so the early-stop line is compared with an adjacent full-work measurement, not with the leg run a minute earlier
         a_np = argparse.Namespace(**dict(vars(a), no_prof=True))
-        mcadj = bench_mcts(a_np, model, device, rk, 3, 1, False, threshold=2.0, min_total_s=1.0)
+        mcadj = bench_mcts(a_np, model, device, rk, 3, 1, False, threshold=2.0, min_total_s=2.0)
         mc05['full_work_adjacent'] = {'value': mcadj['value'], 'ms_per_step': mcadj['ms_per_step'], 'timed_regions': mcadj['timed_regions']}
         mc05['speedup_vs_adjacent_full_work'] = mc05['value'] / mcadj['value']
         single = bench_single_episode(model, device, a.samples) if world == 1 else None
