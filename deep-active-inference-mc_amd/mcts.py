@@ -284,6 +284,9 @@ class BatchedMCTS:
         # expansion / simulation results of a COMPACTED call (only the live episodes, efe_rows.ids) are scattered into these full-size rows
         self.G_full = torch.zeros(E * A, device=dev)
         self.ps_full = torch.zeros(E * A, model.s_dim, device=dev)
+        self.h_active = torch.zeros(4, E, dtype=torch.uint8).pin_memory()      # snapshots of `active` for the lagged host check
+        self.ev_snap = [torch.cuda.Event() for _ in range(4)]
+        self.h_ids = torch.zeros(4, E, dtype=torch.int64).pin_memory()
         self._sim_out = None
         self._ids = None                    # (int32 device tensor of live episode indices, the same as a host list, int64 copy for torch indexing)
         # The simulation of an iteration (habit rollout from the leaf + G over its trajectory: ~1 ms of small launches) is
@@ -322,10 +325,22 @@ class BatchedMCTS:
         """gather the live episodes into a dense batch for the following iterations (called where the host has just read the active count:
         no extra synchronisation).  Worth it from ~8 % lost episodes: the dense layers, which cannot skip single rows, shrink too."""
         cur = self.E if self._ids is None else len(self._ids[1])
-        if n_live <= 0 or n_live > (1.0 - float(getattr(self.p, 'compact_min_dead', 0.08))) * cur:
+        if n_live <= 0 or n_live > (1.0 - float(getattr(self.p, 'compact_min_dead', 0.03))) * cur:
             return
         idx = torch.nonzero(self.active).flatten()
         self._ids = (idx.to(torch.int32).contiguous(), idx.cpu().tolist(), idx)
+
+    def _compact_host(self, snap, n_live):
+        """the same from a host snapshot of `active` (the lagged check): no device synchronisation at all"""
+        cur = self.E if self._ids is None else len(self._ids[1])
+        if n_live <= 0 or n_live > (1.0 - float(getattr(self.p, 'compact_min_dead', 0.03))) * cur:
+            return
+        ids = np.flatnonzero(snap)
+        self._h_ids_k = (getattr(self, '_h_ids_k', -1) + 1) % self.h_ids.shape[0]           # (pinned staging, asynchronous upload: a pageable
+        stage = self.h_ids[self._h_ids_k]                                                   # source would synchronise the whole stream)
+        stage[:len(ids)] = torch.from_numpy(ids)
+        idx = stage[:len(ids)].to(self.active.device, non_blocking=True)
+        self._ids = (idx.to(torch.int32).contiguous(), ids.tolist(), idx)
 
     def _expand(self, nodes, mask, states_rep, stage=None, eps_stage=None, use_mask=True):
         """ONE engine call over E x pi_dim rows (Node.expand, mcts.py:64-86); tree bookkeeping only where mask[e]"""
@@ -445,6 +460,8 @@ class BatchedMCTS:
         # stop, selection -- per episode in the reference's order (mcts.py:176-191).  The active count of iteration r lands in its own
         # zero-initialised word (no memset launch); the last iteration's back-propagation follows the loop.
         self.n_active_it.zero_()
+        lagged = bool(getattr(p, 'lagged_check', True)) and E > 1
+        LAG = 2
         pending = None                                   # (iteration, sims, q0) whose back-propagation is still to run
         for repeat in range(0 if not use_graph else p.repeats, p.repeats):
             if pending is None:
@@ -456,7 +473,27 @@ class BatchedMCTS:
                        float(p.threshold), p_(self.n_active_it[repeat:]), float(p.C), 1 if p.using_prior_for_exploration else 0, self.max_depth,
                        p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))
             pending = None
-            if can_stop and (repeat % CHECK == 0 or E == 1):
+            if can_stop and E == 1:                       # one episode: stop the loop in the iteration the episode stops in
+                if int(self.n_active_it[repeat].item()) == 0:
+                    break
+            elif can_stop and lagged:
+                # The host follows the device LAG iterations behind: a snapshot of `active` is copied to pinned memory behind every
+                # step kernel, and before enqueuing iteration r the host waits for the snapshot of iteration r - LAG only (LAG
+                # iterations of work stay queued: the GPU never drains, unlike a read of the current count).  From that snapshot it
+                # ends the loop and re-compacts the batch (episodes stopped since then are in the batch but masked).
+                slot = repeat % len(self.ev_snap)
+                self.h_active[slot].copy_(active, non_blocking=True)
+                self.ev_snap[slot].record(torch.cuda.current_stream(m.device))
+                if repeat >= LAG:
+                    ls = (repeat - LAG) % len(self.ev_snap)
+                    self.ev_snap[ls].synchronize()
+                    snap = self.h_active[ls].numpy()
+                    n_live = int(snap.sum())
+                    if n_live == 0:
+                        break
+                    if compact:
+                        self._compact_host(snap, n_live)
+            elif can_stop and repeat % CHECK == 0:
                 n_live = int(self.n_active_it[repeat].item())
                 if n_live == 0:
                     break
