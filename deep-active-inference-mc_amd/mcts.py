@@ -323,7 +323,7 @@ class BatchedMCTS:
 
     def _compact(self, n_live):
         """gather the live episodes into a dense batch for the following iterations (called where the host has just read the active count:
-        no extra synchronisation).  Worth it from ~8 % lost episodes: the dense layers, which cannot skip single rows, shrink too."""
+        no extra synchronisation; the graph-free loop uses _compact_host).  The dense layers, which cannot skip single rows, shrink too."""
         cur = self.E if self._ids is None else len(self._ids[1])
         if n_live <= 0 or n_live > (1.0 - float(getattr(self.p, 'compact_min_dead', 0.03))) * cur:
             return
