@@ -258,6 +258,18 @@ def test_row_mask_generic_geometry(pair):
     rows = alive.bool().repeat_interleave(A)
     assert torch.equal(out[0][rows], ref[0][rows]) and torch.equal(out[2][rows], ref[2][rows]) and torch.equal(out[4][rows], ref[4][rows])
     assert torch.equal(m.calculate_G(s0, pi0, samples=2, stage=6)[0], ref[0])
+    # ABI 4: the row set as an argument of the call, and a compacted call (entries 1, 2 only) -- the generic kernels read the mask at the entry id
+    from daimc_amd.model import Rows
+    out2 = m.calculate_G(s0, pi0, samples=2, stage=6, rows=Rows(mask=alive, rows_per_entry=A))
+    assert torch.equal(out2[0][rows], ref[0][rows]) and torch.equal(out2[4][rows], ref[4][rows])
+    keep = torch.nonzero(alive).flatten()
+    kr = (keep[:, None] * A + torch.arange(A, device=m.device)[None]).reshape(-1)
+    s0d, pid = torch.from_numpy(s0).to(m.device), torch.from_numpy(pi0).to(m.device)
+    cmp_ = m.calculate_G(s0d[kr], pid[kr], samples=2, stage=6, rows=Rows(ids=keep.to(torch.int32), rows_per_entry=A, ids_host=keep.tolist()))
+    assert torch.equal(cmp_[0], ref[0][kr]) and torch.equal(cmp_[2], ref[2][kr]) and torch.equal(cmp_[4], ref[4][kr])
+    alive2 = alive.clone(); alive2[2] = 0
+    cm = m.calculate_G(s0d[kr], pid[kr], samples=2, stage=6, rows=Rows(mask=alive2, ids=keep.to(torch.int32), rows_per_entry=A, ids_host=keep.tolist()))
+    assert torch.equal(cm[0][:A], ref[0][kr][:A])
 
 
 def test_generic_chunking_invariance(pair):

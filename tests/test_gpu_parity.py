@@ -847,6 +847,72 @@ def test_mcts_tree_kernels_vs_host_torch(models):
     assert torch.equal(stop_at.cpu() == 7, done) and int(n_act.item()) == int((active.bool() & ~done).sum())
 
 
+def test_mcts_step_equals_backprop_stop_select(models):
+    """efe_mcts_step (ONE launch between two iterations' engine calls) == efe_mcts_backprop of the previous iteration, then efe_mcts_stop,
+    then efe_mcts_select, on random trees: same tree statistics, history row, active set, stop iterations, active count and selection"""
+    import ctypes as C
+    from daimc_amd import _lib
+    m = models(1234, 1.15, 21)
+    e = m._ready()
+    E, A, cap, sd, depth, R = 41, 4, 25, 10, 6, 2
+    g = torch.Generator().manual_seed(11)
+    dev = m.device
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def fresh():
+        gg = torch.Generator().manual_seed(12)
+        W = torch.randn(E, cap, A, generator=gg) * 3
+        N = torch.randint(0, 4, (E, cap, A), generator=gg).float()
+        N[:, 0] = torch.randint(1, 6, (E, A), generator=gg).float()
+        Qpi = torch.rand(E, cap, A, generator=gg)
+        child = torch.full((E, cap, A), -1, dtype=torch.int32)
+        for ep in range(E):
+            nxt = 1
+            for node in range(cap):
+                if node >= nxt:
+                    break
+                if (node == 0 or torch.rand(1, generator=gg).item() < 0.6) and nxt + A <= cap:
+                    child[ep, node] = torch.arange(nxt, nxt + A, dtype=torch.int32)
+                    nxt += A
+        S = torch.randn(E, cap, sd, generator=gg)
+        active = (torch.rand(E, generator=gg) < 0.85).to(torch.uint8)
+        t = [x.to(dev).contiguous() for x in (W, N, Qpi, child, S, active)]
+        tree = _lib.EfeMctsTree(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), E, cap, A, sd)
+        bufs = dict(pn=torch.zeros(E, depth, dtype=torch.int32, device=dev), pa=torch.zeros(2, E, depth, dtype=torch.int32, device=dev),
+                    pl=torch.zeros(2, E, dtype=torch.int32, device=dev), leaf=torch.zeros(E, dtype=torch.int32, device=dev),
+                    ls=torch.zeros(E, sd, device=dev), lr=torch.zeros(E * A, sd, device=dev), stop=torch.full((E,), -1, dtype=torch.int32, device=dev),
+                    nact=torch.zeros(2, dtype=torch.int32, device=dev), g=torch.zeros(E, device=dev), hact=torch.zeros(E, dtype=torch.uint8, device=dev))
+        return t, tree, bufs
+    sims = torch.randn(R, E, generator=g).to(dev)
+    q0 = torch.rand(E, A, generator=g).to(dev)
+    out = []
+    for fused in (False, True):
+        t, tree, b = fresh()
+        act = t[5]
+        # iteration 0: selection (no previous iteration)
+        if fused:
+            e.check(e.lib.efe_mcts_step(e.ctx, C.byref(tree), None, None, None, 1, None, None, None, p(act), p(b['stop']), 0, 0.25, p(b['nact'][0:]),
+                                        1.5, 1, depth, p(b['pn']), p(b['pa'][0]), p(b['pl'][0]), p(b['leaf']), p(b['ls']), p(b['lr']), e.stream()))
+            e.check(e.lib.efe_mcts_step(e.ctx, C.byref(tree), p(b['pa'][0]), p(b['pl'][0]), p(sims), R, p(q0), p(b['g']), p(b['hact']), p(act), p(b['stop']),
+                                        1, 0.25, p(b['nact'][1:]), 1.5, 1, depth, p(b['pn']), p(b['pa'][1]), p(b['pl'][1]), p(b['leaf']), p(b['ls']), p(b['lr']),
+                                        e.stream()))
+        else:
+            for it in (0, 1):
+                if it == 1:
+                    e.check(e.lib.efe_mcts_backprop(e.ctx, C.byref(tree), p(b['pn']), p(b['pa'][0]), p(b['pl'][0]), p(b['leaf']), p(act), p(sims), R, p(q0),
+                                                    depth, p(b['g']), p(b['hact']), e.stream()))
+                na = torch.zeros(1, dtype=torch.int32, device=dev)
+                e.check(e.lib.efe_mcts_stop(e.ctx, C.byref(tree), p(act), p(b['stop']), it, 0.25, p(na), e.stream()))
+                b['nact'][it] = na[0]
+                e.check(e.lib.efe_mcts_select(e.ctx, C.byref(tree), p(act), 1.5, 1, depth, p(b['pn']), p(b['pa'][it]), p(b['pl'][it]), p(b['leaf']),
+                                              p(b['ls']), p(b['lr']), e.stream()))
+        torch.cuda.synchronize()
+        out.append([x.cpu() for x in t[:3]] + [act.cpu()] + [b[k].cpu() for k in ('pn', 'pa', 'pl', 'leaf', 'ls', 'lr', 'stop', 'nact', 'g', 'hact')])
+    for x, y in zip(*out):
+        assert torch.equal(x, y) or (torch.isnan(x) == torch.isnan(y)).all() and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y))
+    assert int(out[0][11][1]) < int(out[0][11][0]) or int(out[0][11][0]) < E        # the stop test did something
+
+
 # ------------------------------------------------------------------------------------------------------
 # the benchmarked configuration itself, pinned at full size
 # ------------------------------------------------------------------------------------------------------
