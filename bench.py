@@ -458,12 +458,11 @@ def bench_single_episode(model, device, samples):
     out['decision_use_means_S1_reference_api'] = ms(lambda: daimc_amd.active_inference_mcts(model, frame[0], p, o_shape=(1, 64, 64)), 3)
     p.host_tree = True            # the host-side Node tree (what a caller of Node.expand / select / backpropagate drives)
     out['decision_use_means_S1_host_node_tree'] = ms(lambda: daimc_amd.active_inference_mcts(model, frame[0], p, o_shape=(1, 64, 64)), 3)
-    for mode in (False, True):
-        q = daimc_amd.MCTS_Params()
-        q.repeats, q.simulation_depth, q.threshold, q.use_means, q.samples, q.use_graph = 50, 5, 2.0, False, samples, mode
-        key = 'decision_S%d_lockstep_E1_%s' % (samples, 'graph' if mode else 'launched')
-        out[key] = ms(lambda: daimc_amd.active_inference_mcts_batch(model, frame, q, o_shape=(1, 64, 64)), 4)
-        out[key.replace('decision', 'iteration')] = out[key] / 51.0          # root expansion + 50 iterations
+    q = daimc_amd.MCTS_Params()
+    q.repeats, q.simulation_depth, q.threshold, q.use_means, q.samples = 50, 5, 2.0, False, samples
+    key = 'decision_S%d_lockstep_E1_launched' % samples
+    out[key] = ms(lambda: daimc_amd.active_inference_mcts_batch(model, frame, q, o_shape=(1, 64, 64)), 4)
+    out[key.replace('decision', 'iteration')] = out[key] / 51.0          # root expansion + 50 iterations
     return out
 
 

@@ -12,8 +12,8 @@ EXPORTS = ['efe_create', 'efe_destroy', 'efe_last_error', 'efe_abi_version', 'ef
            'efe_prof_enable', 'efe_prof_classes', 'efe_prof_read', 'efe_env_reset', 'efe_env_step', 'efe_env_render',
            'efe_check_reward', 'efe_reparameterize', 'efe_mcts_select', 'efe_mcts_expand', 'efe_mcts_backprop', 'efe_mcts_stop',
            'efe_build_id', 'efe_reserve', 'efe_rollout_scratch_bytes', 'efe_arena_stats', 'efe_env_new_image', 'efe_create_cfg', 'efe_get_config', 'efe_set_row_mask',
-           'efe_set_stage_counter', 'efe_mcts_stop_dev', 'efe_mcts_record', 'efe_counter_add', 'efe_calculate_g_rows', 'efe_simulate_rows', 'efe_mcts_step']
-ABI_VERSION = 4
+           'efe_calculate_g_rows', 'efe_simulate_rows', 'efe_mcts_step']
+ABI_VERSION = 5
 
 
 class EfeMctsTree(C.Structure):
@@ -118,9 +118,5 @@ def load():
     lib.efe_mcts_backprop.argtypes = [p, tp, p, p, p, p, p, f32p, i, f32p, i, f32p, p, p]; lib.efe_mcts_backprop.restype = i
     lib.efe_mcts_stop.argtypes = [p, tp, p, p, i, C.c_float, p, p]; lib.efe_mcts_stop.restype = i
     lib.efe_mcts_step.argtypes = [p, tp, p, p, f32p, i, f32p, f32p, p, p, p, i, C.c_float, p, C.c_float, i, i, p, p, p, p, f32p, f32p, p]; lib.efe_mcts_step.restype = i
-    lib.efe_mcts_stop_dev.argtypes = [p, tp, p, p, p, C.c_float, p, p]; lib.efe_mcts_stop_dev.restype = i
-    lib.efe_mcts_record.argtypes = [p, p, i, i, i, p, p, p, p, p, p, p, p, p]; lib.efe_mcts_record.restype = i
-    lib.efe_counter_add.argtypes = [p, p, i, p]; lib.efe_counter_add.restype = i
-    lib.efe_set_stage_counter.argtypes = [p, p, C.c_uint32]; lib.efe_set_stage_counter.restype = i
     _lib = lib
     return lib

@@ -91,7 +91,6 @@ struct efe_ctx {
     int64_t fuse_final_g = 1;      // generic path: last two decoder layers in one kernel (k_dec_bg); 0 = separate launches (A/B, parity tests of k_final_g)
     int64_t last_macs = 0;
     const uint8_t* row_mask = nullptr; int row_mask_div = 1;      // efe_set_row_mask
-    const uint32_t* stage_ctr = nullptr; uint32_t stage_mul = 0;   // efe_set_stage_counter: device-side addend of every noise stage
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
     unsigned prof = 0;        // bitmask of ProfClass values to time
     int cls = PROF_OTHER;
@@ -226,7 +225,6 @@ void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float*
     a.Wp = L.Wp; a.bias = L.bias; a.X = X; a.Y = Y; a.zeros = ctx->zeros;
     a.n_pix = M; a.cin = L.cin; a.cout = L.cout; a.mtiles = L.mtiles; a.ldx = ldx; a.ldy = ldy; a.x_mod = x_mod;
     a.relu = relu; a.dropout = drop; a.tag = tag; a.k0 = nc.k0; a.k1 = nc.k1; a.gm = nc.gm;
-    a.gm.ctr = ctx->stage_ctr; a.gm.ctr_mul = ctx->stage_mul;
     a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = m0;
     hipEvent_t e0 = ctx->prof_begin(st);
     if (L.mtiles >= 64 && !(L.mtiles & 1) && L.cin == 256 && ldx == 256 && x_mod == 0 && relu && drop) {
@@ -247,7 +245,6 @@ void head(efe_ctx* ctx, bool enc, const float* X, float* Y, int M, const NoiseCf
     HeadArgs a{};
     a.W = enc ? ctx->enc16 : ctx->dec16; a.kc0 = enc ? ctx->enc16_kc0 : 1; a.nl = enc ? 4 : 3; a.out_tiles = 2;
     a.tag0 = enc ? TAG_ENC : TAG_DEC; a.X = X; a.Y = Y; a.M = M; a.k0 = nc.k0; a.k1 = nc.k1; a.gm = nc.gm;
-    a.gm.ctr = ctx->stage_ctr; a.gm.ctr_mul = ctx->stage_mul;
     a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = m0;
     hipEvent_t e0 = ctx->prof_begin(st);
     launch_head(a, st);
@@ -259,7 +256,6 @@ int run_mid(efe_ctx* ctx, const float* X, int x_mod, int M, float* tr /*[M][32]*
     if (!ctx->mid_unfused) {           // one launch for the four layers, activations in LDS (fused.hip)
         TransFusedArgs a{};
         a.W = ctx->mid16; a.X = X; a.tr = tr; a.M = M; a.x_mod = x_mod; a.k0 = nc.k0; a.k1 = nc.k1; a.gm = nc.gm;
-        a.gm.ctr = ctx->stage_ctr; a.gm.ctr_mul = ctx->stage_mul;
         a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = 0;
         ctx->cls = PROF_MID;
         hipEvent_t e0 = ctx->prof_begin(st);
@@ -571,7 +567,6 @@ int run_core(efe_ctx* ctx, const CoreIO& io, hipStream_t st) {
         p.ps1_mean_last = (t + 1 == D) ? io.ps1_mean : nullptr;
         p.S = S; p.R = R; p.mean_mode = io.mean_mode; p.carry_mean = io.carry_mean;
         p.k0 = io.k0; p.k1 = io.k1; p.stage = io.stage0 + t; p.row_offset = io.row_offset; p.pi_dim = ctx->pi_dim;
-        p.ctr = ctx->stage_ctr; p.ctr_mul = ctx->stage_mul;
         p.ids = io.ids; p.ids_div = io.mask_div;
         launch_trans_post(p, st);
         x = nx;
@@ -660,7 +655,7 @@ int finish(efe_ctx* ctx) {          // calls that use no engine scratch (environ
 // =====================================================================================================
 extern "C" {
 
-int efe_abi_version(void) { return 4; }
+int efe_abi_version(void) { return 5; }
 
 // efe_build_id(): the digest of the sources this library was compiled from -- a generated translation unit (build.py writes it at
 // link time, so an edit of one kernel file recompiles that file only)
@@ -1043,47 +1038,8 @@ int efe_mcts_stop(efe_ctx* ctx, const efe_mcts_tree* tree, uint8_t* active, int3
     if (mcts_tree(ctx, tree, t)) return 1;
     if (!active || !stop_at || !n_active) return ctx->fail("efe_mcts_stop: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
-    launch_mcts_stop(t, active, stop_at, repeat, nullptr, threshold, n_active, (hipStream_t)stream);
+    launch_mcts_stop(t, active, stop_at, repeat, threshold, n_active, (hipStream_t)stream);
     return finish(ctx);
-}
-
-int efe_mcts_stop_dev(efe_ctx* ctx, const efe_mcts_tree* tree, uint8_t* active, int32_t* stop_at, const int32_t* repeat_dev, float threshold,
-                      int32_t* n_active, void* stream) {
-    if (!ctx) return 1;
-    EFE_LOCK(ctx);
-    MctsTree t;
-    if (mcts_tree(ctx, tree, t)) return 1;
-    if (!active || !stop_at || !repeat_dev || !n_active) return ctx->fail("efe_mcts_stop_dev: bad arguments");
-    HIPCHK(hipSetDevice(ctx->device));
-    launch_mcts_stop(t, active, stop_at, 0, repeat_dev, threshold, n_active, (hipStream_t)stream);
-    return finish(ctx);
-}
-
-int efe_mcts_record(efe_ctx* ctx, const int32_t* iter_dev, int n_rows, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len,
-                    const float* cur_g, const uint8_t* cur_active, int32_t* H_act, int32_t* H_len, float* H_g, uint8_t* H_active, void* stream) {
-    if (!ctx) return 1;
-    EFE_LOCK(ctx);
-    if (!iter_dev || n_rows < 1 || E < 1 || max_depth < 1 || !cur_act || !cur_len || !cur_g || !cur_active || !H_act || !H_len || !H_g || !H_active)
-        return ctx->fail("efe_mcts_record: bad arguments");
-    HIPCHK(hipSetDevice(ctx->device));
-    launch_mcts_record(iter_dev, n_rows, E, max_depth, cur_act, cur_len, cur_g, cur_active, H_act, H_len, H_g, H_active, (hipStream_t)stream);
-    return finish(ctx);
-}
-
-int efe_counter_add(efe_ctx* ctx, int32_t* counter_dev, int delta, void* stream) {
-    if (!ctx) return 1;
-    EFE_LOCK(ctx);
-    if (!counter_dev) return ctx->fail("efe_counter_add: bad arguments");
-    HIPCHK(hipSetDevice(ctx->device));
-    launch_counter_add(counter_dev, delta, (hipStream_t)stream);
-    return finish(ctx);
-}
-
-int efe_set_stage_counter(efe_ctx* ctx, const uint32_t* counter_dev, uint32_t mul) {
-    if (!ctx) return 1;
-    EFE_LOCK(ctx);
-    ctx->stage_ctr = counter_dev; ctx->stage_mul = counter_dev ? mul : 0;
-    return 0;
 }
 
 int64_t efe_last_call_macs(efe_ctx* ctx) { return ctx ? ctx->last_macs : 0; }
@@ -1347,7 +1303,7 @@ int efe_simulate_rows(efe_ctx* ctx, const float* starting_s, int E, int depth, i
         SimChainArgs sa{};
         sa.W = ctx->mid16; sa.H = ctx->top16; sa.s0 = starting_s; sa.E = E; sa.T = T; sa.use_means = use_means;
         sa.k0 = k0; sa.k1 = k1; sa.stage = nz->stage; sa.row_offset = nz->row_offset;
-        sa.eps_inj = eps; sa.u_inj = u; sa.ctr = ctx->stage_ctr; sa.ctr_mul = ctx->stage_mul; sa.ids = rs.ids;
+        sa.eps_inj = eps; sa.u_inj = u; sa.ids = rs.ids;
         sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0; sa.pi_dim = ctx->pi_dim; sa.tr = trp;
         ctx->cls = PROF_MID;
         hipEvent_t e0 = ctx->prof_begin(st);

@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
     const unsigned ln = (unsigned)lane * 16u;
     const int e0 = blockIdx.x * SIM_FE;
     const int E = a.E, T = a.T;
-    const uint32_t stage_ = a.stage + stage_bump(a.ctr, a.ctr_mul);
+    const uint32_t stage_ = a.stage;
     const uint32_t erow = global_row(a.ids, 1, min(e0 + ne, E - 1), a.row_offset);      // (episodes past E: any valid key, results discarded)
     if (tid < SIM_FE * 16) {
         const int rr = tid >> 4, k = tid & 15, e = e0 + rr;

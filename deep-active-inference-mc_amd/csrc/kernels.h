@@ -27,9 +27,6 @@ struct GroupMap {
     int per_stage, S;
     uint32_t pass[3];
     uint32_t stage0, sample0;
-    // optional device-side stage counter (efe_set_stage_counter): the stage of every draw is stage0 + t + *ctr * ctr_mul, so a captured
-    // launch sequence (hipGraph) replays with fresh noise by bumping one device word instead of new kernel arguments
-    const uint32_t* ctr = nullptr; uint32_t ctr_mul = 0;
     // optional row identities (efe_rows.ids: the lock-step planner's compacted batches): logical row r of a group is row
     // ids[r / ids_div] * ids_div + r % ids_div of the un-compacted batch -- the noise keys follow the episode, not its slot
     const int32_t* ids = nullptr; int ids_div = 1;
@@ -40,7 +37,6 @@ __device__ __forceinline__ uint32_t global_row(const int32_t* ids, int ids_div, 
     const int e = r / ids_div;
     return row_offset + (uint32_t)(ids[e] * ids_div + (r - e * ids_div));
 }
-__device__ __forceinline__ uint32_t stage_bump(const uint32_t* ctr, uint32_t mul) { return ctr ? *ctr * mul : 0u; }
 __host__ __device__ inline void group_decode(const GroupMap& gm, int g, int& t, int& pidx, int& samp) {
     t = g / gm.per_stage;
     const int q = g - t * gm.per_stage;
@@ -51,7 +47,7 @@ __device__ __forceinline__ uint2 group_key(const GroupMap& gm, int g) {
     int t, pidx, samp;
     group_decode(gm, g, t, pidx, samp);
     const uint32_t pass = pidx == 0 ? gm.pass[0] : pidx == 1 ? gm.pass[1] : gm.pass[2];
-    return make_uint2(stream_id(pass, gm.sample0 + (uint32_t)samp), gm.stage0 + (uint32_t)t + stage_bump(gm.ctr, gm.ctr_mul));
+    return make_uint2(stream_id(pass, gm.sample0 + (uint32_t)samp), gm.stage0 + (uint32_t)t);
 }
 
 // Optional liveness mask of the logical rows of a call (efe_set_row_mask: the lock-step planner's early-stopped episodes): image m of
@@ -160,7 +156,6 @@ struct TransPostArgs {
     int S, R, mean_mode, carry_mean;
     uint32_t k0, k1, stage, row_offset;
     int pi_dim;            // x rows are [pi (pi_dim) | s (10) | zeros]
-    const uint32_t* ctr; uint32_t ctr_mul;      // optional device-side stage counter (GroupMap)
     const int32_t* ids; int ids_div;            // optional row identities (GroupMap)
 };
 void launch_trans_post(const TransPostArgs& a, hipStream_t st);
@@ -195,8 +190,7 @@ void launch_mcts_expand(const MctsTree& t, int32_t* n_nodes, const int32_t* node
 void launch_mcts_backprop(const MctsTree& t, const int32_t* path_nodes, const int32_t* path_act, const int32_t* path_len,
                           const int32_t* leaf, const uint8_t* active, const float* sims, int R, const float* q0, int max_depth,
                           float* g_out, uint8_t* active_out, hipStream_t st);
-void launch_mcts_stop(const MctsTree& t, uint8_t* active, int32_t* stop_at, int repeat, const int32_t* repeat_dev, float threshold,
-                      int32_t* n_active, hipStream_t st);          // repeat_dev != nullptr: the iteration index is read on the device
+void launch_mcts_stop(const MctsTree& t, uint8_t* active, int32_t* stop_at, int repeat, float threshold, int32_t* n_active, hipStream_t st);
 struct MctsStepArgs {
     // back-propagation of the previous iteration (prev_path_len == nullptr: none); path_nodes / leaf still hold that iteration's selection
     const int32_t* prev_path_act; const int32_t* prev_path_len; const float* sims; int n_sims; const float* q0; float* prev_g_out; uint8_t* prev_active_out;
@@ -207,9 +201,6 @@ struct MctsStepArgs {
     int32_t *path_nodes, *path_act, *path_len, *leaf; float *leaf_s, *leaf_s_rep;
 };
 void launch_mcts_step(const MctsTree& t, const MctsStepArgs& a, hipStream_t st);
-void launch_mcts_record(const int32_t* iter, int n_rows, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len, const float* cur_g,
-                        const uint8_t* cur_active, int32_t* H_act, int32_t* H_len, float* H_g, uint8_t* H_active, hipStream_t st);
-void launch_counter_add(int32_t* counter, int delta, hipStream_t st);
 
 // ---- fused small-MLP kernels (fused.hip) ---------------------------------------------------------------------
 // weights packed for v_mfma_f32_16x16x4_f32: [16-feature tile][16-channel chunk][64 lanes][4], biases padded to the tile count
@@ -251,7 +242,6 @@ struct SimChainArgs {
     float* Qpi0;           // nullable [E][pi_dim]
     float* tr;             // nullable [2][E * T][32]: the trajectory core's transition rows (given T1 | T2 of the same input)
     int pi_dim;
-    const uint32_t* ctr; uint32_t ctr_mul;      // optional device-side stage counter (GroupMap)
     const int32_t* ids;                         // optional episode identities: episode slot e is episode ids[e] of the un-compacted batch
 };
 void launch_sim_chain(const SimChainArgs& a, hipStream_t st);

@@ -211,7 +211,7 @@ __global__ void k_trans_post(const TransPostArgs a) {
         const float mean = tr[k], lv = tr[10 + k];
         float eps;
         if (a.eps_inj) eps = a.eps_inj[((size_t)q * R + r) * 10 + k];
-        else eps = normal_elem(a.k0, a.k1, global_row(a.ids, a.ids_div, r, a.row_offset), stream_id(pass, sample), a.stage + stage_bump(a.ctr, a.ctr_mul), k);
+        else eps = normal_elem(a.k0, a.k1, global_row(a.ids, a.ids_div, r, a.row_offset), stream_id(pass, sample), a.stage, k);
         const float samp = eps * expf(lv * 0.5f) + mean;
         out = use_mean ? mean : samp;
         if (q == S - 1) {

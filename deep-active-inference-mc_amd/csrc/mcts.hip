@@ -119,8 +119,8 @@ __global__ void k_mcts_backprop(const MctsTree t, const int32_t* path_nodes, con
 }
 
 // early stop (mcts.py:130-131, 176): an episode is done when max(N/sum N) - mean(N/sum N) at the root exceeds the threshold
-__device__ __forceinline__ void mcts_stop_one(const MctsTree& t, int e, uint8_t* active, int32_t* stop_at, int repeat, const int32_t* repeat_dev,
-                                              float threshold, int32_t* n_active) {
+__device__ __forceinline__ void mcts_stop_one(const MctsTree& t, int e, uint8_t* active, int32_t* stop_at, int repeat, float threshold,
+                                              int32_t* n_active) {
     if (!active[e]) return;
     const int A = t.A;
     const float* n = t.N + (size_t)e * t.cap * A;            // root = node 0
@@ -135,14 +135,13 @@ __device__ __forceinline__ void mcts_stop_one(const MctsTree& t, int e, uint8_t*
     }
     if (isn) dmax = __builtin_nanf("");
     const float crit = dmax - dsum / (float)A;
-    if (crit > threshold) { active[e] = 0; stop_at[e] = repeat_dev ? *repeat_dev : repeat; }
+    if (crit > threshold) { active[e] = 0; stop_at[e] = repeat; }
     else atomicAdd(n_active, 1);
 }
-__global__ void k_mcts_stop(const MctsTree t, uint8_t* active, int32_t* stop_at, int repeat, const int32_t* repeat_dev, float threshold,
-                            int32_t* n_active) {
+__global__ void k_mcts_stop(const MctsTree t, uint8_t* active, int32_t* stop_at, int repeat, float threshold, int32_t* n_active) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= t.E) return;
-    mcts_stop_one(t, e, active, stop_at, repeat, repeat_dev, threshold, n_active);
+    mcts_stop_one(t, e, active, stop_at, repeat, threshold, n_active);
 }
 // One launch for the tree work between two iterations' engine calls: back-propagation of the previous iteration (skipped for the
 // first), early-stop test, selection of the next leaf -- the three one-thread-per-episode kernels above, in that order, per episode.
@@ -153,7 +152,7 @@ __global__ void k_mcts_step(const MctsTree t, MctsStepArgs a) {
     if (a.prev_path_len)
         mcts_backprop_one(t, e, a.path_nodes, a.prev_path_act, a.prev_path_len, a.leaf, a.active, a.sims, a.n_sims, a.q0, a.max_depth, a.prev_g_out,
                           a.prev_active_out);
-    mcts_stop_one(t, e, a.active, a.stop_at, a.repeat, nullptr, a.threshold, a.n_active);
+    mcts_stop_one(t, e, a.active, a.stop_at, a.repeat, a.threshold, a.n_active);
     mcts_select_one(t, e, a.active, a.C, a.use_prior, a.max_depth, a.path_nodes, a.path_act, a.path_len, a.leaf, a.leaf_s, a.leaf_s_rep);
 }
 void launch_mcts_step(const MctsTree& t, const MctsStepArgs& a, hipStream_t st) {
@@ -175,31 +174,9 @@ void launch_mcts_backprop(const MctsTree& t, const int32_t* path_nodes, const in
     hipLaunchKernelGGL(k_mcts_backprop, dim3((t.E + 63) / 64), dim3(64), 0, st, t, path_nodes, path_act, path_len, leaf, active, sims, R,
                        q0, max_depth, g_out, active_out);
 }
-void launch_mcts_stop(const MctsTree& t, uint8_t* active, int32_t* stop_at, int repeat, const int32_t* repeat_dev, float threshold,
-                      int32_t* n_active, hipStream_t st) {
+void launch_mcts_stop(const MctsTree& t, uint8_t* active, int32_t* stop_at, int repeat, float threshold, int32_t* n_active, hipStream_t st) {
     (void)hipMemsetAsync(n_active, 0, sizeof(int32_t), st);
-    hipLaunchKernelGGL(k_mcts_stop, dim3((t.E + 63) / 64), dim3(64), 0, st, t, active, stop_at, repeat, repeat_dev, threshold, n_active);
+    hipLaunchKernelGGL(k_mcts_stop, dim3((t.E + 63) / 64), dim3(64), 0, st, t, active, stop_at, repeat, threshold, n_active);
 }
-
-// An iteration captured in a hipGraph writes its history row into fixed scratch rows; this copies them into row *iter of the
-// [iterations][E] history (the host-side loop passes the row pointers as kernel arguments instead)
-__global__ void k_mcts_record(const int32_t* iter, int n_rows, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len, const float* cur_g,
-                              const uint8_t* cur_active, int32_t* H_act, int32_t* H_len, float* H_g, uint8_t* H_active) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    if (*iter < 0 || *iter >= n_rows) return;          // a counter outside the history (a replayed graph run past its buffers) writes nothing
-    const size_t it = (size_t)*iter;
-    for (int d = 0; d < max_depth; ++d) H_act[(it * E + e) * max_depth + d] = cur_act[(size_t)e * max_depth + d];
-    H_len[it * E + e] = cur_len[e];
-    H_g[it * E + e] = cur_g[e];
-    H_active[it * E + e] = cur_active[e];
-}
-__global__ void k_counter_add(int32_t* counter, int delta) { *counter += delta; }
-void launch_mcts_record(const int32_t* iter, int n_rows, int E, int max_depth, const int32_t* cur_act, const int32_t* cur_len, const float* cur_g,
-                        const uint8_t* cur_active, int32_t* H_act, int32_t* H_len, float* H_g, uint8_t* H_active, hipStream_t st) {
-    hipLaunchKernelGGL(k_mcts_record, dim3((E + 63) / 64), dim3(64), 0, st, iter, n_rows, E, max_depth, cur_act, cur_len, cur_g, cur_active, H_act, H_len,
-                       H_g, H_active);
-}
-void launch_counter_add(int32_t* counter, int delta, hipStream_t st) { hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, st, counter, delta); }
 
 }  // namespace efe

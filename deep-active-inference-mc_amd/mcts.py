@@ -34,9 +34,6 @@ class MCTS_Params:
         self.method = 'ai'
         self.using_prior_for_exploration = False
         self.samples = 1          # extension: MC samples per expansion (reference always expands with 1)
-        self.use_graph = False    # lock-step planner: replay the iteration as ONE captured hipGraph instead of ~50 launches (same results;
-                                  # measured neutral on MI355X -- a small-batch iteration is bound by its chain of dependent kernels on
-                                  # the GPU, 0.88 ms for one episode either way, not by the host's launches -- so it is off by default)
 
 
 class Node:
@@ -269,18 +266,8 @@ class BatchedMCTS:
         self.n_active = torch.zeros(1, dtype=torch.int32, device=dev)
         self.n_active_it = torch.zeros(R + 1, dtype=torch.int32, device=dev)       # efe_mcts_step: one word per iteration
         self.q0 = torch.zeros(E, A, device=dev)
-        # graph form of the loop (see _loop_graph): the iteration index / noise stage live in device words, the iteration's history row
-        # is written to fixed scratch rows and copied into the history by a kernel, every buffer an iteration touches is persistent
         self.active = torch.zeros(E, dtype=torch.uint8, device=dev)
-        self.it = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.stg = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.cur_act = torch.zeros(E, self.max_depth, dtype=torch.int32, device=dev)
-        self.cur_len = torch.zeros(E, dtype=torch.int32, device=dev)
-        self.cur_g = torch.zeros(E, device=dev)
-        self.cur_active = torch.zeros(E, dtype=torch.uint8, device=dev)
         self.root_nodes = torch.zeros(E, dtype=torch.int32, device=dev)
-        self.plan_stream = None
-        self._graph, self._graph_key = None, None
         # expansion / simulation results of a COMPACTED call (only the live episodes, efe_rows.ids) are scattered into these full-size rows
         self.G_full = torch.zeros(E * A, device=dev)
         self.ps_full = torch.zeros(E * A, model.s_dim, device=dev)
@@ -323,7 +310,7 @@ class BatchedMCTS:
 
     def _compact(self, n_live):
         """gather the live episodes into a dense batch for the following iterations (called where the host has just read the active count:
-        no extra synchronisation; the graph-free loop uses _compact_host).  The dense layers, which cannot skip single rows, shrink too."""
+        no extra synchronisation; the lagged check uses _compact_host).  The dense layers, which cannot skip single rows, shrink too."""
         cur = self.E if self._ids is None else len(self._ids[1])
         if n_live <= 0 or n_live > (1.0 - float(getattr(self.p, 'compact_min_dead', 0.03))) * cur:
             return
@@ -342,7 +329,7 @@ class BatchedMCTS:
         idx = stage[:len(ids)].to(self.active.device, non_blocking=True)
         self._ids = (idx.to(torch.int32).contiguous(), ids.tolist(), idx)
 
-    def _expand(self, nodes, mask, states_rep, stage=None, eps_stage=None, use_mask=True):
+    def _expand(self, nodes, mask, states_rep, stage=None, use_mask=True):
         """ONE engine call over E x pi_dim rows (Node.expand, mcts.py:64-86); tree bookkeeping only where mask[e]"""
         m, p_, A = self.model, self._p, self.pi_dim
         ro = self.ep0 * A
@@ -353,10 +340,9 @@ class BatchedMCTS:
             states_rep = states_rep.view(self.E, A, -1).index_select(0, idx).reshape(idx.numel() * A, -1)
             pi_hot = self.pi_hot[:idx.numel() * A]
         if self.p.use_means:
-            G, _, ps_next, _ = m.calculate_G_mean(states_rep, pi_hot, row_offset=ro, stage=stage, eps_stage=eps_stage, rows=rows)
+            G, _, ps_next, _ = m.calculate_G_mean(states_rep, pi_hot, row_offset=ro, stage=stage, rows=rows)
         else:
-            G, _, ps_next, _, _ = m.calculate_G(states_rep, pi_hot, samples=getattr(self.p, 'samples', 1), row_offset=ro, stage=stage,
-                                                eps_stage=eps_stage, rows=rows)
+            G, _, ps_next, _, _ = m.calculate_G(states_rep, pi_hot, samples=getattr(self.p, 'samples', 1), row_offset=ro, stage=stage, rows=rows)
         if self._ids is not None:
             idx = self._ids[2]
             self.G_full.view(self.E, A).index_copy_(0, idx, G.view(-1, A))
@@ -365,7 +351,7 @@ class BatchedMCTS:
         G, ps_next = G.contiguous(), ps_next.contiguous()
         self._call(m._engine.lib.efe_mcts_expand, p_(self.n_nodes), p_(nodes), p_(mask), p_(G), p_(ps_next))
 
-    def _simulate(self, model, mask, stage_of, eps_stage_of=lambda r: None, direct=False):
+    def _simulate(self, model, mask, stage_of, direct=False):
         """the iteration's simulations from the selected leaves (mcts.py:186-189) -> self.sims, self.q0 (direct: with one simulation per
         iteration and an un-compacted batch the engine's own output tensors are handed to the back-propagation: self._sim_out, no copies)"""
         p = self.p
@@ -373,8 +359,7 @@ class BatchedMCTS:
         leaf_s = self.leaf_s if self._ids is None else self.leaf_s.index_select(0, self._ids[2])
         self._sim_out = None
         for r in range(p.simulation_repeats):
-            G, _, q0 = model.simulate_batch(leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0, stage=stage_of(r),
-                                            eps_stage=eps_stage_of(r), rows=rows)
+            G, _, q0 = model.simulate_batch(leaf_s, p.simulation_depth, use_means=False, row_offset=self.ep0, stage=stage_of(r), rows=rows)
             if direct and p.simulation_repeats == 1 and self._ids is None:
                 self._sim_out = (G, q0)          # (kept until the next iteration's simulation, which starts behind this one's back-propagation)
             elif self._ids is None:
@@ -397,7 +382,7 @@ class BatchedMCTS:
         return _trim_path(visited, self.pi_dim)
 
     def reset(self):
-        """fresh trees (a planner object, with its buffers and its captured iteration, is reused across decisions)"""
+        """fresh trees (a planner object, with its buffers, is reused across decisions)"""
         self.W.zero_(); self.N.zero_(); self.Qpi.zero_()
         self.child.fill_(-1); self.n_nodes.fill_(1); self.stop_at.fill_(-1)
 
@@ -441,7 +426,7 @@ class BatchedMCTS:
         # (efe_rows.mask: the per-image kernels read it on the device and skip dead rows; efe_mcts_stop clears entries as the loop runs, no
         # host round trip involved), and where the host learns the active count anyway the live episodes are compacted into a dense batch
         skip = bool(getattr(p, 'skip_stopped', True))
-        compact = skip and bool(getattr(p, 'compact_stopped', True)) and not bool(getattr(p, 'use_graph', False))      # (a captured iteration has fixed launch sizes)
+        compact = skip and bool(getattr(p, 'compact_stopped', True))
         self._ids = None
         if compact and not bool(active_h.all()):
             self._compact(int(active_h.sum()))
@@ -453,9 +438,6 @@ class BatchedMCTS:
         # threshold cannot be exceeded (max - mean of a distribution over A actions is below 1 - 1/A).
         CHECK = int(getattr(p, 'check_every', 8))
         can_stop = float(p.threshold) < 1.0 - 1.0 / A
-        use_graph = bool(getattr(p, 'use_graph', False))
-        if use_graph and p.repeats > 0:
-            n_iter = self._loop_graph(st0, per_it, can_stop, CHECK)
         # The tree work between two iterations' engine calls is ONE launch (efe_mcts_step): back-propagation of the previous iteration, early
         # stop, selection -- per episode in the reference's order (mcts.py:176-191).  The active count of iteration r lands in its own
         # zero-initialised word (no memset launch); the last iteration's back-propagation follows the loop.
@@ -463,7 +445,7 @@ class BatchedMCTS:
         lagged = bool(getattr(p, 'lagged_check', True)) and E > 1
         LAG = 2
         pending = None                                   # (iteration, sims, q0) whose back-propagation is still to run
-        for repeat in range(0 if not use_graph else p.repeats, p.repeats):
+        for repeat in range(p.repeats):
             if pending is None:
                 prev = (None, None, None, 1, None, None, None)
             else:
@@ -559,90 +541,6 @@ class BatchedMCTS:
             done |= child[ar, node, 0] < 0
         return out
 
-    # ---- the iteration as a replayable launch sequence -----------------------------------------------------
-    def _body(self, eps_stage=None):
-        """ONE planner iteration (early stop -> select -> expansion || simulation -> back-propagation -> history row) whose kernel arguments
-        do not depend on the iteration: the index comes from self.it, the noise stage from self.stg (efe_set_stage_counter), the history
-        row goes through fixed scratch rows (efe_mcts_record).  eps_stage: the iteration's first stage, for injected-noise runs only."""
-        m, p, p_ = self.model, self.p, self._p
-        lib = m._engine.lib
-        e = m._ready()
-        self._call(lib.efe_mcts_stop_dev, p_(self.active), p_(self.stop_at), p_(self.it), float(p.threshold), p_(self.n_active))
-        self._call(lib.efe_mcts_select, p_(self.active), float(p.C), 1 if p.using_prior_for_exploration else 0, self.max_depth,
-                   p_(self.path_nodes), p_(self.cur_act), p_(self.cur_len), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))
-        es = (lambda k: None) if eps_stage is None else (lambda k: eps_stage + k)
-
-        skip = bool(getattr(p, 'skip_stopped', True))
-        mask = self.active if skip else None
-
-        def simulate(model):
-            self._simulate(model, mask, lambda r: 1 + r, lambda r: es(1 + r))
-        if self.overlap:
-            cur = torch.cuda.current_stream(m.device)
-            self.ev_sel.record(cur)
-            with torch.cuda.stream(self.sim_stream):
-                self.sim_stream.wait_event(self.ev_sel)
-                simulate(self.sim_model)
-                self.ev_sim.record(self.sim_stream)
-            self._expand(self.leaf, self.active, self.leaf_rep, stage=0, eps_stage=es(0), use_mask=skip)
-            cur.wait_event(self.ev_sim)
-        else:
-            self._expand(self.leaf, self.active, self.leaf_rep, stage=0, eps_stage=es(0), use_mask=skip)
-            simulate(m)
-        self._call(lib.efe_mcts_backprop, p_(self.path_nodes), p_(self.cur_act), p_(self.cur_len), p_(self.leaf), p_(self.active),
-                   p_(self.sims), int(p.simulation_repeats), p_(self.q0), self.max_depth, p_(self.cur_g), p_(self.cur_active))
-        e.check(lib.efe_mcts_record(e.ctx, p_(self.it), int(self.H_g.shape[0]), self.E, self.max_depth, p_(self.cur_act), p_(self.cur_len), p_(self.cur_g),
-                                    p_(self.cur_active), p_(self.H_act), p_(self.H_len), p_(self.H_g), p_(self.H_active), e.stream()))
-        e.check(lib.efe_counter_add(e.ctx, p_(self.it), 1, e.stream()))
-        e.check(lib.efe_counter_add(e.ctx, p_(self.stg), 1 + p.simulation_repeats, e.stream()))
-
-    def _loop_graph(self, st0, per_it, can_stop, CHECK):
-        """the planning loop as: iteration 0 launched normally (it also sizes the scratch arenas), iterations 1.. as replays of ONE captured
-        hipGraph of _body -- ~50 launches per iteration become one graph launch, which is what a few-episode decision is bound by.
-        Device noise only (injected-noise runs launch _body every iteration: their normals are built on the host per stage)."""
-        m, p = self.model, self.p
-        dev = m.device
-        if self.plan_stream is None:
-            self.plan_stream = torch.cuda.Stream(device=dev)
-        models = [m] + ([self.sim_model] if self.overlap else [])
-        injected = m.eps_source is not None or m.u_source is not None
-        self.plan_stream.wait_stream(torch.cuda.current_stream(dev))
-        n_iter = 0
-        try:
-            with torch.cuda.stream(self.plan_stream):
-                self.it.zero_()
-                self.stg.fill_(int(st0))
-                for mm in models:
-                    mm.set_stage_counter(self.stg, 1)
-                self._body(eps_stage=st0 if injected else None)
-                n_iter = 1
-                # everything a captured launch bakes in: weights (buffer addresses), scratch layout, the Philox key words and row offset
-                # (kernel arguments), every engine option (launch paths), the mask setting
-                key = (getattr(m, '_weights_version', 0), int(m.seed), int(m.row_offset), tuple(sorted(getattr(m, '_opts', {}).items())),
-                       bool(getattr(p, 'skip_stopped', True))) + tuple(tuple(sorted(mm.arena_stats().items())) for mm in models)
-                if not injected and any(getattr(mm, '_prof_on', False) for mm in models):
-                    raise RuntimeError('MCTS_Params.use_graph: disable profiling (prof_enable(False)) before planning with a captured '
-                                       'iteration -- HIP events recorded inside a capture can never be read')
-                if not injected and (self._graph is None or self._graph_key != key):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=self.plan_stream):
-                        self._body()
-                    self._graph, self._graph_key = g, key
-                while n_iter < p.repeats:
-                    if injected:
-                        self._body(eps_stage=st0 + n_iter * per_it)
-                    else:
-                        self._graph.replay()
-                    n_iter += 1
-                    if can_stop and n_iter % CHECK == 0 and int(self.n_active.item()) == 0:
-                        break
-                self.plan_stream.synchronize()
-        finally:
-            for mm in models:
-                mm.set_stage_counter(None)
-        torch.cuda.current_stream(dev).wait_stream(self.plan_stream)
-        return n_iter
-
     def root_visit_distribution(self):
         """N / sum N at the roots, [E, pi_dim]: the policy-value that multi-GPU runs gather (mcts.py:177)"""
         n = self.N[:, 0].cpu()
@@ -653,7 +551,7 @@ def active_inference_mcts_batch(model, frames, params, o_shape=(64, 64, 1), epis
     """E planning decisions in lock-step; returns a list of E tuples shaped like active_inference_mcts's result and
     the [E, pi_dim] root visit distribution."""
     frames = torch.as_tensor(frames)
-    # planner objects (device buffers + the captured iteration graph) are kept per (episodes, offset, parameters) on the model
+    # planner objects (device buffers) are kept per (episodes, offset, parameters) on the model
     try:
         key = (int(frames.shape[0]), int(episode_offset), tuple(sorted((k, v) for k, v in vars(params).items())))
         hash(key)

@@ -388,20 +388,6 @@ class ActiveInferenceModel:
         self._row_mask = mask
         e.check(e.lib.efe_set_row_mask(e.ctx, C.c_void_p(mask.data_ptr()), int(rows_per_entry)))
 
-    def set_stage_counter(self, counter, mul=1):
-        """efe_set_stage_counter: every noise stage of the following calls on this model is stage + counter[0] * mul, read on the device
-        when the kernels run (`counter`: a 1-element int32 / uint32 tensor on this device, kept alive by the caller; None clears).  This is
-        what lets a captured launch sequence (hipGraph) replay with fresh noise."""
-        e = self._ready()
-        if counter is None:
-            self._stage_counter = None
-            e.check(e.lib.efe_set_stage_counter(e.ctx, None, 0))
-            return
-        if counter.device != self.device or counter.numel() != 1 or counter.element_size() != 4:
-            raise ValueError('set_stage_counter: a 1-element 32-bit integer tensor on the model device is required')
-        self._stage_counter = counter
-        e.check(e.lib.efe_set_stage_counter(e.ctx, C.c_void_p(counter.data_ptr()), int(mul)))
-
     def arena_stats(self):
         """-> dict(capacity_bytes, high_water_bytes, grow_count)"""
         e = self._engine
@@ -419,8 +405,6 @@ class ActiveInferenceModel:
         r = getattr(self, '_replica', None)
         if r is not None:                   # the planner's simulation context follows (one tree must not mix two reward definitions)
             r.set_option(name, value)
-        for planner in getattr(self, '_planners', {}).values():        # captured iteration graphs bake the option's launch paths in
-            planner._graph = None
 
     def save_weights(self, folder_chp):
         """torchmodel.py:167-171"""
@@ -514,7 +498,7 @@ class ActiveInferenceModel:
         _, Qpi, _ = self.model_top.encode_s(qs_mean)
         return Qpi
 
-    def calculate_G(self, s0, pi0, samples=10, *, stage=None, eps=None, row_offset=None, _mean_mode=False, _parts=None, eps_stage=None, rows=None):
+    def calculate_G(self, s0, pi0, samples=10, *, stage=None, eps=None, row_offset=None, _mean_mode=False, _parts=None, rows=None):
         """torchmodel.py:270-300 -> (G, [term0, term1, term2], ps1, ps1_mean, po1); rows: optional Rows (liveness mask / compacted batch)"""
         e = self._ready()
         s0 = e.tensor(s0, (-1, self.s_dim)); pi0 = e.tensor(pi0, (-1, self.pi_dim))
@@ -523,8 +507,8 @@ class ActiveInferenceModel:
         S = 1 if _mean_mode else int(samples)
         if S < 1:
             raise RuntimeError('efe engine: samples must be >= 1')
-        if eps is None and self.eps_source is not None:       # (eps_stage: the stage the injected normals belong to when a device-side
-            src_stage = nz.stage if eps_stage is None else int(eps_stage)                                       # stage counter supplies part of it)
+        if eps is None and self.eps_source is not None:
+            src_stage = nz.stage
             hr = rows.host_rows(rows.rows_per_entry) if rows is not None else None
             if hr is None:
                 eps = self._src_eps_calcG(M, S, src_stage, row_offset)
@@ -540,9 +524,9 @@ class ActiveInferenceModel:
             return G, [terms[0], terms[1], terms[2]], ps1_mean, po1
         return G, [terms[0], terms[1], terms[2]], ps1, ps1_mean, po1
 
-    def calculate_G_mean(self, s0, pi0, *, stage=None, eps=None, row_offset=None, _parts=None, eps_stage=None, rows=None):
+    def calculate_G_mean(self, s0, pi0, *, stage=None, eps=None, row_offset=None, _parts=None, rows=None):
         """torchmodel.py:302-327 -> (G, terms, ps1_mean, po1)"""
-        return self.calculate_G(s0, pi0, 1, stage=stage, eps=eps, row_offset=row_offset, _mean_mode=True, _parts=_parts, eps_stage=eps_stage, rows=rows)
+        return self.calculate_G(s0, pi0, 1, stage=stage, eps=eps, row_offset=row_offset, _mean_mode=True, _parts=_parts, rows=rows)
 
     def _rollout(self, o, pi, steps, calc_mean, samples, per_stage_mean, stage, eps, row_offset):
         e = self._ready()
@@ -593,7 +577,7 @@ class ActiveInferenceModel:
         eps_t = e.tensor(eps, (3, T, 10)) if eps is not None else None
         return e.ops.trajectory(e.h, s0, ps1, mean, lv, pi0, self._seed64(), nz.stage, nz.row_offset, eps_t)
 
-    def simulate_batch(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None, eps=None, u=None, eps_stage=None, rows=None):
+    def simulate_batch(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None, eps=None, u=None, rows=None):
         """mcts_step_simulate for E lock-step episodes -> (G[E], pi0[E,depth,4], Qpi0[E,4]).
         eps: optional injected normals, flat [depth*E*10 (step transitions)] + [3*E*depth*10 (trajectory T1/T2/D2B)];
         u: optional injected action uniforms [depth, E]; rows: optional Rows (entry = episode)."""
@@ -602,7 +586,7 @@ class ActiveInferenceModel:
         E, T = s.shape[0], int(depth)
         nz = self._noise(stage, 0, 0, row_offset)
         ro = self.row_offset if row_offset is None else int(row_offset)
-        src_stage = nz.stage if eps_stage is None else int(eps_stage)
+        src_stage = nz.stage
         he = rows.host_rows(1) if rows is not None else None          # a compacted call: the episodes it holds
         if eps is None and self.eps_source is not None:
             if he is None:

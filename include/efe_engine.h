@@ -48,7 +48,7 @@ int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channel
 int efe_get_config(efe_ctx* ctx, int* s_dim, int* pi_dim, int* channels, int* resolution);      /* outputs may be NULL */
 void efe_destroy(efe_ctx* ctx);
 const char* efe_last_error(efe_ctx* ctx);
-int efe_abi_version(void);                                       /* 3 */
+int efe_abi_version(void);                                       /* 5 (history of the versions: INTEGRATION.md section 4) */
 /* hex digest of the sources this library was compiled from (build.py stamps it; the Python loader refuses a library whose
  * digest differs from the sources next to it, so a stale shipped binary fails loudly). */
 const char* efe_build_id(void);
@@ -219,23 +219,6 @@ int efe_mcts_backprop(efe_ctx*, const efe_mcts_tree* tree, const int32_t* path_n
 int efe_mcts_stop(efe_ctx*, const efe_mcts_tree* tree, uint8_t* active, int32_t* stop_at, int repeat, float threshold,
                   int32_t* n_active, void* stream);
 
-/* ---- replaying a captured launch sequence (hipGraph) ----------------------------------------------------------------------------
- * A planner iteration (select -> expansion || simulation -> back-propagation -> early stop; src/mcts.py:170-191) is the same ~50 launches
- * every time; what changes between iterations is the noise stage, the iteration index stored by the early stop and the history row.
- * These three come from device memory here, so that the captured sequence can be replayed unchanged (ABI version 3, additive):
- *   efe_set_stage_counter : every noise stage of the following calls on this context is stage + *counter_dev * mul (read when the
- *                           kernels run); NULL clears.  The caller bumps the counter between replays (efe_counter_add).
- *   efe_mcts_stop_dev     : efe_mcts_stop with the iteration index read from *repeat_dev
- *   efe_mcts_record       : copies the iteration's history row, written by efe_mcts_select / efe_mcts_backprop into fixed scratch rows
- *                           cur_act [E][max_depth], cur_len [E], cur_g [E], cur_active [E], into row *iter_dev of H_* [iterations][E]...
- *   efe_counter_add       : *counter_dev += delta on the stream */
-int efe_set_stage_counter(efe_ctx* ctx, const uint32_t* counter_dev, uint32_t mul);
-int efe_mcts_stop_dev(efe_ctx*, const efe_mcts_tree* tree, uint8_t* active, int32_t* stop_at, const int32_t* repeat_dev, float threshold,
-                      int32_t* n_active, void* stream);
-int efe_mcts_record(efe_ctx*, const int32_t* iter_dev, int n_rows /* rows of H_*: an index beyond them is dropped */, int E, int max_depth,
-                    const int32_t* cur_act, const int32_t* cur_len, const float* cur_g, const uint8_t* cur_active, int32_t* H_act, int32_t* H_len,
-                    float* H_g, uint8_t* H_active, void* stream);
-int efe_counter_add(efe_ctx*, int32_t* counter_dev, int delta, void* stream);
 
 /* introspection for benches: algorithmic MACs of the last EFE-level call. */
 int64_t efe_last_call_macs(efe_ctx*);

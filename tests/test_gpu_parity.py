@@ -480,49 +480,6 @@ def test_planners_at_benchmark_depth_vs_reference(golden, models, name):
         _check_deep(g, e, out1[0], v1[0])
 
 
-def test_planner_iteration_with_device_counters_vs_reference(golden, models):
-    """the replayable form of the planner iteration (iteration index, noise stage and history row through device memory:
-    efe_set_stage_counter / efe_mcts_stop_dev / efe_mcts_record / efe_counter_add) against the 8-episode fixture captured from the
-    reference planner -- injected noise, so every iteration is launched (no graph), which pins the counter mechanics themselves"""
-    import daimc_amd
-    g = golden('mcts_batch_s10')
-    m = inject(_model(g, models))
-    p = _deep_params(dict(g, using_prior_for_exploration=0, use_habit=0))
-    p.use_graph = True
-    m._stage = int(g['stage'])
-    out, visits = daimc_amd.active_inference_mcts_batch(m, torch.from_numpy(g['frames']), p, o_shape=(1, 64, 64))
-    for e in range(int(g['episodes'])):
-        _check_deep(g, e, out[e], visits[e])
-
-
-@pytest.mark.parametrize('E', [1, 3, 16])
-def test_planner_graph_replay_equals_launched_iterations(models, E):
-    """lock-step planner with the iteration replayed from ONE captured hipGraph (device noise) == the same planner launching every
-    iteration: identical paths, G history and visit counts -- for 1 and 3 episodes (single stream) and 16 (simulation forked onto a
-    second stream inside the capture); a second decision reuses the cached planner and its graph"""
-    import daimc_amd
-    m = models(1234, 1.15, 19)
-    frames = torch.from_numpy(synth.make_frames(57, E)[:, 0][:, None])
-    res = {}
-    for mode in (False, True):
-        p = daimc_amd.MCTS_Params()
-        p.repeats, p.simulation_depth, p.use_means, p.threshold, p.samples = 12, 3, False, 0.45, 2
-        p.use_graph = mode
-        runs = []
-        for rep in range(2):
-            m._stage = 100
-            out, visits = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
-            runs.append((out, visits))
-        assert [o[:2] + (o[3], o[4]) for o in runs[0][0]] == [o[:2] + (o[3], o[4]) for o in runs[1][0]] and torch.equal(runs[0][1], runs[1][1])
-        res[mode] = runs[0]
-    a, b = res[False], res[True]
-    for e in range(E):
-        assert a[0][e][0] == b[0][e][0] and a[0][e][3] == b[0][e][3] and a[0][e][4] == b[0][e][4], e
-        # repeats_done: the launched loop stops looking once every episode has stopped; both report the iteration of the stop
-        assert a[0][e][1] == b[0][e][1] and a[0][e][2] == b[0][e][2]
-    assert torch.equal(a[1], b[1])
-
-
 def test_batched_mcts_episode_invariance(models):
     """episode e planned inside a batch of 3 == planned alone with episode_offset = e (global noise keys):
     the property that lets episodes shard across GPUs with identical results"""
