@@ -375,7 +375,12 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
            'config': {'workload': f'lock-step MCTS, {E} episodes per GPU x 50 expansions x {a.samples} MC samples, simulation depth 5, '
                                   f'early-stop threshold {threshold} (BASELINE configs[{2 if world == 1 else 3}])'
                                   + (' + all_gather of the root visit distributions' if rk.on else ''),
-                      'episodes_per_gpu': E, 'threshold': threshold},
+                      'episodes_per_gpu': E, 'threshold': threshold,
+                      # the code path of this leg (device-side stop, lagged host check, compaction of stopped episodes) is pinned to the reference
+                      # planner's own early stops at this depth and threshold by tests/golden/mcts_deep_s10_thr.npz (oracle/make_golden_thr.py;
+                      # tests/test_gpu_parity.py::test_lockstep_batch_with_early_stops_contains_the_reference_episodes)
+                      **({'parity_fixture': 'tests/golden/mcts_deep_s10_thr.npz (threshold 0.5: reference stops before iterations 41, 50, 50, 50, 29, 50)'}
+                         if abs(threshold - 0.5) < 1e-9 else {})},
            'iterations_done_mean': float(np.mean(iters)), 'iterations_done_min': int(min(iters)),
            'work_fraction_mean': float(np.mean(work_timed)), 'work_fraction_per_decision_batch': [round(x, 4) for x in work_timed]}
     out.update(rk.info())
@@ -435,7 +440,7 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
 def bench_single_episode(model, device, samples):
     """the reference's own call shape (/root/reference/src/mcts.py:150-195, 64-86): ONE episode -- active_inference_mcts with 4-row
     expansions and batch-1 simulations -- as host-observed latency: milliseconds per 50-iteration decision (use_means, S = 1; and the
-    benchmark's S MC samples per expansion, through the lock-step planner at E = 1, launched and replayed from the captured hipGraph) and per
+    benchmark's S MC samples per expansion, through the lock-step planner at E = 1) and per
     calculate_G / calculate_G_mean call on the 4 action rows of one state.  Latency-bound (dependent launches of a few images each): a
     per-call figure, not a roofline entry."""
     import daimc_amd

@@ -240,6 +240,37 @@ def test_lockstep_batch_at_benchmark_size_contains_the_reference_episodes(golden
     assert int(planner.n_nodes.max()) <= planner.cap
 
 
+@pytest.mark.parametrize('name', ['mcts_deep_s10_thr', 'mcts_deep_s10_thr04'])
+def test_lockstep_batch_with_early_stops_contains_the_reference_episodes(golden, models, name):
+    """the path bench.py's threshold-0.5 leg runs, against the reference planner's own early stops at the benchmark's depth
+    (oracle/make_golden_thr.py: /root/reference/src/mcts.py:170-181 at threshold 0.5 -> episodes stop before iterations 41, 50, 50, 50, 29,
+    50; at 0.4 -> 28, 45, 19, 50, 19, 42): 64 episodes in lock-step, the lagged host check, stopped episodes compacted out of the batch
+    (efe_rows.ids) while the others keep planning -- episodes 0-5 must reproduce the capture: repeats_done, every path, the G history,
+    the final path, the root visit distribution at the moment of the stop."""
+    import daimc_amd
+    g = golden(name)
+    m = inject(_model(g, models))
+    p = _deep_params(g)
+    E, E0 = 64, int(g['episodes'])
+    frames = torch.cat([torch.from_numpy(g['frames']), torch.from_numpy(synth.make_frames(78, E - E0))], 0)
+    m._stage = int(g['stage'])
+    out, visits = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
+    planner = next(pl for pl in m._planners.values() if pl.E == E)
+    assert planner.overlap and planner._ids is not None and len(planner._ids[1]) < E          # the batch WAS compacted
+    for e in range(E0):
+        _check_deep(g, e, out[e], visits[e])
+    stops = [o_[1] for o_ in out]
+    assert min(stops) < p.repeats and max(stops) == p.repeats           # some of the other 58 stop early too, some run to the end
+    np.testing.assert_allclose(visits.sum(1).numpy(), 1.0, rtol=1e-6)
+    # the same batch without compaction and without the lagged check (masked only, host reads the count every 8th iteration): identical
+    q = _deep_params(g)
+    q.compact_stopped, q.lagged_check = False, False
+    m._stage = int(g['stage'])
+    out2, visits2 = daimc_amd.active_inference_mcts_batch(m, frames, q, o_shape=(1, 64, 64))
+    assert [(o_[0], o_[1], o_[2], o_[3]) for o_ in out] == [(o_[0], o_[1], o_[2], o_[3]) for o_ in out2]
+    assert all(o_[4] == o2[4] for o_, o2 in zip(out, out2)) and torch.equal(visits, visits2)
+
+
 def test_planner_replica_follows_engine_options(models):
     """engine options are per context: the replica the lock-step planner simulates on must compute with the options of the model it
     mirrors (reward_upstream_intent changes term0 / G) -- a planner with the simulations on the second stream equals the same planner
@@ -452,7 +483,7 @@ def _check_deep(g, e, res, visits=None):
         np.testing.assert_array_equal(visits.numpy(), g['root_N'][e] / g['root_N'][e].sum())
 
 
-@pytest.mark.parametrize('name', ['mcts_deep_s10', 'mcts_prior_s10'])
+@pytest.mark.parametrize('name', ['mcts_deep_s10', 'mcts_prior_s10', 'mcts_deep_s10_thr', 'mcts_deep_s10_thr04'])
 def test_planners_at_benchmark_depth_vs_reference(golden, models, name):
     """BASELINE configs[2] pinned at its real depth (mcts_deep_s10: 50 iterations x 10-sample expansions x depth-5 simulations, every
     iteration run: 205-node trees, paths up to 6 actions, path trimming on long paths) and the prior-exploration bonus combined with

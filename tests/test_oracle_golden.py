@@ -214,6 +214,23 @@ def test_oracle_planner_at_benchmark_depth_vs_reference(golden, weights_cache):
     _check_planner_fixture(g, e, (got[0], got[1], got[2], got[3], got[4], got[5].numpy()))
 
 
+@pytest.mark.parametrize('name,e', [('mcts_deep_s10_thr', 4), ('mcts_deep_s10_thr04', 2)])
+def test_oracle_planner_early_stop_at_benchmark_depth_vs_reference(golden, weights_cache, name, e):
+    """the reference planner's early stop (mcts.py:170-181) at the benchmark's depth: threshold 0.5 (the reference's default, bench.py's
+    early-stop leg) stops episode 4 before iteration 29, threshold 0.4 stops episode 2 before 19 (oracle/make_golden_thr.py)"""
+    from oracle import mcts_oracle as MO
+    g = golden(name)
+    m = _oracle(g, weights_cache)
+    p = MO.Params(repeats=int(g['repeats']), simulation_depth=int(g['simulation_depth']), use_means=False,
+                  threshold=float(g['threshold']), samples=int(g['samples']))
+    assert 10 <= int(g['repeats_done'][e]) <= 45
+    # the stop statistic of the last check exceeded the threshold, every earlier one did not
+    ts = g['thr_stat'][e][:int(g['repeats_done'][e]) + 1]
+    assert ts[-1] > float(g['threshold']) and (ts[:-1] <= float(g['threshold'])).all()
+    got = MO.plan(m, torch.from_numpy(g['frames'][e]), p, int(g['stage']), episode=e)
+    _check_planner_fixture(g, e, (got[0], got[1], got[2], got[3], got[4], got[5].numpy()))
+
+
 @pytest.mark.parametrize('e', [0, 1])
 def test_oracle_planner_prior_with_ten_samples_vs_reference(golden, weights_cache, e):
     """using_prior_for_exploration (mcts.py:44-45) together with Node.expand(samples=10) and use_habit (shortcut evaluated, not taken)"""
