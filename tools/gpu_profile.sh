@@ -1,11 +1,12 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/gpu_profile.sh <tag> [bench args...]
-# kernel-trace/stats pass plus separate PMC passes (never combined with other trace domains).
+# kernel-trace/stats pass plus separate PMC passes (never combined with other trace domains).  8 warm-up + 8 timed steps: every kernel
+# has >= 16 calls, tools/prof_summary.py averages the last half (steady state: the clock ramp after idle covers the first ~4 launches).
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu --no-prof --no-extras --single-region $@"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 8 --no-cpu --no-prof --no-extras --single-region $@"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --pmc TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_mem -- $BENCH > $OUT/pmc_mem.log 2>&1

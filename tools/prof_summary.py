@@ -1,6 +1,11 @@
 #!/usr/bin/env python
 """Summarise a tools/gpu_profile.sh output directory (rocprofv3 csv) into a small text table:
-per kernel: calls, avg us, share; PMC counters averaged per dispatch."""
+per kernel: calls, avg us, share; the STEADY-STATE average (the last half of each kernel's calls in the kernel trace: the first launches
+after idle run inside the clock ramp) with the roofline fraction recomputed from it (algorithmic FLOPs of DESIGN section 5 / steady
+average), next to MFMA-busy and the shader clock of the PMC pass; PMC counters averaged per dispatch.
+
+  python tools/prof_summary.py <dir> [rows]        rows = decoder images per launch of the persistent kernels (default: the largest
+                                                   one-workgroup-per-image grid in the trace, i.e. 19 200 for the headline)"""
 import csv
 import glob
 import os
@@ -13,15 +18,62 @@ def short(n):
     return n.split('(')[0][:60]
 
 
-def main(d):
+PEAK_TF = 157.3          # fp32 MFMA, MI355X_MICROARCH.md
+# algorithmic MACs per decoder image / row: dSprites kernels, and the generic path at BASELINE configs[4] (3 x 84 x 84)
+MACS = {'k_dec_b4<1>': 20054016, 'k_dec_b4<4>': 20054016, 'k_dec_a': 18874368, 'k_dec_a_s': 18874368, 'k_fc4<2>': 4194304, 'k_fc4<1>': 4194304}
+MACS_G84 = {'k_dec_bg<3>': 21 * 21 * 4 * 9 * 64 * 32 + 84 * 84 * 9 * 32 * 3, 'k_convt_p<1, 4>': 21 * 21 * 9 * 64 * 64, 'k_convt_p<2, 4>': 21 * 21 * 9 * 64 * 64,
+            'k_fc4<2>': 256 * 64 * 21 * 21}
+
+
+def steady_table(d, rows_arg):
+    """-> lines; per kernel the mean duration of the LAST HALF of its calls in the kernel trace and the roofline fraction it implies"""
+    tr = glob.glob(os.path.join(d, 'kt', '**', '*kernel_trace.csv'), recursive=True)
+    if not tr:
+        return ['(no kernel trace csv: steady-state table skipped)'], {}
+    calls = defaultdict(list)
+    for r in csv.DictReader(open(tr[0])):
+        k = short(r['Kernel_Name'])
+        wg = max(int(r.get('Workgroup_Size', r.get('Workgroup_Size_X', 256)) or 256), 1)
+        calls[k].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp']), int(r.get('Grid_Size', r.get('Grid_Size_X', 0)) or 0) // wg))
+    generic = any(k.startswith('k_dec_bg') for k in calls)
+    macs = dict(MACS, **MACS_G84) if generic else MACS
+    per_img = [k for k in calls if k.startswith('k_dec_b4<1>') or k.startswith('k_dec_bg')]
+    rows = rows_arg or max((max(c[2] for c in calls[k]) for k in per_img), default=0)
+    out = ['\n== steady state (kernel trace, last half of each kernel\'s calls) and the roofline fraction it implies ==',
+           f'(persistent kernels: {rows} images per launch; peak {PEAK_TF} TFLOP/s fp32 MFMA; algorithmic MACs per image from DESIGN section 5)',
+           f'{"kernel":28s} {"calls":>6s} {"all_avg_us":>11s} {"steady_avg_us":>14s} {"steady_min_us":>14s} {"images":>8s} {"TFLOP/s":>9s} {"frac":>7s}']
+    fr = {}
+    for k in sorted(calls, key=lambda k: -sum(c[1] for c in calls[k])):
+        if not k.startswith('k_'):
+            continue
+        c = sorted(calls[k])
+        big = max(x[2] for x in c)
+        c = [x for x in c if x[2] == big] if k in per_img else c          # the full-size launches only
+        half = c[len(c) // 2:]
+        avg_all = sum(x[1] for x in c) / len(c) / 1e3
+        avg = sum(x[1] for x in half) / len(half) / 1e3
+        mn = min(x[1] for x in half) / 1e3
+        n_img = big if k in per_img else rows
+        if k in macs and n_img:
+            tf = 2.0 * macs[k] * n_img / (avg * 1e-6) / 1e12
+            fr[k] = tf / PEAK_TF
+            out.append(f'{k:28s} {len(c):6d} {avg_all:11.1f} {avg:14.1f} {mn:14.1f} {n_img:8d} {tf:9.1f} {tf / PEAK_TF:7.3f}')
+        else:
+            out.append(f'{k:28s} {len(c):6d} {avg_all:11.1f} {avg:14.1f} {mn:14.1f}')
+    return out, fr
+
+
+def main(d, rows_arg=0):
     out = []
     ks = glob.glob(os.path.join(d, 'kt', '**', '*kernel_stats.csv'), recursive=True)
     if ks:
-        out.append('== rocprofv3 --kernel-trace --stats (the default bench command: bench.py --steps 5 --warmup 2; the first call of a kernel is cold) ==')
+        out.append('== rocprofv3 --kernel-trace --stats (tools/gpu_profile.sh: bench.py --steps 8 --warmup 8; avg_us includes the clock ramp of the first calls -- see the steady-state table) ==')
         out.append(f'{"kernel":62s} {"calls":>6s} {"total_us":>12s} {"avg_us":>10s} {"min_us":>10s} {"pct":>6s}')
         for r in csv.DictReader(open(ks[0])):
             out.append(f'{short(r["Name"]):62s} {r["Calls"]:>6s} {float(r["TotalDurationNs"]) / 1e3:12.1f} '
                        f'{float(r["AverageNs"]) / 1e3:10.1f} {float(r["MinNs"]) / 1e3:10.1f} {float(r["Percentage"]):6.2f}')
+    st_lines, frac_steady = steady_table(d, rows_arg)
+    out += st_lines
     for sub in ('pmc_sq', 'pmc_mem', 'pmc_fetch', 'pmc_write'):
         cs = glob.glob(os.path.join(d, sub, '**', '*counter_collection.csv'), recursive=True)
         if not cs:
@@ -59,7 +111,9 @@ def main(d):
                 if r['Counter_Name'] == key:
                     mem[short(r['Kernel_Name'])][key] += float(r['Counter_Value'])
         out.append('\n== per-kernel roofline view (whole profiled run) ==')
-        out.append(f'{"kernel":28s} {"time_ms":>9s} {"MFMA_busy":>10s} {"clk_GHz":>8s} {"HBM_read_GB":>12s} {"HBM_write_GB":>13s} {"HBM_GB/s":>9s}')
+        out.append('(MFMA_busy and clk_GHz are measured INSIDE the PMC pass -- GRBM_GUI_ACTIVE over the dispatch durations of that pass; frac_steady is the')
+        out.append(' kernel-trace pass above, un-profiled clock: bench.py samples that one as roofline.sclk_mhz_under_load)')
+        out.append(f'{"kernel":28s} {"time_ms":>9s} {"MFMA_busy":>10s} {"clk_GHz":>8s} {"frac_steady":>12s} {"HBM_read_GB":>12s} {"HBM_write_GB":>13s} {"HBM_GB/s":>9s}')
         for k in sorted(kt, key=lambda k: -kt[k][1]):
             if not k.startswith('k_') or k not in sq:
                 continue
@@ -69,7 +123,8 @@ def main(d):
             clk = g / sq[k]['_dur'] if sq[k]['_dur'] else 0.0
             rd = 2 * mem[k]['FETCH_SIZE'] * 1024 / 1e9
             wr = mem[k]['WRITE_SIZE'] * 1024 / 1e9
-            out.append(f'{k:28s} {t_ms:9.3f} {busy:10.3f} {clk:8.3f} {rd:12.3f} {wr:13.3f} {(rd + wr) / (t_ms * 1e-3):9.0f}')
+            fs = f'{frac_steady[k]:12.3f}' if k in frac_steady else f'{"":12s}'
+            out.append(f'{k:28s} {t_ms:9.3f} {busy:10.3f} {clk:8.3f} {fs} {rd:12.3f} {wr:13.3f} {(rd + wr) / (t_ms * 1e-3):9.0f}')
     except Exception as ex:
         out.append(f'(no roofline table: {ex})')
     # HBM traffic of the dominant kernel per decoder image: FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts
@@ -103,4 +158,4 @@ def main(d):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)
