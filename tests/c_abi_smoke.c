@@ -1,7 +1,12 @@
 /* Plain-C consumer of include/efe_engine.h: no Python, no torch -- the drop-in boundary is a C ABI.
  * Build:  gcc tests/c_abi_smoke.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -L<pkg> -lefe_mi355x -L/opt/rocm/lib -lamdhip64 -lm
  * Loads random weights of the reference architecture (state_dict key names of SURVEY 8b), runs ModelDown.decoder,
- * calculate_G and the action posterior on device buffers, checks ranges / determinism. */
+ * calculate_G and the action posterior on device buffers, checks ranges / determinism.
+ *
+ *   c_abi_smoke <weights.bin> <tests/golden/calcG_m4s1_g115.bin>
+ * additionally loads a weight file (records: key\0, int32 ndim, int64 shape[ndim], float32 data -- written by the test from the synthetic weights
+ * the fixture was captured with) and compares efe_calculate_g, with the fixture's injected normals, against the REFERENCE's values in the committed
+ * blob (tests/golden/make_c_blob.py: derived from calcG_m4s1_g115.npz, i.e. from /root/reference/src/torchmodel.py:270-300 itself). */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
@@ -43,9 +48,63 @@ static int conv(efe_ctx* ctx, const char* name, int d0, int d1, int nbias, float
     return set_w(ctx, k, nbias, 0, 0, 0, 0.1f);
 }
 
-int main(void) {
+/* the reference-captured fixture through the plain C ABI: 0 = equal within the tolerances of tests/test_gpu_parity.py */
+static int fixture_check(efe_ctx* ctx, const char* wpath, const char* bpath) {
+    FILE* f = fopen(wpath, "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", wpath); return 1; }
+    int nw = 0;
+    for (;;) {
+        char key[128]; int k = 0, ch;
+        while ((ch = fgetc(f)) != EOF && ch != 0 && k < 127) key[k++] = (char)ch;
+        if (ch == EOF) break;
+        key[k] = 0;
+        int32_t nd; int64_t shape[4]; size_t n = 1;
+        if (fread(&nd, 4, 1, f) != 1 || nd < 1 || nd > 4 || fread(shape, 8, (size_t)nd, f) != (size_t)nd) { fprintf(stderr, "bad weight record %s\n", key); return 1; }
+        for (int i = 0; i < nd; ++i) n *= (size_t)shape[i];
+        float* h = (float*)malloc(n * sizeof(float));
+        if (fread(h, sizeof(float), n, f) != n) { fprintf(stderr, "short weight record %s\n", key); return 1; }
+        CHECK(efe_set_weight(ctx, key, h, shape, nd));
+        free(h); ++nw;
+    }
+    fclose(f);
+    CHECK(efe_commit_weights(ctx));
+    f = fopen(bpath, "rb");
+    if (!f) { fprintf(stderr, "cannot open %s\n", bpath); return 1; }
+    int32_t hdr[4]; uint64_t seed;                       /* M, S, stage, reserved; noise seed */
+    if (fread(hdr, 4, 4, f) != 4 || fread(&seed, 8, 1, f) != 1) return 1;
+    const int M = hdr[0], S = hdr[1];
+    const size_t n_in = (size_t)M * 10 + (size_t)M * 4 + (size_t)3 * S * M * 10, n_out = (size_t)7 * M;      /* G, t0, t1, t2, t2_1, t2_2, (unused) */
+    float* in = (float*)malloc(n_in * 4); float* ex = (float*)malloc(n_out * 4);
+    if (fread(in, 4, n_in, f) != n_in || fread(ex, 4, 6 * (size_t)M, f) != 6 * (size_t)M) { fprintf(stderr, "short blob\n"); return 1; }
+    fclose(f);
+    float *ds, *dpi, *deps, *dG, *dT, *dmean, *dparts;
+    HIP(hipMalloc((void**)&ds, M * 40)); HIP(hipMalloc((void**)&dpi, M * 16)); HIP(hipMalloc((void**)&deps, (size_t)3 * S * M * 40));
+    HIP(hipMalloc((void**)&dG, M * 4)); HIP(hipMalloc((void**)&dT, 3 * M * 4)); HIP(hipMalloc((void**)&dmean, M * 40)); HIP(hipMalloc((void**)&dparts, 2 * M * 4));
+    HIP(hipMemcpy(ds, in, M * 40, hipMemcpyHostToDevice)); HIP(hipMemcpy(dpi, in + M * 10, M * 16, hipMemcpyHostToDevice));
+    HIP(hipMemcpy(deps, in + M * 14, (size_t)3 * S * M * 40, hipMemcpyHostToDevice));
+    efe_noise nz = {seed, (uint32_t)hdr[2], 0u, 0u, 0u};
+    CHECK(efe_calculate_g(ctx, ds, dpi, M, S, 0, &nz, deps, dG, dT, NULL, dmean, NULL, dparts, NULL));
+    float got[7 * 64];
+    HIP(hipMemcpy(got, dG, M * 4, hipMemcpyDeviceToHost)); HIP(hipMemcpy(got + M, dT, 3 * M * 4, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(got + 4 * M, dparts, 2 * M * 4, hipMemcpyDeviceToHost));
+    float t21 = 1.f;
+    for (int i = 0; i < M; ++i) if (fabsf(ex[4 * M + i]) > t21) t21 = fabsf(ex[4 * M + i]);
+    const float gtol = 1e-6f * t21 + 5e-4f;               /* tests/test_gpu_parity.py::gtol */
+    const char* names[6] = {"G", "term0", "term1", "term2", "term2_1", "term2_2"};
+    for (int q = 0; q < 6; ++q)
+        for (int i = 0; i < M; ++i) {
+            const float e = ex[q * M + i], g = got[q * M + i];
+            const float tol = (q == 0 || q == 3) ? gtol : (q == 1 || q == 2) ? 1e-4f : 1e-6f * fabsf(e) + 1e-3f;
+            if (!(fabsf(g - e) <= tol)) { fprintf(stderr, "fixture: %s[%d] = %.7g, reference %.7g (tol %g)\n", names[q], i, g, e, tol); return 1; }
+        }
+    printf("c_abi_smoke fixture OK: %d weight tensors, calculate_G(M=%d, S=%d) == reference capture, G[0]=%.6f (reference %.6f)\n", nw, M, S, got[0], ex[0]);
+    hipFree(ds); hipFree(dpi); hipFree(deps); hipFree(dG); hipFree(dT); hipFree(dmean); hipFree(dparts); free(in); free(ex);
+    return 0;
+}
+
+int main(int argc, char** argv) {
     efe_ctx* ctx = NULL;
-    if (efe_abi_version() != 4) { fprintf(stderr, "abi version\n"); return 1; }
+    if (efe_abi_version() != 5) { fprintf(stderr, "abi version\n"); return 1; }
     if (efe_create(&ctx, 0)) { fprintf(stderr, "efe_create failed (no HIP device?)\n"); return 2; }
     CHECK(lin(ctx, "top.qpi_net.0", 128, 10)); CHECK(lin(ctx, "top.qpi_net.2", 128, 128)); CHECK(lin(ctx, "top.qpi_net.4", 4, 128));
     CHECK(lin(ctx, "mid.ps_net.0", 512, 14)); CHECK(lin(ctx, "mid.ps_net.3", 512, 512)); CHECK(lin(ctx, "mid.ps_net.6", 512, 512));
@@ -132,6 +191,7 @@ int main(void) {
     if (strlen(efe_last_error(ctx)) == 0) { fprintf(stderr, "no error message\n"); return 1; }
     CHECK(efe_decoder(ctx, ds, M, &nz, dpo, NULL));
     printf("c_abi_smoke OK  G[0]=%g  macs(last call)=%lld\n", hG[0][0], (long long)efe_last_call_macs(ctx));
+    if (argc > 2 && fixture_check(ctx, argv[1], argv[2])) return 1;
     efe_destroy(ctx);
     return 0;
 }

@@ -255,7 +255,7 @@ def test_lockstep_batch_with_early_stops_contains_the_reference_episodes(golden,
     frames = torch.cat([torch.from_numpy(g['frames']), torch.from_numpy(synth.make_frames(78, E - E0))], 0)
     m._stage = int(g['stage'])
     out, visits = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
-    planner = next(pl for pl in m._planners.values() if pl.E == E)
+    planner = next(pl for pl in m._planners.values() if pl.E == E and pl.p.threshold == p.threshold)
     assert planner.overlap and planner._ids is not None and len(planner._ids[1]) < E          # the batch WAS compacted
     for e in range(E0):
         _check_deep(g, e, out[e], visits[e])
@@ -759,9 +759,17 @@ def test_c_abi_from_plain_c(tmp_path):
            '-D__HIP_PLATFORM_AMD__', '-L' + pkg, '-lefe_mi355x', '-L/opt/rocm/lib', '-lamdhip64', '-lm',
            '-Wl,-rpath,' + pkg, '-Wl,-rpath,/opt/rocm/lib', '-o', exe]
     subprocess.run(cmd, check=True)
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    # the weights the committed fixture blob was captured with, as a flat file the C program loads through efe_set_weight
+    g = load_golden('calcG_m4s1_g115')
+    wfile = str(tmp_path / 'weights.bin')
+    with open(wfile, 'wb') as f:
+        for key, arr in synth.make_weights(int(g['wseed']), float(g['gain'])).items():
+            arr = np.ascontiguousarray(arr, dtype='<f4')
+            f.write(key.encode() + b'\0' + np.int32(arr.ndim).tobytes() + np.asarray(arr.shape, dtype='<i8').tobytes() + arr.tobytes())
+    blob = os.path.join(ROOT, 'tests', 'golden', 'calcG_m4s1_g115.bin')
+    r = subprocess.run([exe, wfile, blob], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert 'c_abi_smoke OK' in r.stdout
+    assert 'c_abi_smoke OK' in r.stdout and 'c_abi_smoke fixture OK' in r.stdout
 
 
 def test_reparameterize_through_engine(models):
