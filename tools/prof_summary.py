@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Summarise a tools/gpu_profile.sh output directory (rocprofv3 csv) into a small text table:
-per kernel: calls, avg us, share; the STEADY-STATE average (the last half of each kernel's calls in the kernel trace: the first launches
-after idle run inside the clock ramp) with the roofline fraction recomputed from it (algorithmic FLOPs of DESIGN section 5 / steady
-average), next to MFMA-busy and the shader clock of the PMC pass; PMC counters averaged per dispatch.
+per kernel: calls, avg us, share; the STEADY-STATE duration (the MEDIAN of each kernel's calls in the kernel trace: the first two launches
+after every idle gap -- start of the run, the barrier between warm-up and timed steps -- run inside the clock ramp) with the roofline
+fraction recomputed from it (algorithmic FLOPs of DESIGN section 5 / median), next to MFMA-busy and the shader clock of the PMC pass; PMC counters averaged per dispatch.
 
   python tools/prof_summary.py <dir> [rows]        rows = decoder images per launch of the persistent kernels (default: the largest
                                                    one-workgroup-per-image grid in the trace, i.e. 19 200 for the headline)"""
@@ -26,7 +26,7 @@ MACS_G84 = {'k_dec_bg<3>': 21 * 21 * 4 * 9 * 64 * 32 + 84 * 84 * 9 * 32 * 3, 'k_
 
 
 def steady_table(d, rows_arg):
-    """-> lines; per kernel the mean duration of the LAST HALF of its calls in the kernel trace and the roofline fraction it implies"""
+    """-> lines; per kernel the MEDIAN duration of its calls in the kernel trace and the roofline fraction it implies"""
     tr = glob.glob(os.path.join(d, 'kt', '**', '*kernel_trace.csv'), recursive=True)
     if not tr:
         return ['(no kernel trace csv: steady-state table skipped)'], {}
@@ -39,9 +39,9 @@ def steady_table(d, rows_arg):
     macs = dict(MACS, **MACS_G84) if generic else MACS
     per_img = [k for k in calls if k.startswith('k_dec_b4<1>') or k.startswith('k_dec_bg')]
     rows = rows_arg or max((max(c[2] for c in calls[k]) for k in per_img), default=0)
-    out = ['\n== steady state (kernel trace, last half of each kernel\'s calls) and the roofline fraction it implies ==',
+    out = ['\n== steady state (kernel trace, median over each kernel\'s calls) and the roofline fraction it implies ==',
            f'(persistent kernels: {rows} images per launch; peak {PEAK_TF} TFLOP/s fp32 MFMA; algorithmic MACs per image from DESIGN section 5)',
-           f'{"kernel":28s} {"calls":>6s} {"all_avg_us":>11s} {"steady_avg_us":>14s} {"steady_min_us":>14s} {"images":>8s} {"TFLOP/s":>9s} {"frac":>7s}']
+           f'{"kernel":28s} {"calls":>6s} {"all_avg_us":>11s} {"median_us":>14s} {"min_us":>14s} {"images":>8s} {"TFLOP/s":>9s} {"frac":>7s}']
     fr = {}
     for k in sorted(calls, key=lambda k: -sum(c[1] for c in calls[k])):
         if not k.startswith('k_'):
@@ -49,10 +49,10 @@ def steady_table(d, rows_arg):
         c = sorted(calls[k])
         big = max(x[2] for x in c)
         c = [x for x in c if x[2] == big] if k in per_img else c          # the full-size launches only
-        half = c[len(c) // 2:]
-        avg_all = sum(x[1] for x in c) / len(c) / 1e3
-        avg = sum(x[1] for x in half) / len(half) / 1e3
-        mn = min(x[1] for x in half) / 1e3
+        durs = sorted(x[1] for x in c)
+        avg_all = sum(durs) / len(durs) / 1e3
+        avg = (durs[(len(durs) - 1) // 2] + durs[len(durs) // 2]) / 2e3
+        mn = durs[0] / 1e3
         n_img = big if k in per_img else rows
         if k in macs and n_img:
             tf = 2.0 * macs[k] * n_img / (avg * 1e-6) / 1e12
