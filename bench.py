@@ -336,6 +336,20 @@ class Ranks:
             return {}
         return {'rccl_ranks': int(self.dist.get_world_size()), 'backend': str(self.dist.get_backend())}
 
+    def check_devices(self, model, local, share_device):
+        """rank r really runs on GPU r: the engine context's own device (efe_get_device) is the local rank's, and no two ranks of the job hold
+        the same PCI device (unless --share-device asked for exactly that) -> the per-rank (device index, PCI bus id) list for the line"""
+        idx, bus = model.engine_device()
+        if idx != local or idx != torch.cuda.current_device():
+            sys.exit(f'[bench] rank {self.rank}: engine context on device {idx}, expected local rank {local} (current device {torch.cuda.current_device()})')
+        if not self.on:
+            return [[idx, bus]]
+        mine = [None] * self.world
+        self.dist.all_gather_object(mine, [idx, bus])
+        if not share_device and len({b for _, b in mine}) != self.world:
+            sys.exit(f'[bench] {self.world} ranks on {len({b for _, b in mine})} distinct GPUs: {mine} -- one rank per GPU is required (or --share-device)')
+        return mine
+
 
 def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min_total_s=2.5):
     """BASELINE configs[2]/[3]: E episodes per GPU, each a full MCTS decision (50 expansions with S MC samples,
@@ -384,6 +398,7 @@ def bench_mcts(a, model, device, rk, steps, warmup, with_cpu, threshold=2.0, min
            'iterations_done_mean': float(np.mean(iters)), 'iterations_done_min': int(min(iters)),
            'work_fraction_mean': float(np.mean(work_timed)), 'work_fraction_per_decision_batch': [round(x, 4) for x in work_timed]}
     out.update(rk.info())
+    out['devices'] = rk.check_devices(model, torch.cuda.current_device(), bool(getattr(a, 'share_device', False)))
     if rk.on:
         out['per_rank_ms_per_step'] = [round(x, 3) for x in per_rank_ms]
         out['all_gather_ms'] = rk.time_gather(last['P'], world * E)
@@ -550,6 +565,7 @@ def bench_generic(a, device, rk, steps, warmup, with_cpu, min_total_s=2.0):
            'roofline': {'bound': 'mfma', 'kernel': 'whole step (generic-geometry path)', 'achieved': tf / world,
                         'peak': PEAK_FP32_MFMA_TF, 'unit': 'TFLOP/s', 'frac': tf / world / PEAK_FP32_MFMA_TF, 'traffic': None}}
     out.update(rk.info())
+    out['devices'] = rk.check_devices(model, torch.cuda.current_device(), bool(getattr(a, 'share_device', False)))
     if rk.on:
         out['per_rank_ms_per_step'] = [round(x, 3) for x in per_rank_ms]
         out['all_gather_ms'] = rk.time_gather(last['P'], world * E)
@@ -730,6 +746,7 @@ def main():
             breakdown[c] = (ms / nb, n // nb, ms, n)
         model.prof_enable(False)
 
+    devs = rk.check_devices(model, local, a.share_device)           # every rank (a collective at N > 1)
     out = None
     if rank == 0:
         value = world * R * a.steps / dt
@@ -747,6 +764,7 @@ def main():
             'frac_of_fp32_mfma_peak_whole_step': value * 2 * MAC_ROLLOUT / 1e12 / world / PEAK_FP32_MFMA_TF,
         }
         out.update(rk.info())
+        out['devices'] = devs
         if use_dist:
             out['per_rank_ms_per_step'] = [round(x, 3) for x in per_rank_ms]
             out['all_gather_ms'] = gather_ms

@@ -11,7 +11,7 @@ EXPORTS = ['efe_create', 'efe_destroy', 'efe_last_error', 'efe_abi_version', 'ef
            'efe_rollout', 'efe_trajectory', 'efe_simulate', 'efe_action_posterior', 'efe_last_call_macs',
            'efe_prof_enable', 'efe_prof_classes', 'efe_prof_read', 'efe_env_reset', 'efe_env_step', 'efe_env_render',
            'efe_check_reward', 'efe_reparameterize', 'efe_mcts_select', 'efe_mcts_expand', 'efe_mcts_backprop', 'efe_mcts_stop',
-           'efe_build_id', 'efe_reserve', 'efe_rollout_scratch_bytes', 'efe_arena_stats', 'efe_env_new_image', 'efe_create_cfg', 'efe_get_config', 'efe_set_row_mask',
+           'efe_build_id', 'efe_reserve', 'efe_rollout_scratch_bytes', 'efe_arena_stats', 'efe_env_new_image', 'efe_create_cfg', 'efe_get_config', 'efe_get_device', 'efe_set_row_mask',
            'efe_calculate_g_rows', 'efe_simulate_rows', 'efe_mcts_step']
 ABI_VERSION = 5
 
@@ -82,6 +82,7 @@ def load():
     nzp = C.POINTER(EfeNoise)
     lib.efe_create.argtypes = [C.POINTER(p), i]; lib.efe_create.restype = i
     lib.efe_get_config.argtypes = [p, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i)]; lib.efe_get_config.restype = i
+    lib.efe_get_device.argtypes = [p, C.POINTER(i), C.c_char_p, i]; lib.efe_get_device.restype = i
     lib.efe_create_cfg.argtypes = [C.POINTER(p), i, i, i, i, i]; lib.efe_create_cfg.restype = i
     lib.efe_destroy.argtypes = [p]; lib.efe_destroy.restype = None
     lib.efe_last_error.argtypes = [p]; lib.efe_last_error.restype = C.c_char_p

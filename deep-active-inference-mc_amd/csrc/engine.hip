@@ -89,6 +89,7 @@ struct efe_ctx {
     int64_t enc_tiled = 1;         // generic path: LDS-tiled encoder layers 1 and 2 (k_conv_e); 0 = k_conv_g for every layer (A/B, parity of the fallback)
     int64_t dec_split = 1;         // dSprites path: decoder launches of <= 128 images run k_dec_b4 with four workgroups per image (0 = never: A/B)
     int64_t fuse_final_g = 1;      // generic path: last two decoder layers in one kernel (k_dec_bg); 0 = separate launches (A/B, parity tests of k_final_g)
+    int64_t check_rows = 0;        // development: range-check efe_rows.ids on the host before every _rows call
     int64_t last_macs = 0;
     const uint8_t* row_mask = nullptr; int row_mask_div = 1;      // efe_set_row_mask
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
@@ -722,6 +723,16 @@ int efe_get_config(efe_ctx* ctx, int* s_dim, int* pi_dim, int* channels, int* re
     return 0;
 }
 
+int efe_get_device(efe_ctx* ctx, int* device, char* pci_bus_id, int pci_bus_id_len) {
+    if (!ctx) return 1;
+    if (device) *device = ctx->device;
+    if (pci_bus_id && pci_bus_id_len > 0) {
+        pci_bus_id[0] = 0;
+        if (hipDeviceGetPCIBusId(pci_bus_id, pci_bus_id_len, ctx->device) != hipSuccess) return ctx->fail("efe_get_device: hipDeviceGetPCIBusId failed");
+    }
+    return 0;
+}
+
 const char* efe_last_error(efe_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const int64_t* shape, int ndim) {
@@ -748,6 +759,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "dec_chunk_g")) { if (value < 1) return ctx->fail("dec_chunk_g < 1"); ctx->dec_chunk_g = value; return 0; }
     if (!strcmp(name, "poison")) { ctx->poison = value; return 0; }
     if (!strcmp(name, "trace")) { ctx->trace = value; return 0; }
+    if (!strcmp(name, "check_rows")) { ctx->check_rows = value ? 1 : 0; return 0; }
     if (!strcmp(name, "arena_align")) { if (value < 256 || (value & (value - 1))) return ctx->fail("arena_align must be a power of two >= 256"); ctx->arena_align = value; return 0; }
     if (!strcmp(name, "mid_unfused")) { ctx->mid_unfused = value; return 0; }
     if (!strcmp(name, "head_unfused")) { ctx->head_unfused = value; return 0; }
@@ -1177,10 +1189,26 @@ int efe_reparameterize(efe_ctx* ctx, const float* mean, const float* logvar, int
 // ---- EFE level -----------------------------------------------------------------------------------------
 // the row set of a call: argument if given, else the context's (deprecated) efe_set_row_mask state
 struct RowSet { const uint8_t* mask; const int32_t* ids; int div; };
-static int row_set(efe_ctx* ctx, const efe_rows* rows, int n_rows, int fixed_div, RowSet& out, const char* who) {
+static int row_set(efe_ctx* ctx, const efe_rows* rows, int n_rows, int fixed_div, RowSet& out, const char* who, hipStream_t st) {
     if (!rows) { out = RowSet{ctx->row_mask, nullptr, fixed_div > 0 ? fixed_div : ctx->row_mask_div}; return 0; }
     const int div = fixed_div > 0 ? fixed_div : rows->rows_per_entry;
     if (div < 1 || ((rows->mask || rows->ids) && n_rows % div != 0)) { ctx->fail((std::string(who) + ": efe_rows.rows_per_entry must divide the row count").c_str()); return 1; }
+    const int n_entries = n_rows / div;
+    if (rows->n_total < 0 || (rows->n_total > 0 && n_entries > rows->n_total)) {
+        ctx->fail((std::string(who) + ": the call has " + std::to_string(n_entries) + " entries, efe_rows.n_total says " + std::to_string(rows->n_total)).c_str());
+        return 1;
+    }
+    if (ctx->check_rows && rows->ids && rows->n_total > 0) {          // development option: ids range-checked on the host (synchronises)
+        std::vector<int32_t> hid((size_t)n_entries);
+        if (hipMemcpyAsync(hid.data(), rows->ids, (size_t)n_entries * sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            ctx->fail((std::string(who) + ": check_rows could not read efe_rows.ids").c_str()); return 1;
+        }
+        for (int i = 0; i < n_entries; ++i)
+            if (hid[(size_t)i] < 0 || hid[(size_t)i] >= rows->n_total) {
+                ctx->fail((std::string(who) + ": efe_rows.ids[" + std::to_string(i) + "] = " + std::to_string(hid[(size_t)i]) + " is outside [0, n_total = " + std::to_string(rows->n_total) + ")").c_str());
+                return 1;
+            }
+    }
     out = RowSet{rows->mask, rows->ids, div};
     return 0;
 }
@@ -1207,7 +1235,7 @@ int efe_calculate_g_rows(efe_ctx* ctx, const float* s0, const float* pi0, int M,
     io.k0 = (uint32_t)nz->seed; io.k1 = (uint32_t)(nz->seed >> 32); io.stage0 = nz->stage; io.row_offset = nz->row_offset;
     io.eps = eps; io.G = G; io.terms = terms; io.ps1 = ps1; io.ps1_mean = ps1_mean; io.po1 = po1; io.t2parts = t2parts;
     RowSet rs;
-    if (row_set(ctx, rows, M, 0, rs, "efe_calculate_g_rows")) return 1;
+    if (row_set(ctx, rows, M, 0, rs, "efe_calculate_g_rows", st)) return 1;
     io.mask = rs.mask; io.ids = rs.ids; io.mask_div = rs.div;
     if (run_core(ctx, io, st)) return 1;
     return finish(ctx, st);
@@ -1291,20 +1319,23 @@ int efe_simulate_rows(efe_ctx* ctx, const float* starting_s, int E, int depth, i
     const uint32_t k0 = (uint32_t)nz->seed, k1 = (uint32_t)(nz->seed >> 32);
     const int T = depth;
     RowSet rs;
-    if (row_set(ctx, rows, E, 1, rs, "efe_simulate_rows")) return 1;      // one episode = one entry
+    if (row_set(ctx, rows, E, 1, rs, "efe_simulate_rows", (hipStream_t)stream)) return 1;      // one episode = one entry
     float* s0t = ctx->allocT<float>((size_t)E * T * 10);
     float* ps1t = ctx->allocT<float>((size_t)E * T * 10);
     float* mt = ctx->allocT<float>((size_t)E * T * 10);
     float* lvt = ctx->allocT<float>((size_t)E * T * 10);
     float* Gt = ctx->allocT<float>((size_t)E * T);
-    float* trp = ctx->allocT<float>((size_t)2 * E * T * 32);        // the trajectory core's transition rows, written by the chain kernel
+    // the trajectory core's transition rows, written by the chain kernel -- unless the A/B option mid_unfused asks for the layer-by-layer
+    // transition: then the trajectory's loop-2 transition goes through run_mid like every other one (the chain kernel keeps its own rollout)
+    float* trp = ctx->allocT<float>((size_t)2 * E * T * 32);
+    float* pre_tr = ctx->mid_unfused ? nullptr : trp;
     if (!s0t || !ps1t || !mt || !lvt || !Gt || !trp) return 1;
     {   // the whole habit-policy rollout (depth x (encode_s, sample, transition, reparameterise)) is one launch (fused.hip)
         SimChainArgs sa{};
         sa.W = ctx->mid16; sa.H = ctx->top16; sa.s0 = starting_s; sa.E = E; sa.T = T; sa.use_means = use_means;
         sa.k0 = k0; sa.k1 = k1; sa.stage = nz->stage; sa.row_offset = nz->row_offset;
         sa.eps_inj = eps; sa.u_inj = u; sa.ids = rs.ids;
-        sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0; sa.pi_dim = ctx->pi_dim; sa.tr = trp;
+        sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0; sa.pi_dim = ctx->pi_dim; sa.tr = pre_tr;
         ctx->cls = PROF_MID;
         hipEvent_t e0 = ctx->prof_begin(st);
         launch_sim_chain(sa, st);
@@ -1313,7 +1344,7 @@ int efe_simulate_rows(efe_ctx* ctx, const float* starting_s, int E, int depth, i
         ctx->last_macs += (int64_t)E * T * (2 * ctx->mac_trans + ctx->mac_habit);      // the rollout's transition and the trajectory's loop-2 transition
     }
     if (trajectory_impl(ctx, s0t, ps1t, mt, lvt, pi0, E * T, k0, k1, nz->stage, nz->row_offset * (uint32_t)T,
-                        eps ? eps + (size_t)T * E * 10 : nullptr, Gt, rs.mask, rs.ids, T, trp, st)) return 1;     // trajectory row e * T + t belongs to episode slot e
+                        eps ? eps + (size_t)T * E * 10 : nullptr, Gt, rs.mask, rs.ids, T, pre_tr, st)) return 1;     // trajectory row e * T + t belongs to episode slot e
     launch_mean_rows(Gt, G_mean, E, T, st);
     return finish(ctx, st);
 }

@@ -45,8 +45,8 @@ const float* optp(const OptT& t, Tensor& keep, const char* name, int64_t numel) 
     return keep.data_ptr<float>();
 }
 // the optional row set of a call (efe_rows): mask = uint8 [entries of the un-compacted batch], ids = int32 [entries of this call]
-struct RowsArg { efe_rows r{nullptr, nullptr, 1}; Tensor mk, ik; const efe_rows* ptr = nullptr; };
-void rows_arg(RowsArg& ra, const OptT& mask, const OptT& ids, int64_t rows_per_entry, int64_t n_entries) {
+struct RowsArg { efe_rows r{nullptr, nullptr, 1, 0}; Tensor mk, ik; const efe_rows* ptr = nullptr; };
+void rows_arg(RowsArg& ra, const OptT& mask, const OptT& ids, int64_t rows_per_entry, int64_t n_entries, int64_t n_total) {
     const bool hm = mask.has_value() && mask->defined(), hi = ids.has_value() && ids->defined();
     if (!hm && !hi) return;
     TORCH_CHECK(rows_per_entry >= 1, "efe: rows_per_entry must be >= 1");
@@ -54,6 +54,9 @@ void rows_arg(RowsArg& ra, const OptT& mask, const OptT& ids, int64_t rows_per_e
     if (hm) {
         TORCH_CHECK(mask->is_cuda() && mask->scalar_type() == at::kByte && mask->is_contiguous(), "efe: row mask must be a contiguous uint8 HIP tensor");
         TORCH_CHECK(hi || mask->numel() >= n_entries, "efe: row mask has ", mask->numel(), " entries, the call has ", n_entries);
+        // the mask is indexed by entry ID: it must cover the whole un-compacted batch (n_total; with ids and no n_total the bound is unknown here)
+        TORCH_CHECK(n_total <= 0 || mask->numel() >= n_total, "efe: row mask has ", mask->numel(), " entries, the un-compacted batch has ", n_total);
+        if (n_total <= 0 && !hi) n_total = mask->numel();
         ra.mk = *mask; ra.r.mask = ra.mk.data_ptr<uint8_t>();
     }
     if (hi) {
@@ -61,6 +64,8 @@ void rows_arg(RowsArg& ra, const OptT& mask, const OptT& ids, int64_t rows_per_e
         TORCH_CHECK(ids->numel() == n_entries, "efe: row ids has ", ids->numel(), " entries, the call has ", n_entries);
         ra.ik = *ids; ra.r.ids = ra.ik.data_ptr<int32_t>();
     }
+    TORCH_CHECK(n_total >= 0 && n_total <= INT32_MAX, "efe: bad n_total");
+    ra.r.n_total = (int32_t)n_total;
     ra.ptr = &ra.r;
 }
 void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
@@ -132,7 +137,7 @@ std::tuple<Tensor, Tensor, Tensor> habit(int64_t h, const Tensor& s_) {
 // calculate_G / calculate_G_mean, torchmodel.py:270-327
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> calculate_g(int64_t h, const Tensor& s0_, const Tensor& pi0_, int64_t samples,
                                                                        bool mean_mode, int64_t seed, int64_t stage, int64_t row_offset,
-                                                                       const OptT& eps, const OptT& mask, const OptT& ids, int64_t rows_per_entry) {
+                                                                       const OptT& eps, const OptT& mask, const OptT& ids, int64_t rows_per_entry, int64_t n_total) {
     efe_ctx* c = CTX(h);
     Tensor s0 = in(s0_, "s0"), pi0 = in(pi0_, "pi0"), ek;
     const Geo gq = geo(c);
@@ -146,7 +151,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> calculate_g(int64_t h
     efe_noise nz = noise(seed, stage, 0, 0, row_offset);
     RowsArg ra;
     TORCH_CHECK(rows_per_entry < 1 || M % rows_per_entry == 0, "efe: rows_per_entry must divide the row count");
-    rows_arg(ra, mask, ids, rows_per_entry, rows_per_entry >= 1 ? M / rows_per_entry : M);
+    rows_arg(ra, mask, ids, rows_per_entry, rows_per_entry >= 1 ? M / rows_per_entry : M, n_total);
     ok(c, efe_calculate_g_rows(c, s0.data_ptr<float>(), pi0.data_ptr<float>(), M, S, mean_mode ? 1 : 0, &nz, optp(eps, ek, "eps", (int64_t)3 * S * M * 10),
                           ra.ptr, G.data_ptr<float>(), terms.data_ptr<float>(), ps1.data_ptr<float>(), ps1m.data_ptr<float>(), po1.data_ptr<float>(),
                           parts.data_ptr<float>(), stream_of(s0)));
@@ -190,7 +195,7 @@ Tensor trajectory(int64_t h, const Tensor& s0_, const Tensor& ps1_, const Tensor
 
 // mcts_step_simulate for E lock-step episodes, torchmodel.py:354-393
 std::tuple<Tensor, Tensor, Tensor> simulate(int64_t h, const Tensor& s_, int64_t depth, bool use_means, int64_t seed, int64_t stage,
-                                            int64_t row_offset, const OptT& eps, const OptT& u, const OptT& mask, const OptT& ids) {
+                                            int64_t row_offset, const OptT& eps, const OptT& u, const OptT& mask, const OptT& ids, int64_t n_total) {
     efe_ctx* c = CTX(h);
     Tensor s = in(s_, "starting_s"), ek, uk;
     const int E = rows(s, 10, "starting_s");
@@ -200,7 +205,7 @@ std::tuple<Tensor, Tensor, Tensor> simulate(int64_t h, const Tensor& s_, int64_t
     Tensor G = at::empty({E}, op), pi0 = at::empty({E, depth, A}, op), q0 = at::empty({E, A}, op);
     efe_noise nz = noise(seed, stage, 0, 0, row_offset);
     RowsArg ra;
-    rows_arg(ra, mask, ids, 1, E);
+    rows_arg(ra, mask, ids, 1, E, n_total);
     ok(c, efe_simulate_rows(c, s.data_ptr<float>(), E, (int)depth, use_means ? 1 : 0, &nz, optp(eps, ek, "eps", (int64_t)4 * depth * E * 10),
                        optp(u, uk, "u", depth * E), ra.ptr, G.data_ptr<float>(), pi0.data_ptr<float>(), q0.data_ptr<float>(), stream_of(s)));
     return {G, pi0, q0};
@@ -249,10 +254,10 @@ TORCH_LIBRARY(efe, m) {
     m.def("decoder(int ctx, Tensor s, int seed, int stage, int pass_id, int sample, int row_offset) -> Tensor");
     m.def("encoder(int ctx, Tensor o, int seed, int stage, int pass_id, int sample, int row_offset, Tensor? eps, bool want_s) -> (Tensor s, Tensor mean, Tensor logvar)");
     m.def("habit(int ctx, Tensor s) -> (Tensor logits, Tensor q, Tensor logq)");
-    m.def("calculate_g(int ctx, Tensor s0, Tensor pi0, int samples, bool mean_mode, int seed, int stage, int row_offset, Tensor? eps, Tensor? mask=None, Tensor? ids=None, int rows_per_entry=1) -> (Tensor G, Tensor terms, Tensor ps1, Tensor ps1_mean, Tensor po1, Tensor t2parts)");
+    m.def("calculate_g(int ctx, Tensor s0, Tensor pi0, int samples, bool mean_mode, int seed, int stage, int row_offset, Tensor? eps, Tensor? mask=None, Tensor? ids=None, int rows_per_entry=1, int n_total=0) -> (Tensor G, Tensor terms, Tensor ps1, Tensor ps1_mean, Tensor po1, Tensor t2parts)");
     m.def("rollout(int ctx, Tensor o, Tensor pi, int steps, int samples, bool calc_mean, bool per_stage_mean, int seed, int stage, int row_offset, Tensor? eps) -> (Tensor sum_G, Tensor sum_terms, Tensor po1)");
     m.def("trajectory(int ctx, Tensor s0_traj, Tensor ps1_traj, Tensor ps1_mean_traj, Tensor ps1_logvar_traj, Tensor pi0_traj, int seed, int stage, int row_offset, Tensor? eps) -> Tensor");
-    m.def("simulate(int ctx, Tensor starting_s, int depth, bool use_means, int seed, int stage, int row_offset, Tensor? eps, Tensor? u, Tensor? mask=None, Tensor? ids=None) -> (Tensor G, Tensor pi0, Tensor Qpi0)");
+    m.def("simulate(int ctx, Tensor starting_s, int depth, bool use_means, int seed, int stage, int row_offset, Tensor? eps, Tensor? u, Tensor? mask=None, Tensor? ids=None, int n_total=0) -> (Tensor G, Tensor pi0, Tensor Qpi0)");
     m.def("action_posterior(int ctx, Tensor sum_G, int n, float temperature) -> (Tensor P, Tensor logP)");
     m.def("check_reward(int ctx, Tensor o) -> Tensor");
     m.def("reparameterize(int ctx, Tensor mean, Tensor logvar, int seed, int stage, int pass_id, int sample, int row_offset, Tensor? eps) -> Tensor");

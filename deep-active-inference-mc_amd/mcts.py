@@ -275,6 +275,7 @@ class BatchedMCTS:
         self.ev_snap = [torch.cuda.Event() for _ in range(4)]
         self.h_ids = torch.zeros(4, E, dtype=torch.int64).pin_memory()
         self._sim_out = None
+        self._rows_cache = {}
         self._ids = None                    # (int32 device tensor of live episode indices, the same as a host list, int64 copy for torch indexing)
         # The simulation of an iteration (habit rollout from the leaf + G over its trajectory: ~1 ms of small launches) is
         # independent of the expansion of the same leaf (~6 ms of large ones): with more than a few episodes it runs on a second
@@ -305,8 +306,13 @@ class BatchedMCTS:
         from .model import Rows
         if mask is None and self._ids is None:
             return None
-        ids, ids_host = (self._ids[0], self._ids[1]) if self._ids is not None else (None, None)
-        return Rows(mask=mask, ids=ids, rows_per_entry=rows_per_entry, ids_host=ids_host)
+        # one Rows object per (mask, rows_per_entry) and compaction: built where the batch is compacted, reused by every call until the next one
+        key = (None if mask is None else mask.data_ptr(), rows_per_entry)
+        r = self._rows_cache.get(key)
+        if r is None:
+            ids, ids_host = (self._ids[0], self._ids[1]) if self._ids is not None else (None, None)
+            r = self._rows_cache[key] = Rows(mask=mask, ids=ids, rows_per_entry=rows_per_entry, ids_host=ids_host, n_total=self.E)
+        return r
 
     def _compact(self, n_live):
         """gather the live episodes into a dense batch for the following iterations (called where the host has just read the active count:
@@ -316,6 +322,7 @@ class BatchedMCTS:
             return
         idx = torch.nonzero(self.active).flatten()
         self._ids = (idx.to(torch.int32).contiguous(), idx.cpu().tolist(), idx)
+        self._rows_cache = {}
 
     def _compact_host(self, snap, n_live):
         """the same from a host snapshot of `active` (the lagged check): no device synchronisation at all"""
@@ -328,6 +335,7 @@ class BatchedMCTS:
         stage[:len(ids)] = torch.from_numpy(ids)
         idx = stage[:len(ids)].to(self.active.device, non_blocking=True)
         self._ids = (idx.to(torch.int32).contiguous(), ids.tolist(), idx)
+        self._rows_cache = {}
 
     def _expand(self, nodes, mask, states_rep, stage=None, use_mask=True):
         """ONE engine call over E x pi_dim rows (Node.expand, mcts.py:64-86); tree bookkeeping only where mask[e]"""
@@ -427,7 +435,7 @@ class BatchedMCTS:
         # host round trip involved), and where the host learns the active count anyway the live episodes are compacted into a dense batch
         skip = bool(getattr(p, 'skip_stopped', True))
         compact = skip and bool(getattr(p, 'compact_stopped', True))
-        self._ids = None
+        self._ids, self._rows_cache = None, {}
         if compact and not bool(active_h.all()):
             self._compact(int(active_h.sum()))
         self._expand(self.root_nodes, active, self.S[:, 0].repeat_interleave(A, dim=0).contiguous(), stage=st_root, use_mask=skip)

@@ -230,14 +230,17 @@ class Rows:
     entries of `rows_per_entry` consecutive rows (the pi_dim action rows of an episode; simulate_batch: one episode = one entry).
       mask : uint8 device tensor indexed by entry ID, read when the kernels run -- dead entries are skipped, their outputs unspecified
       ids  : int32 device tensor, entry slot -> entry ID: a COMPACTED call (only the live episodes) that still draws the noise of the
-             episodes it holds; `ids_host` (the same indices as a host sequence) is needed only with injected noise (eps_source)."""
+             episodes it holds; `ids_host` (the same indices as a host sequence) is needed only with injected noise (eps_source)
+      n_total : entries of the un-compacted batch (length of `mask`, exclusive bound of every id); 0 = not stated.  The engine rejects a
+             call with more entries, and with set_option('check_rows', 1) range-checks the ids on the host before the launch."""
 
-    def __init__(self, mask=None, ids=None, rows_per_entry=1, ids_host=None):
+    def __init__(self, mask=None, ids=None, rows_per_entry=1, ids_host=None, n_total=0):
         for t, dt, nm in ((mask, torch.uint8, 'mask'), (ids, torch.int32, 'ids')):
             if t is not None and (t.dtype != dt or not t.is_cuda or not t.is_contiguous()):
                 raise ValueError(f'Rows.{nm}: a contiguous {dt} tensor on the model device is required')
-        self.mask, self.ids, self.rows_per_entry = mask, ids, int(rows_per_entry)
-        self.ids_host = None if ids_host is None else [int(i) for i in ids_host]
+        self.mask, self.ids, self.rows_per_entry, self.n_total = mask, ids, int(rows_per_entry), int(n_total)
+        # (kept by reference: the planner builds one Rows per compaction and reuses it for every call of the iterations that follow)
+        self.ids_host = ids_host
 
     def host_rows(self, div):
         """global-within-rank row index of every row of the call, for injected noise"""
@@ -388,6 +391,14 @@ class ActiveInferenceModel:
         self._row_mask = mask
         e.check(e.lib.efe_set_row_mask(e.ctx, C.c_void_p(mask.data_ptr()), int(rows_per_entry)))
 
+    def engine_device(self):
+        """-> (HIP device index, PCI bus id) of the engine context (efe_get_device): the GPU the kernels of this model run on"""
+        e = self._engine
+        dev = C.c_int(-1)
+        buf = C.create_string_buffer(64)
+        e.check(e.lib.efe_get_device(e.ctx, C.byref(dev), buf, 64))
+        return dev.value, buf.value.decode()
+
     def arena_stats(self):
         """-> dict(capacity_bytes, high_water_bytes, grow_count)"""
         e = self._engine
@@ -515,9 +526,9 @@ class ActiveInferenceModel:
             else:                                               # a compacted call: the normals of the rows it holds
                 eps = self._src_eps_calcG(int(hr.max()) + 1, S, src_stage, row_offset)[:, hr]
         eps_t = e.tensor(eps, (3 * S, M, 10)) if eps is not None else None
-        rm, ri, rpe = (rows.mask, rows.ids, rows.rows_per_entry) if rows is not None else (None, None, 1)
+        rm, ri, rpe, rnt = (rows.mask, rows.ids, rows.rows_per_entry, rows.n_total) if rows is not None else (None, None, 1, 0)
         G, terms, ps1, ps1_mean, po1, parts = e.ops.calculate_g(e.h, s0, pi0, S, bool(_mean_mode), self._seed64(), nz.stage,
-                                                                nz.row_offset, eps_t, rm, ri, rpe)
+                                                                nz.row_offset, eps_t, rm, ri, rpe, rnt)
         if _parts is not None:
             _parts.append(parts)
         if _mean_mode:
@@ -587,7 +598,8 @@ class ActiveInferenceModel:
         nz = self._noise(stage, 0, 0, row_offset)
         ro = self.row_offset if row_offset is None else int(row_offset)
         src_stage = nz.stage
-        he = rows.host_rows(1) if rows is not None else None          # a compacted call: the episodes it holds
+        injected = (eps is None and self.eps_source is not None) or (u is None and self.u_source is not None)
+        he = rows.host_rows(1) if (rows is not None and injected) else None          # a compacted call with injected noise: the episodes it holds
         if eps is None and self.eps_source is not None:
             if he is None:
                 parts = [self._src_eps(E, 10, PASS_SIM, t, src_stage, ro).reshape(-1) for t in range(T)]
@@ -606,8 +618,8 @@ class ActiveInferenceModel:
         if eps_t is not None and eps_t.numel() != 4 * T * E * 10:
             raise ValueError(f'eps has {eps_t.numel()} elements, efe_simulate expects depth*E*10 + 3*E*depth*10 = {4 * T * E * 10}')
         u_t = e.tensor(u, (T, E)) if u is not None else None
-        rm, ri = (rows.mask, rows.ids) if rows is not None else (None, None)
-        return e.ops.simulate(e.h, s, T, bool(use_means), self._seed64(), nz.stage, nz.row_offset, eps_t, u_t, rm, ri)
+        rm, ri, rnt = (rows.mask, rows.ids, rows.n_total) if rows is not None else (None, None, 0)
+        return e.ops.simulate(e.h, s, T, bool(use_means), self._seed64(), nz.stage, nz.row_offset, eps_t, u_t, rm, ri, rnt)
 
     def mcts_step_simulate(self, starting_s, depth, use_means=False, *, stage=None, row_offset=None, eps=None, u=None):
         """torchmodel.py:354-393 -> (float G, pi0[depth,4], Qpi[4])"""

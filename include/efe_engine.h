@@ -46,6 +46,9 @@ int efe_create(efe_ctx** out, int device);                       /* ActiveInfere
  * torchutils.py:34-37.  Observations are NCHW [M, C, res, res].  Parity unpinned: validated against oracle/efe_oracle.py (cfg=) only. */
 int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channels, int resolution);
 int efe_get_config(efe_ctx* ctx, int* s_dim, int* pi_dim, int* channels, int* resolution);      /* outputs may be NULL */
+/* the HIP device the context was created on (efe_create's `device`) and the PCI bus id string of that device ("0000:c1:00.0"; buf may be
+ * NULL): what a multi-GPU launcher checks so that rank r really owns GPU r (bench.py gathers them and refuses two ranks on one device) */
+int efe_get_device(efe_ctx* ctx, int* device, char* pci_bus_id, int pci_bus_id_len);
 void efe_destroy(efe_ctx* ctx);
 const char* efe_last_error(efe_ctx* ctx);
 int efe_abi_version(void);                                       /* 5 (history of the versions: INTEGRATION.md section 4) */
@@ -71,7 +74,8 @@ int efe_commit_weights(efe_ctx* ctx);
  *                   layers 1 and 2, default 1, bit-identical to 0), "mid_unfused" (layer-by-layer transition MLP), "head_unfused" (the decoder / encoder dense heads as
  *                   one k_dense launch per layer instead of one k_head launch per head; same masks, fp32 summation order differs).  None of them removes work:
  *                   every setting computes the same quantities (fp32 summation order may differ where stated).
- *   development   : "poison" (pre-fill scratch with a byte), "trace" (synchronise and log every profiled launch), "arena_align" */
+ *   development   : "poison" (pre-fill scratch with a byte), "trace" (synchronise and log every profiled launch), "arena_align", "check_rows"
+ *                   (range-check efe_rows.ids against efe_rows.n_total on the host before every _rows call: one synchronisation per call) */
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value);
 
 /* scratch arena: efe_reserve makes the arena one block of >= bytes (synchronises once); efe_rollout_scratch_bytes is what
@@ -90,12 +94,17 @@ int efe_arena_stats(efe_ctx* ctx, int64_t* capacity_bytes, int64_t* high_water_b
  *   ids  : DEVICE array, entry slot -> entry ID: the call's entry i IS entry ids[i] of the un-compacted batch -- its noise keys are those of
  *          rows ids[i] * rows_per_entry + k (plus efe_noise.row_offset) and the mask is read at ids[i].  A planner that has lost episodes
  *          passes only the live ones (a dense, smaller call) and still draws exactly what the full batch would.  NULL = identity.
+ *   n_total : entries of the UN-COMPACTED batch = the length of `mask` and the exclusive upper bound of every id (ABI 5).  0 = not stated.
+ *          When stated, a call with more entries than n_total (no ids) fails, and with the development option "check_rows" = 1 the
+ *          ids are copied back and range-checked before the launch (one synchronisation: a stale or corrupt id would otherwise be a
+ *          silent out-of-bounds read of `mask` and a wrong noise key).
  * A NULL efe_rows* means "all rows, identity" -- except that a mask installed with the DEPRECATED efe_set_row_mask (context state: every
  * efe_calculate_g / efe_simulate on the context sees it until cleared; kept as a shim for ABI 3 callers) then applies. */
 typedef struct efe_rows {
     const uint8_t* mask;
     const int32_t* ids;
     int32_t rows_per_entry;
+    int32_t n_total;
 } efe_rows;
 int efe_set_row_mask(efe_ctx* ctx, const uint8_t* mask, int rows_per_entry);      /* deprecated: pass efe_rows to the _rows entry points */
 

@@ -150,7 +150,7 @@ int main(int argc, char** argv) {
         for (int g = 0; g < M / 4; ++g) hmask[g] = g != 0;
         HIP(hipMalloc((void**)&dmask, M / 4));
         HIP(hipMemcpy(dmask, hmask, M / 4, hipMemcpyHostToDevice));
-        efe_rows rows = {dmask, NULL, 4};           /* the mask is an ARGUMENT of the call (ABI 4) ... */
+        efe_rows rows = {dmask, NULL, 4, M / 4};    /* the mask is an ARGUMENT of the call (ABI 4); n_total = its length (ABI 5) ... */
         CHECK(efe_calculate_g_rows(ctx, ds, dpi, M, S, 0, &nz, NULL, &rows, dG, dT, dps1, dmean, dpo1, NULL, NULL));
         float hGm[M];
         HIP(hipMemcpy(hGm, dG, M * 4, hipMemcpyDeviceToHost));
@@ -164,10 +164,19 @@ int main(int argc, char** argv) {
             for (int g = 1; g < M / 4; ++g) hids[g - 1] = g;
             HIP(hipMalloc((void**)&dids, sizeof(hids)));
             HIP(hipMemcpy(dids, hids, sizeof(hids), hipMemcpyHostToDevice));
-            efe_rows crows = {NULL, dids, 4};
+            efe_rows crows = {NULL, dids, 4, M / 4};
             CHECK(efe_calculate_g_rows(ctx, ds + 4 * 10, dpi + 4 * 4, M - 4, S, 0, &nz, NULL, &crows, dG, dT, dps1, dmean, dpo1, NULL, NULL));
             HIP(hipMemcpy(hGm, dG, (M - 4) * 4, hipMemcpyDeviceToHost));
             for (int i = 0; i < M - 4; ++i) if (hGm[i] != hG[0][i + 4]) { fprintf(stderr, "compacted rows differ from the full batch\n"); return 1; }
+            /* n_total is the bound of the ids: with the development option check_rows a stale id is an ERROR, not an out-of-bounds read */
+            efe_rows brows = {NULL, dids, 4, 1};          /* ids hold entry 1 (= M/4 - 1 for M = 8): outside [0, 1) */
+            CHECK(efe_set_option(ctx, "check_rows", 1));
+            if (efe_calculate_g_rows(ctx, ds + 4 * 10, dpi + 4 * 4, M - 4, S, 0, &nz, NULL, &brows, dG, dT, dps1, dmean, dpo1, NULL, NULL) == 0 ||
+                !strstr(efe_last_error(ctx), "outside [0, n_total")) { fprintf(stderr, "check_rows accepted an id >= n_total (%s)\n", efe_last_error(ctx)); return 1; }
+            CHECK(efe_calculate_g_rows(ctx, ds + 4 * 10, dpi + 4 * 4, M - 4, S, 0, &nz, NULL, &crows, dG, dT, dps1, dmean, dpo1, NULL, NULL));
+            CHECK(efe_set_option(ctx, "check_rows", 0));
+            efe_rows trows = {dmask, NULL, 4, 1};         /* more entries in the call than the batch is said to have */
+            if (efe_calculate_g_rows(ctx, ds, dpi, M, S, 0, &nz, NULL, &trows, dG, dT, dps1, dmean, dpo1, NULL, NULL) == 0) { fprintf(stderr, "n_total < entries accepted\n"); return 1; }
             HIP(hipFree(dids));
         }
         /* the deprecated context-state form still works */

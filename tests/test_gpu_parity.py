@@ -271,6 +271,28 @@ def test_lockstep_batch_with_early_stops_contains_the_reference_episodes(golden,
     assert all(o_[4] == o2[4] for o_, o2 in zip(out, out2)) and torch.equal(visits, visits2)
 
 
+def test_unfused_transition_option_covers_every_path(models):
+    """A/B option mid_unfused (layer-by-layer transition MLP through k_dense instead of k_trans_fused): calculate_G AND the trajectory core
+    behind mcts_step_simulate (whose loop-2 transition otherwise comes from k_sim_chain) follow it -- same masks and normals, fp32
+    summation order of the 512-wide layers differs"""
+    m = models(1234, 1.15, 29)
+    s0 = PX.uniform_fill(6, (8, 10), 310, -1, 1)
+    starts = PX.uniform_fill(6, (5, 10), 311, -1, 1)
+    ref_G = c(m.calculate_G(s0, torch.eye(4).repeat(2, 1), samples=2, stage=3)[0])
+    ref_sim = [c(t) for t in m.simulate_batch(starts, 4, False, stage=9)]
+    try:
+        m.set_option('mid_unfused', 1)
+        G = c(m.calculate_G(s0, torch.eye(4).repeat(2, 1), samples=2, stage=3)[0])
+        sim = [c(t) for t in m.simulate_batch(starts, 4, False, stage=9)]
+    finally:
+        m.set_option('mid_unfused', 0)
+    np.testing.assert_allclose(G, ref_G, atol=gtol(np.array([2800.0])))
+    np.testing.assert_allclose(sim[0], ref_sim[0], atol=gtol(np.array([2800.0])))
+    assert np.array_equal(sim[1], ref_sim[1])                 # the sampled actions (k_sim_chain's own rollout is the same launch either way)
+    np.testing.assert_allclose(sim[2], ref_sim[2], rtol=1e-6)
+    assert not np.array_equal(sim[0], ref_sim[0]) or not np.array_equal(G, ref_G)      # the option really switched the kernels
+
+
 def test_planner_replica_follows_engine_options(models):
     """engine options are per context: the replica the lock-step planner simulates on must compute with the options of the model it
     mirrors (reward_upstream_intent changes term0 / G) -- a planner with the simulations on the second stream equals the same planner

@@ -129,12 +129,25 @@ def test_bench_rccl_path_at_one_rank():
     assert d['value'] > 1000 and d['config']['rows_per_gpu'] == 128
 
 
-def test_bench_launcher_at_four_ranks_on_one_device():
-    """`python bench.py --gpus 4 --share-device`: the self-launcher (torch.distributed.run on 127.0.0.1), episode sharding with global row
-    offsets, region-count agreement across ranks, rank 0's single JSON line with the per-rank figures and the CPU leg -- every rank on
-    cuda:0 over gloo (a rehearsal of the 8-GPU line, which needs a multi-GPU node; the 8-rank form runs in tools/rehearse_8gpu.sh)"""
-    d = _bench_line(['--gpus', '4', '--share-device', '--no-extras', '--no-prof', '--steps', '2', '--warmup', '1', '--min-seconds', '0.5'], 900)
-    assert d['n_gpus'] == 4 and d['rccl_ranks'] == 4 and d['backend'] == 'gloo' and d.get('share_device') is True
-    assert len(d['per_rank_ms_per_step']) == 4 and d['all_gather_ms'] > 0 and d['scaling'] == 'weak'
+@pytest.mark.parametrize('n', [4, 8])
+def test_bench_launcher_at_n_ranks_on_one_device(n):
+    """`python bench.py --gpus N --share-device` at 4 and at the 8 ranks of the driver's scaling run: the self-launcher
+    (torch.distributed.run on 127.0.0.1), episode sharding with global row offsets, region-count agreement across ranks, rank 0's single
+    JSON line with the per-rank figures, the per-rank (device, PCI bus id) list and the CPU leg -- every rank on cuda:0 over gloo (a
+    rehearsal of the 8-GPU line, which needs a multi-GPU node).  Without --share-device the same command REFUSES to put two ranks on one
+    GPU (bench.py Ranks.check_devices: efe_get_device of every rank's engine context, gathered)."""
+    d = _bench_line(['--gpus', str(n), '--share-device', '--no-extras', '--no-prof', '--steps', '2', '--warmup', '1', '--min-seconds', '0.5'], 1200)
+    assert d['n_gpus'] == n and d['rccl_ranks'] == n and d['backend'] == 'gloo' and d.get('share_device') is True
+    assert len(d['per_rank_ms_per_step']) == n and d['all_gather_ms'] > 0 and d['scaling'] == 'weak'
+    assert len(d['devices']) == n and all(dev[0] == 0 and dev[1] == d['devices'][0][1] and len(dev[1]) >= 7 for dev in d['devices'])
     assert d['cpu_baseline']['value'] > 0
     assert d['config']['rows_per_gpu'] == 128 and d['value'] > 1000
+
+
+def test_engine_context_reports_its_device():
+    """efe_get_device: the context's HIP device index and PCI bus id -- what bench.py's rank -> GPU check reads"""
+    import daimc_amd
+    import torch
+    m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=1)
+    idx, bus = m.engine_device()
+    assert idx == 0 and bus.count(':') == 2 and '.' in bus
