@@ -746,7 +746,7 @@ def main():
             breakdown[c] = (ms / nb, n // nb, ms, n)
         model.prof_enable(False)
 
-    devs = rk.check_devices(model, local, a.share_device)           # every rank (a collective at N > 1)
+    devs = rk.check_devices(model, device.index, a.share_device)           # every rank (a collective at N > 1)
     out = None
     if rank == 0:
         value = world * R * a.steps / dt
