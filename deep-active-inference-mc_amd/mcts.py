@@ -156,8 +156,12 @@ def _frames_nchw(model, frames, n, o_shape):
 def active_inference_mcts(model, frame, params, o_shape=(64, 64, 1)):
     """One planning decision (mcts.py:150-195) -> (path, repeats_done, states_explored, all_paths, all_paths_G).
     The decision runs on the device-resident planner (BatchedMCTS with one episode: tree statistics, selection, back-propagation and
-    the early stop are kernels, the simulation runs beside the expansion on a second stream) -- the same draws and the same results as
-    the host-side Node tree below, which `params.host_tree = True` selects (it is what Node.expand / select / backpropagate users get)."""
+    the early stop are kernels, the simulation runs beside the expansion on a second stream) -- per decision the same draws and the same results as
+    the host-side Node tree below, which `params.host_tree = True` selects (it is what Node.expand / select / backpropagate users get).  The
+    device planner reserves the noise stages of a whole decision up front, the host tree takes them as it goes: after a decision that ended
+    early (habit shortcut, early stop) the NEXT decision on the same model draws from different stages in the two modes.  With the default
+    parameters the planner also creates (once per weight version, cached on the model) a replica engine context for the second stream:
+    INTEGRATION.md section 4; `overlap_simulate = False` avoids it."""
     if not getattr(params, 'host_tree', False) and not (frame is None or (isinstance(frame, (list, tuple)) and len(frame) == 0)):
         out, _ = active_inference_mcts_batch(model, torch.as_tensor(frame)[None], params, o_shape=o_shape)
         return out[0]
