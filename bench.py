@@ -820,6 +820,35 @@ def main():
                      'what': 'the headline steps alternated over two engine contexts on two HIP streams (same kernels, same results; '
                              'the transition stages of one step overlap the decoder of the other)'}
         del m2
+    b3 = None
+    if not a.no_extras and solo:
+        # OPT-IN EXPERIMENT, never the headline (narrower inputs than the reference's fp32 arithmetic): the same steps with the decoder's
+        # Linear(256, 16384) on the bf16 matrix pipe, both operands split into three bf16 planes (engine option mfma_bf16x3, csrc/bf16x3.hip:
+        # 6 products, fp32 accumulation; every fixture passes at the unchanged tolerances with it, profiles/r5_observed_errors.txt)
+        PEAK_BF16_TF = 2516.6                                      # dense bf16 MFMA, MI355X_MICROARCH.md; 6 products per fp32-equivalent MAC
+        model.set_option('mfma_bf16x3', 1)
+        try:
+            for k in range(4):
+                step(kk); kk += 1
+            regs3, _, kk = timed_regions(step, a.steps, kk, rk, min_total_s=2.0, max_regions=12)
+            dt3 = statistics.median(regs3)
+            model.prof_enable(True, classes=['dec_dense_16384'])
+            for _ in range(5):
+                step(kk); kk += 1
+            ms3, n3 = model.prof_read()['dec_dense_16384']
+            model.prof_enable(False)
+            fl = 2.0 * 256 * 16384 * (3 * S * D * R)                # fp32-equivalent flops of one launch (19 200 rows at the default size)
+            b3 = {'value': R * a.steps / dt3, 'unit': 'rollouts/s', 'ms_per_step': 1e3 * dt3 / a.steps, 'timed_regions': len(regs3),
+                  'dtype': 'bf16 x 3 planes per operand, 6 products, fp32 accumulate (Linear(256, 16384) only; every other kernel f32)',
+                  'what': 'EXPERIMENT, not the headline: engine option mfma_bf16x3 = 1 on the headline workload',
+                  'kernel': {'name': 'k_fc4_b3', 'avg_launch_ms': ms3 / max(n3, 1), 'fp32_kernel_ms': ((locals().get('kern') or {}).get('dec_dense_16384') or {}).get('ms'),
+                             'fp32_equivalent_tflops': fl / (ms3 / max(n3, 1) * 1e-3) / 1e12 if n3 else None},
+                  'roofline': {'bound': 'mfma', 'peak': PEAK_BF16_TF / 6.0, 'unit': 'TFLOP/s (fp32-equivalent: bf16 dense peak / 6 products)',
+                               'achieved': fl / (ms3 / max(n3, 1) * 1e-3) / 1e12 if n3 else None,
+                               'frac': fl / (ms3 / max(n3, 1) * 1e-3) / 1e12 / (PEAK_BF16_TF / 6.0) if n3 else None},
+                  'speedup_vs_headline': (R * a.steps / dt3) / value if rank == 0 else None}
+        finally:
+            model.set_option('mfma_bf16x3', 0)
     if not a.no_extras:
         # every rank runs the extras (they are collective at N > 1); rank 0 attaches them
         key = 'mcts_cfg3' if world == 1 else 'mcts_cfg4_sharded'
@@ -839,6 +868,8 @@ def main():
             out['extras'] = {key: mc, key + '_threshold_0.5': mc05, 'animalai_cfg5': ai}
             if pipelined:
                 out['extras']['rollout_two_streams'] = pipelined
+            if b3:
+                out['extras']['rollout_bf16x3'] = b3
             if single:
                 out['extras']['single_episode'] = single
     emit(out)

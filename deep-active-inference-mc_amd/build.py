@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['csrc/kernels.hip', 'csrc/decoder.hip', 'csrc/encoder.hip', 'csrc/mcts.hip', 'csrc/fused.hip', 'csrc/generic.hip', 'csrc/generic_dec.hip', 'csrc/generic_enc.hip', 'csrc/engine.hip']
+SOURCES = ['csrc/kernels.hip', 'csrc/decoder.hip', 'csrc/encoder.hip', 'csrc/mcts.hip', 'csrc/fused.hip', 'csrc/generic.hip', 'csrc/generic_dec.hip', 'csrc/generic_enc.hip', 'csrc/bf16x3.hip', 'csrc/engine.hip']
 HEADERS = ['csrc/kernels.h', 'csrc/philox.h', 'csrc/mfma_pipe.h', '../include/efe_engine.h']
 LIB = os.path.join(HERE, 'libefe_mi355x.so')
 OPS_SOURCES = ['csrc/torch_ops.cpp']

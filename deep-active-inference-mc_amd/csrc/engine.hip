@@ -89,6 +89,8 @@ struct efe_ctx {
     int64_t enc_tiled = 1;         // generic path: LDS-tiled encoder layers 1 and 2 (k_conv_e); 0 = k_conv_g for every layer (A/B, parity of the fallback)
     int64_t dec_split = 1;         // dSprites path: decoder launches of <= 128 images run k_dec_b4 with four workgroups per image (0 = never: A/B)
     int64_t fuse_final_g = 1;      // generic path: last two decoder layers in one kernel (k_dec_bg); 0 = separate launches (A/B, parity tests of k_final_g)
+    int64_t mfma_bf16x3 = 0;       // OPT-IN EXPERIMENT (bf16x3.hip): Linear(256, 16384) of the decoder on the bf16 pipe, operands split in three bf16 planes
+    uint16_t* fc4_b3 = nullptr;    // its packed planes (part of wbufs)
     int64_t check_rows = 0;        // development: range-check efe_rows.ids on the host before every _rows call
     int64_t last_macs = 0;
     const uint8_t* row_mask = nullptr; int row_mask_div = 1;      // efe_set_row_mask
@@ -229,7 +231,8 @@ void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float*
     a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = m0;
     hipEvent_t e0 = ctx->prof_begin(st);
     if (L.mtiles >= 64 && !(L.mtiles & 1) && L.cin == 256 && ldx == 256 && x_mod == 0 && relu && drop) {
-        launch_fc4(a, st);          // Linear(256, 64 * base^2): batch tile staged in LDS
+        if (ctx->mfma_bf16x3 && ctx->fc4_b3 && &L == &ctx->dec_fc[3]) { a.Wb3 = ctx->fc4_b3; launch_fc4_b3(a, st); }     // opt-in experiment
+        else launch_fc4(a, st);     // Linear(256, 64 * base^2): batch tile staged in LDS
     } else {
         // tile shape by problem size: small launches (transition / habit / heads) use 32x32 wave tiles so that the
         // grid still covers the 256 CUs
@@ -671,7 +674,7 @@ int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channel
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return 2;
     if (hipSetDevice(device) != hipSuccess) return 3;
-    if (init_small_kernels() || init_decoder_kernels() || init_fused_kernels() || init_generic_kernels()) return 5;       // per device: a second context on another GPU needs them too
+    if (init_small_kernels() || init_decoder_kernels() || init_fused_kernels() || init_generic_kernels() || init_bf16x3_kernels()) return 5;       // per device: a second context on another GPU needs them too
     efe_ctx* ctx = new efe_ctx();
     ctx->device = device;
     ctx->pi_dim = pi_dim; ctx->chan = channels; ctx->res = resolution;
@@ -747,6 +750,8 @@ int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const 
     return 0;
 }
 
+static int pack_fc4_b3(efe_ctx* ctx);
+
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return 1;
     EFE_LOCK(ctx);
@@ -760,11 +765,30 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "poison")) { ctx->poison = value; return 0; }
     if (!strcmp(name, "trace")) { ctx->trace = value; return 0; }
     if (!strcmp(name, "check_rows")) { ctx->check_rows = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "mfma_bf16x3")) {       // opt-in experiment; the planes are packed now if the weights are already committed
+        if (value && ctx->generic) return ctx->fail("mfma_bf16x3: the experiment covers the Dynamic-dSprites geometry only");
+        ctx->mfma_bf16x3 = value ? 1 : 0;
+        if (value && ctx->committed && !ctx->fc4_b3) { HIPCHK(hipSetDevice(ctx->device)); if (pack_fc4_b3(ctx)) return 1; }
+        return 0;
+    }
     if (!strcmp(name, "arena_align")) { if (value < 256 || (value & (value - 1))) return ctx->fail("arena_align must be a power of two >= 256"); ctx->arena_align = value; return 0; }
     if (!strcmp(name, "mid_unfused")) { ctx->mid_unfused = value; return 0; }
     if (!strcmp(name, "head_unfused")) { ctx->head_unfused = value; return 0; }
     if (!strcmp(name, "enc_chunk")) { if (value < 1) return ctx->fail("enc_chunk < 1"); ctx->enc_chunk = value; return 0; }
     return ctx->fail(std::string("unknown option ") + name);
+}
+
+// option mfma_bf16x3: down.po_net.9 (rows in NHWC order) as three bf16 planes for k_fc4_b3
+static int pack_fc4_b3(efe_ctx* ctx) {
+    const HostTensor* w = need(ctx, "down.po_net.9.weight", {16384, 256});
+    if (!w) return 1;
+    std::vector<int> rowp(16384);
+    for (int p = 0; p < 256; ++p) for (int c = 0; c < 64; ++c) rowp[p * 64 + c] = c * 256 + p;
+    std::vector<uint16_t> planes((size_t)16384 * 256 * 3);
+    pack_bf16x3(w->data.data(), rowp.data(), 16384, 256, planes.data());
+    HIPCHK(hipMalloc((void**)&ctx->fc4_b3, planes.size() * 2)); ctx->wbufs.push_back(ctx->fc4_b3);
+    HIPCHK(hipMemcpy(ctx->fc4_b3, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+    return 0;
 }
 
 int efe_commit_weights(efe_ctx* ctx) {
@@ -776,6 +800,7 @@ int efe_commit_weights(efe_ctx* ctx) {
         HIPCHK(hipDeviceSynchronize());
         for (void* p : ctx->wbufs) (void)hipFree(p);
         ctx->wbufs.clear();
+        ctx->fc4_b3 = nullptr;
     }
     ctx->committed = false;
     const int A = ctx->pi_dim;
@@ -912,6 +937,7 @@ int efe_commit_weights(efe_ctx* ctx) {
         std::vector<int> rowp(16384);
         for (int p = 0; p < 256; ++p) for (int c = 0; c < 64; ++c) rowp[p * 64 + c] = c * 256 + p;
         if (pack_linear(ctx, ctx->dec_fc[3], "down.po_net.9", 16384, 256, rowp.data(), nullptr)) return 1;
+        if (ctx->mfma_bf16x3 && pack_fc4_b3(ctx)) return 1;
     }
     for (int i = 0; i < 3; ++i) {   // ConvTranspose2d weights are [Cin][Cout][kh][kw]
         const HostTensor* w = need(ctx, std::string(tk[i]) + ".weight", {tci[i], tco[i], 3, 3});

@@ -97,6 +97,7 @@ struct GemmArgs {
     int rows_per_group;
     uint32_t row_offset;  // global index of row 0 of a group on this rank
     int m0;               // index of column 0 of this launch inside the [group][row] batch
+    const void* Wb3 = nullptr;   // option mfma_bf16x3 (bf16x3.hip): the same weights as three bf16 planes [mtile][16][3][64 lanes][8]
 };
 
 // fused decoder, stage A: x4 [rows][16][16][64] -> ConvT(64,64,s1)+ReLU -> ConvT(64,64,s2)+ReLU -> y2 [rows][4 parities][8 channel groups][16x16 positions][8] (see k_dec_a)
@@ -139,6 +140,9 @@ struct EncArgs {
 };
 void launch_enc_trunk(const EncArgs& a, hipStream_t st);
 void launch_fc4(const GemmArgs& a, hipStream_t st);      // Linear(256,16384)+ReLU+Dropout with the batch tile staged in LDS
+void launch_fc4_b3(const GemmArgs& a, hipStream_t st);   // the same on the bf16 pipe, operands split in three (opt-in experiment, bf16x3.hip)
+void pack_bf16x3(const float* W, const int* row_perm, int out, int in, uint16_t* dst);
+int init_bf16x3_kernels();
 void launch_dec_a(const DecAArgs& a, hipStream_t st);
 void launch_dec_b(const DecBArgs& a, hipStream_t st);
 

@@ -1264,3 +1264,68 @@ def test_contexts_release_their_device_memory(weights_cache):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, f'{(free0 - free1) >> 20} MiB of device memory not returned after 6 create/destroy cycles'
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# OPT-IN EXPERIMENT (engine option mfma_bf16x3, csrc/bf16x3.hip): Linear(256, 16384) of the decoder on the bf16 matrix pipe with both
+# operands split into three bf16 planes (6 products, fp32 accumulation).  Narrower inputs than the reference's fp32 -- never the default,
+# never the headline -- so every decoder-bearing fixture is run through it at the UNCHANGED tolerances
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def models_b3(models):
+    used = []
+
+    def get(wseed, gain, seed):
+        m = models(wseed, gain, seed)
+        m.set_option('mfma_bf16x3', 1)
+        used.append(m)
+        return m
+    yield get
+    for m in used:
+        m.set_option('mfma_bf16x3', 0)
+
+
+def test_bf16x3_every_decoder_fixture_at_unchanged_tolerances(golden, models_b3):
+    """the reference-captured fixtures that go through the decoder, with the experiment on: same assertions, same tolerances"""
+    for gain in GAINS:
+        test_networks_vs_golden(golden, models_b3, gain)
+        for case in ('m4s1', 'm6s3'):
+            test_calculate_G_vs_golden(golden, models_b3, gain, case)
+        test_calculate_G_mean_vs_golden(golden, models_b3, gain)
+    for name in ('rollout_cfg1', 'rollout_m8d2s2', 'rollout_m8d2s2mean'):
+        test_rollout_vs_golden(golden, models_b3, name)
+    for name in ('rollout4_s2', 'rollout4_mean'):
+        test_rollout4_vs_golden(golden, models_b3, name)
+    for name in ('simulate_sample', 'simulate_means'):
+        test_simulate_vs_golden(golden, models_b3, name)
+    for name in ('mcts_deep_s10_thr',):
+        test_planners_at_benchmark_depth_vs_reference(golden, models_b3, name)
+
+
+def test_bf16x3_vs_fp32_path_and_oracle_on_many_rows(models, weights_cache):
+    """1100 decoder rows (several 64-row tiles + a ragged tail, every feature group): the experiment against the fp32 kernel (same masks,
+    images within the sigmoid tolerance) and against the oracle; and it really is another kernel (not bit-identical)"""
+    seed, M, st = 31, 1100, 5
+    m = models(1234, 1.15, seed)
+    s = PX.uniform_fill(12, (M, 10), 400, -1.5, 1.5)
+    ref = c(m.model_down.decoder(s, stage=st, pass_=PX.PASS_D2A))
+    try:
+        m.set_option('mfma_bf16x3', 1)
+        got = c(m.model_down.decoder(s, stage=st, pass_=PX.PASS_D2A))
+    finally:
+        m.set_option('mfma_bf16x3', 0)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=4e-6)
+    assert not np.array_equal(got, ref)
+    orc = EO.OracleModel(weights_cache(1234, 1.15), EO.PhiloxNoise(seed))
+    with torch.no_grad():
+        o = orc.decoder(torch.from_numpy(s[:200]), PX.PASS_D2A, 0, st).numpy()
+    np.testing.assert_allclose(got[:200], o, rtol=1e-5, atol=4e-6)
+
+
+def test_bf16x3_is_off_by_default_and_refused_on_other_geometries(models):
+    import daimc_amd
+    m = models(1234, 1.15, 3)
+    assert getattr(m, '_opts', {}).get('mfma_bf16x3', 0) == 0
+    g = daimc_amd.ActiveInferenceModel(10, 3, 0.0, 1.0, 1.0, colour_channels=3, resolution=32, device='cuda:0', seed=1)
+    with pytest.raises(RuntimeError):
+        g.set_option('mfma_bf16x3', 1)

@@ -1,4 +1,6 @@
-"""dev tool: observed |engine - fixture| per quantity over the committed goldens (basis of the tolerances in tests/test_gpu_parity.py)"""
+"""dev tool: observed |engine - fixture| per quantity over the committed goldens (basis of the tolerances in tests/test_gpu_parity.py)
+
+  python tools/measure_errors.py [bf16x3]      bf16x3: with the opt-in experiment mfma_bf16x3 on (csrc/bf16x3.hip)"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,6 +9,13 @@ import daimc_amd
 from conftest import load_golden, eps_calcG, eps_rollout
 from oracle import synth, philox as PX
 worst = {}
+B3 = len(sys.argv) > 1 and sys.argv[1] == 'bf16x3'
+_orig_load = daimc_amd.ActiveInferenceModel.load_flat_weights
+def _load(self, w):
+    _orig_load(self, w)
+    if B3:
+        self.set_option('mfma_bf16x3', 1)
+daimc_amd.ActiveInferenceModel.load_flat_weights = _load
 def upd(k, a, b):
     d = float(np.max(np.abs(a.detach().cpu().numpy() - b)))
     worst[k] = max(worst.get(k, 0.0), d)
@@ -36,5 +45,6 @@ for name in ('rollout_cfg1', 'rollout_m8d2s2', 'rollout_m8d2s2mean'):
     D, S, st, M = int(g['steps']), int(g['samples']), int(g['stage']), len(g['o'])
     sG, T, po1 = m.calculate_G_repeated(g['o'], g['pi'], steps=D, calc_mean=bool(g['calc_mean']), samples=S, stage=st, eps=eps_rollout(int(g['nseed']), M, D, S, st))
     upd('rollout sum_G', sG, g['sum_G']); upd('rollout t0', T[0], g['t0']); upd('rollout t1', T[1], g['t1'])
+print('engine option mfma_bf16x3 =', int(B3))
 for k, v in worst.items():
     print(f'{k:16s} max |engine - reference fixture| = {v:.3e}')
