@@ -113,23 +113,21 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
         // fragment of (tile mt, step ks, plane p): float4 index ((mt * 16 + ks) * 3 + p) * 64 + lane
         auto afrag = [&](int mt, int ks, int p) -> float4 { return wfrag(wr, ln, (size_t)(((mt0 + mt) * 16 + ks) * 3 + p) * 64); };
         auto bfrag = [&](int nt, int ks, int p) -> float4 { return *reinterpret_cast<const float4*>(brow[nt] + p * 512 + ks * 32); };
-        float4 an[2][3], bn[2][3];
+        // fragments of step ks live in buffer set ks & 1; the loop is fully unrolled so that every index is static (hipcc copies a
+        // software-pipeline buffer it cannot rename: 48 v_mov per step and an s_waitcnt vmcnt(0) on the loads that were meant to stay in flight)
+        float4 af[2][2][3], bf[2][2][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) { an[t][p] = afrag(t, 0, p); bn[t][p] = bfrag(t, 0, p); }
-#pragma unroll 4
+            for (int p = 0; p < 3; ++p) { af[0][t][p] = afrag(t, 0, p); bf[0][t][p] = bfrag(t, 0, p); }
+#pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            float4 ac[2][3], bc[2][3];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) { ac[t][p] = an[t][p]; bc[t][p] = bn[t][p]; }
+            const int cb = ks & 1, nb = cb ^ 1;
             if (ks < 15) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) { an[t][p] = afrag(t, ks + 1, p); bn[t][p] = bfrag(t, ks + 1, p); }
+                    for (int p = 0; p < 3; ++p) { af[nb][t][p] = afrag(t, ks + 1, p); bf[nb][t][p] = bfrag(t, ks + 1, p); }
             }
             __builtin_amdgcn_sched_barrier(0);
             // the six products, smallest first: (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi); planes 0 = hi, 1 = mid, 2 = lo
@@ -140,8 +138,9 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[mt][PA[pr]]), __builtin_bit_cast(bf16x8, bc[nt][PB[pr]]),
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[cb][mt][PA[pr]]), __builtin_bit_cast(bf16x8, bf[cb][nt][PB[pr]]),
                                                                               acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue: the same as k_fc4 (bias, ReLU, dropout mask from Philox, NHWC store)
 #pragma unroll
