@@ -22,6 +22,16 @@ namespace efe {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// LDS-DMA of 1 KiB per wave: lane l copies 16 bytes from its own global address to LDS byte address lds_dst + 16 l (lds_dst wave-uniform).
+// As inline asm, not __builtin_amdgcn_global_load_lds: hipcc orders every later ds_read behind the builtin with s_waitcnt vmcnt(0) (it
+// cannot see that the copy targets the OTHER weight buffer), which exposes the copy's whole latency; the asm form is invisible to its
+// counters, so the caller drains it itself (glds_drain) in front of the barrier that publishes the buffer.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 constexpr int B3_ROWB = 3 * 512 + 16;                 // bytes per staged row: three planes of 256 bf16 + padding
 constexpr size_t B3_LDS = (size_t)64 * B3_ROWB;       // 99 328 B: one workgroup per CU
 
@@ -38,6 +48,20 @@ __host__ __device__ inline void split3(float x, uint32_t& hi, uint32_t& mid, uin
     mid = bf16_rne(r1);
     const float r2 = r1 - __builtin_bit_cast(float, mid << 16);
     lo = bf16_rne(r2);
+}
+
+// the same split for a PAIR of values on the device: v_cvt_pk_bf16_f32 (round to nearest even in hardware, two values per instruction) ->
+// packed (hi, mid, lo) words, element 0 in the low half; 9 VALU instructions per pair against ~40 for two integer split3
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pk(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    f32x2 v; v.x = x0; v.y = x1;
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+    f32x2 hf; hf.x = __builtin_bit_cast(float, hi << 16); hf.y = __builtin_bit_cast(float, hi & 0xffff0000u);
+    const f32x2 r1 = v - hf;
+    mid = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2_t));
+    f32x2 mf; mf.x = __builtin_bit_cast(float, mid << 16); mf.y = __builtin_bit_cast(float, mid & 0xffff0000u);
+    const f32x2 r2 = r1 - mf;
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2_t));
 }
 
 __host__ __device__ inline int fc4b3_spg(int mtiles) { return ((mtiles + 15) / 16 + 7) / 8; }     // steps of 16 feature tiles, dealt to 8 groups
@@ -76,13 +100,12 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
                 const int r = idx >> 6, c4 = idx & 63;
                 const int gr = row0 + r;
                 const f32x4 v = (gr < a.n_pix) ? X[(size_t)gr * 64 + c4] : (f32x4)(0.f);
-                uint32_t hi[4], mid[4], lo[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split3(v[e], hi[e], mid[e], lo[e]);
+                uint32_t hi[2], mid[2], lo[2];
+                split3_pk(v[0], v[1], hi[0], mid[0], lo[0]); split3_pk(v[2], v[3], hi[1], mid[1], lo[1]);
                 unsigned char* d = smb + (size_t)r * B3_ROWB + c4 * 8;
-                *reinterpret_cast<uint2*>(d) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-                *reinterpret_cast<uint2*>(d + 512) = make_uint2(mid[0] | (mid[1] << 16), mid[2] | (mid[3] << 16));
-                *reinterpret_cast<uint2*>(d + 1024) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+                *reinterpret_cast<uint2*>(d) = make_uint2(hi[0], hi[1]);
+                *reinterpret_cast<uint2*>(d + 512) = make_uint2(mid[0], mid[1]);
+                *reinterpret_cast<uint2*>(d + 1024) = make_uint2(lo[0], lo[1]);
             }
             __syncthreads();
 #pragma unroll
@@ -165,7 +188,235 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// k_dec_a_b3: the two fused layers of k_dec_a (decoder.hip: ConvTranspose2d(64, 64, s1) + ReLU -> ConvTranspose2d(64, 64, s2) + ReLU,
+// /root/reference/src/torchmodel.py:120-123) on the bf16 pipe, same option.  EVERY operand comes from LDS -- the ablation of k_fc4_b3
+// (profiles/r5_fc4_b3_ablation.txt) shows the three-plane form bound by the return path of its global fragment loads (~30 B/clk and CU):
+//   * the image as three bf16 planes, [257 pixels][3 planes][64 channels] + 16 B of padding per pixel (400 B: 16 consecutive pixels of
+//     a ds_read_b128 cover the 64 banks); layer 1's output is split and written back IN PLACE as layer 2's input, as in k_dec_a;
+//   * the weights of ONE tap (all 64 x 64, three planes, fragment-major = lane-linear: 24 KiB) in a double buffer, staged by the whole
+//     workgroup one tap ahead -- every wave reads the same fragments, so they cross the L1 once per workgroup instead of once per wave.
+// One workgroup of 4 waves per CU (150 KB of LDS), persistent over images (static stride, the next image prefetched into registers
+// during the contraction; one wave per SIMD has 512 registers).  A wave owns 64 channels x 64 pixels (2 x 2 tiles) like k_dec_a's:
+// per 16-channel step 12 ds_read_b128 feed 24 MFMAs (LDS at half its bandwidth).  y2 leaves in k_dec_a's fp32 layout: k_dec_b4 is unchanged.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DA3_PXB = 3 * 128 + 16;                   // bytes per staged pixel
+constexpr int DA3_IMG = 257 * DA3_PXB;                  // image + zero pixel
+constexpr int DA3_SLAB = 2 * 4 * 3 * 1024;              // one tap's weights: [2 mt][4 ks][3 planes][64 lanes][16 B]
+constexpr int DA3_W0 = (DA3_IMG + 255) & ~255;          // byte offset of weight buffer 0
+constexpr int DA3_BIAS = DA3_W0 + 2 * DA3_SLAB;         // two bias vectors (fp32)
+constexpr size_t DA3_LDS = DA3_BIAS + 2 * 64 * sizeof(float);
+
+__global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm3[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, g = lane >> 5;
+    if ((int)blockIdx.x >= a.rows) return;
+    const float4* bias4 = reinterpret_cast<const float4*>(sm3 + DA3_BIAS);
+    if (tid < 16) reinterpret_cast<float4*>(sm3 + DA3_BIAS)[tid] = reinterpret_cast<const float4*>(a.b1)[tid];
+    else if (tid < 32) reinterpret_cast<float4*>(sm3 + DA3_BIAS)[tid] = reinterpret_cast<const float4*>(a.b2)[tid - 16];
+    for (int i = tid; i < DA3_PXB / 4; i += 256) reinterpret_cast<uint32_t*>(sm3 + 256 * DA3_PXB)[i] = 0u;      // the zero pixel
+    // weight slab of tap index T (0 .. 17: layer 1 taps 0 .. 8, then layer 2's taps in the order the parities use them) -> buffer T & 1;
+    // 24 KiB = 6 float4 per thread, lane-linear
+    const float4* W1 = reinterpret_cast<const float4*>(a.w1b3);
+    const float4* W2 = reinterpret_cast<const float4*>(a.w2b3);
+    // packed tap index kh * 3 + kw of tap t of output parity par of the stride-2 layer (the order of ConvT2Addr, mfma_pipe.h)
+    auto l2_wt = [](int par, int t) -> int {
+        const int ph = par >> 1, pw = par & 1;
+        const int th = t / (1 + pw), tw = t - th * (1 + pw);
+        return (ph ? (th ? 2 : 0) : 1) * 3 + (pw ? (tw ? 2 : 0) : 1);
+    };
+    // a tap's 24 KiB of packed weights go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, destination = a
+    // wave-uniform base + lane * 16 -- exactly the fragment-major layout; no staging registers, no ds_write): wave w copies pieces 6 w .. 6 w + 5
+    const unsigned lds_w0 = (unsigned)(size_t)(sm3 + DA3_W0) + (unsigned)(6 * w) * 1024u;       // this wave's pieces inside weight buffer 0
+    auto slab_dma = [&](const float4* src, int buf) {
+        const char* sp = reinterpret_cast<const char*>(src) + (size_t)(6 * w) * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) glds16(sp + i * 1024, lds_w0 + (unsigned)(buf * DA3_SLAB + i * 1024));
+    };
+    // fp32 quad (4 consecutive channels c .. c + 3 of one pixel) -> the three planes of that pixel
+    auto put_planes = [&](unsigned char* px, int c, const float v0, const float v1, const float v2, const float v3) {
+        uint32_t hi[2], mid[2], lo[2];
+        split3_pk(v0, v1, hi[0], mid[0], lo[0]); split3_pk(v2, v3, hi[1], mid[1], lo[1]);
+        *reinterpret_cast<uint2*>(px + c * 2) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(px + 128 + c * 2) = make_uint2(mid[0], mid[1]);
+        *reinterpret_cast<uint2*>(px + 256 + c * 2) = make_uint2(lo[0], lo[1]);
+    };
+    f32x4 pf[16];                                        // the next image: 64 KiB / 256 threads
+    {
+        const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)blockIdx.x * 4096;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) pf[it] = X[it * 256 + tid];
+    }
+    // this wave's 64 pixels: image rows 4 w .. 4 w + 3 as two 32-pixel tiles (rows 4 w + 2 nt, + 1)
+    const int pcol = j & 15, prow0 = 4 * w + (j >> 4);
+    const unsigned char* abase = sm3 + DA3_W0 + lane * 16;
+
+    for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
+        const bool live = row_live(a.live, img);
+        const int nimg = img + (int)gridDim.x;
+        __syncthreads();                                  // every wave is done with the previous image's planes
+        if (live) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int idx = it * 256 + tid;           // pixel idx >> 4, channel quad idx & 15
+                put_planes(sm3 + (size_t)(idx >> 4) * DA3_PXB, 4 * (idx & 15), pf[it][0], pf[it][1], pf[it][2], pf[it][3]);
+            }
+        }
+        slab_dma(W1, 0);
+        f32x16 acc[2][2];
+        auto acc_init = [&](int boff) {                   // the accumulators start at the bias: register e of tile mt holds channel 32 mt + (e & 3) + 8 (e >> 2) + 4 g
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 bb = bias4[boff + mt * 8 + 2 * g4 + g];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) { acc[mt][nt][4 * g4] = bb.x; acc[mt][nt][4 * g4 + 1] = bb.y; acc[mt][nt][4 * g4 + 2] = bb.z; acc[mt][nt][4 * g4 + 3] = bb.w; }
+                }
+        };
+        // one tap: B views at pixel byte offsets pb[nt] (+ g * 16), weights in buffer T & 1 (staged during the previous tap); the next
+        // tap's slab is requested in front of the MFMAs and written behind them
+        // one tap: B views at pixel byte offsets pb[nt] (+ g * 16), weights in buffer T & 1 (copied during the previous tap); the next tap's
+        // slab is copied during this one.  With ONE wave per SIMD nothing else fills the matrix pipe while this wave issues loads, so every
+        // LDS read and every DMA piece sits between two MFMAs (a burst of 12 ds_read_b128 in front of a step's 24 MFMAs cost as much time
+        // as the MFMAs: profiles/r5_dec_a_b3_ablation.txt): step ks issues, after every second MFMA, one of the 12 fragment reads of step
+        // ks + 1, and steps 0 .. 2 two DMA pieces each.
+        auto tap = [&](int T, const int (&pb)[2], const float4* next) {
+            glds_drain();                                 // this wave's pieces of slab T have landed ...
+            __syncthreads();                              // ... and everybody's; nobody reads buffer (T + 1) & 1 any more
+            const unsigned char* ab = abase + (T & 1) * DA3_SLAB;
+            const char* dsp = reinterpret_cast<const char*>(next) + (size_t)(6 * w) * 1024 + lane * 16;
+            const unsigned ddp = lds_w0 + (unsigned)(((T + 1) & 1) * DA3_SLAB);
+            if (T == 14) {                                // the next image, requested over the last four taps (16 float4 per thread: held only from here)
+                const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)(nimg < a.rows ? nimg : img) * 4096;
+#pragma unroll
+                for (int it = 0; it < 16; ++it) pf[it] = X[it * 256 + tid];
+            }
+            float4 af[2][2][3], bf[2][2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    af[0][t][p] = *reinterpret_cast<const float4*>(ab + ((t * 4 + 0) * 3 + p) * 1024);
+                    bf[0][t][p] = *reinterpret_cast<const float4*>(sm3 + pb[t] + p * 128);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cb = ks & 1, nb = cb ^ 1;
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {            // MFMAs 2 q, 2 q + 1 of the step's 24, then one load of the next step
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int m = 2 * q + u, pr = m >> 2, mt = (m >> 1) & 1, nt = m & 1;
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[cb][mt][PA[pr]]), __builtin_bit_cast(bf16x8, bf[cb][nt][PB[pr]]),
+                                                                              acc[mt][nt], 0, 0, 0);
+                    }
+                    if (ks < 3) {
+                        const int t = (q % 6) / 3, pl = q % 3;
+                        if (q < 6) af[nb][t][pl] = *reinterpret_cast<const float4*>(ab + ((t * 4 + ks + 1) * 3 + pl) * 1024);
+                        else bf[nb][t][pl] = *reinterpret_cast<const float4*>(sm3 + pb[t] + pl * 128 + (ks + 1) * 32);
+                        if (next != nullptr && (q == 3 || q == 9)) {
+                            const int i = 2 * ks + (q == 9);
+                            glds16(dsp + i * 1024, ddp + (unsigned)(i * 1024));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        // ---------------- layer 1: out[oh, ow] = sum_{kh, kw} in[oh + 1 - kh, ow + 1 - kw] . W[:, :, kh, kw] -------------------------------
+        acc_init(0);
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t - kh * 3;
+            int pb[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int sy = prow0 + 2 * nt + 1 - kh, sx = pcol + 1 - kw;
+                const bool ok = sy >= 0 && sy < 16 && sx >= 0 && sx < 16;
+                pb[nt] = (ok ? sy * 16 + sx : 256) * DA3_PXB + g * 16;
+            }
+            tap(t, pb, t < 8 ? W1 + (size_t)(t + 1) * (DA3_SLAB / 16) : W2 + (size_t)l2_wt(0, 0) * (DA3_SLAB / 16));
+        }
+        __syncthreads();                                  // every wave is done reading the input planes
+        if (live) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                unsigned char* px = sm3 + (size_t)(64 * w + 32 * nt + j) * DA3_PXB;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        put_planes(px, mt * 32 + 8 * g4 + 4 * g, relu_bits(acc[mt][nt][4 * g4 + 0]), relu_bits(acc[mt][nt][4 * g4 + 1]),
+                                   relu_bits(acc[mt][nt][4 * g4 + 2]), relu_bits(acc[mt][nt][4 * g4 + 3]));
+            }
+        }
+        // ---------------- layer 2 (stride 2): 4 output parities, oh = 2 ih - 1 + kh (the tap order of ConvT2Addr, mfma_pipe.h) ---------------
+        float* Y = a.y2 + (size_t)img * (32 * 32 * 64);
+        int T = 9;
+#pragma unroll 1
+        for (int par = 0; par < 4; ++par) {
+            const int ph = par >> 1, pw = par & 1;
+            acc_init(16);
+            const int ntaps = (1 + ph) * (1 + pw);
+#pragma unroll 1
+            for (int t = 0; t < ntaps; ++t, ++T) {
+                const int th = t / (1 + pw), tw = t - th * (1 + pw);
+                const int da = (ph && th == 0) ? 1 : 0, db = (pw && tw == 0) ? 1 : 0;
+                int pb[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int sy = prow0 + 2 * nt + da, sx = pcol + db;
+                    pb[nt] = ((sy < 16 && sx < 16) ? sy * 16 + sx : 256) * DA3_PXB + g * 16;
+                }
+                const int npar = t + 1 < ntaps ? par : par + 1, nt_ = t + 1 < ntaps ? t + 1 : 0;
+                tap(T, pb, T < 17 ? W2 + (size_t)l2_wt(npar, nt_) * (DA3_SLAB / 16) : nullptr);
+            }
+            if (live) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float4* yp = reinterpret_cast<float4*>(Y) + (size_t)par * 4096 + ((4 * w + 2 * nt) * 16 + j) * 2 + g;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            float4 v;
+                            v.x = relu_bits(acc[mt][nt][4 * g4 + 0]); v.y = relu_bits(acc[mt][nt][4 * g4 + 1]);
+                            v.z = relu_bits(acc[mt][nt][4 * g4 + 2]); v.w = relu_bits(acc[mt][nt][4 * g4 + 3]);
+                            yp[(mt * 4 + g4) * 512] = v;
+                        }
+                }
+            }
+        }
+    }
+}
+
+void launch_dec_a_b3(const DecAArgs& a, hipStream_t st) {
+    const int grid = a.rows < 256 ? a.rows : 256;        // persistent: one workgroup per CU
+    hipLaunchKernelGGL(k_dec_a_b3, dim3(grid), dim3(256), DA3_LDS, st, a);
+}
+
+// conv weights for k_dec_a_b3: get(tap, co, ci) -> [tap][2 mt][4 ks][3 planes][64 lanes][8 bf16]
+void pack_conv_bf16x3(const float* W_cicokk, int Cin, int Cout, uint16_t* dst) {
+    for (int t = 0; t < 9; ++t)
+        for (int mt = 0; mt < Cout / 32; ++mt)
+            for (int ks = 0; ks < Cin / 16; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 8; ++s) {
+                        const int co = mt * 32 + (lane & 31), ci = ks * 16 + 8 * (lane >> 5) + s;
+                        uint32_t p[3];
+                        split3(W_cicokk[((size_t)ci * Cout + co) * 9 + t], p[0], p[1], p[2]);       // ConvTranspose2d weights are [Cin][Cout][kh][kw]
+                        for (int pl = 0; pl < 3; ++pl)
+                            dst[(((((size_t)t * (Cout / 32) + mt) * (Cin / 16) + ks) * 3 + pl) * 64 + lane) * 8 + s] = (uint16_t)p[pl];
+                    }
+}
+
 int init_bf16x3_kernels() {
+    if (hipFuncSetAttribute((const void*)k_dec_a_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DA3_LDS) != hipSuccess) return 1;
     return hipFuncSetAttribute((const void*)k_fc4_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS) != hipSuccess;
 }
 

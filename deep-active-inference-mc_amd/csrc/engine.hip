@@ -91,6 +91,7 @@ struct efe_ctx {
     int64_t fuse_final_g = 1;      // generic path: last two decoder layers in one kernel (k_dec_bg); 0 = separate launches (A/B, parity tests of k_final_g)
     int64_t mfma_bf16x3 = 0;       // OPT-IN EXPERIMENT (bf16x3.hip): Linear(256, 16384) of the decoder on the bf16 pipe, operands split in three bf16 planes
     uint16_t* fc4_b3 = nullptr;    // its packed planes (part of wbufs)
+    uint16_t* ct_b3[2] = {nullptr, nullptr};      // po_net.13 / .15 (k_dec_a's layers) as bf16 planes
     int64_t check_rows = 0;        // development: range-check efe_rows.ids on the host before every _rows call
     int64_t last_macs = 0;
     const uint8_t* row_mask = nullptr; int row_mask_div = 1;      // efe_set_row_mask
@@ -458,7 +459,8 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         da.x4 = x4; da.y2 = y2; da.w1 = ctx->dec_ct[0].Wp; da.b1 = ctx->dec_ct[0].bias; da.w2 = ctx->dec_ct[1].Wp;
         da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.live = live_of(nc, m0); da.queue = queues + m0 / C; da.parts = split ? 8 : 1;
         hipEvent_t e0 = ctx->prof_begin(st);
-        launch_dec_a(da, st);
+        if (ctx->mfma_bf16x3 && ctx->ct_b3[0] && !split) { da.w1b3 = ctx->ct_b3[0]; da.w2b3 = ctx->ct_b3[1]; launch_dec_a_b3(da, st); }      // opt-in experiment
+        else launch_dec_a(da, st);
         ctx->prof_end(e0, st);
         ctx->cls = PROF_CT3;
         DecBArgs db{};
@@ -788,6 +790,15 @@ static int pack_fc4_b3(efe_ctx* ctx) {
     pack_bf16x3(w->data.data(), rowp.data(), 16384, 256, planes.data());
     HIPCHK(hipMalloc((void**)&ctx->fc4_b3, planes.size() * 2)); ctx->wbufs.push_back(ctx->fc4_b3);
     HIPCHK(hipMemcpy(ctx->fc4_b3, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+    const char* ck[2] = {"down.po_net.13", "down.po_net.15"};
+    for (int i = 0; i < 2; ++i) {
+        const HostTensor* cw = need(ctx, std::string(ck[i]) + ".weight", {64, 64, 3, 3});
+        if (!cw) return 1;
+        std::vector<uint16_t> cp((size_t)9 * 64 * 64 * 3);
+        pack_conv_bf16x3(cw->data.data(), 64, 64, cp.data());
+        HIPCHK(hipMalloc((void**)&ctx->ct_b3[i], cp.size() * 2)); ctx->wbufs.push_back(ctx->ct_b3[i]);
+        HIPCHK(hipMemcpy(ctx->ct_b3[i], cp.data(), cp.size() * 2, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -800,7 +811,7 @@ int efe_commit_weights(efe_ctx* ctx) {
         HIPCHK(hipDeviceSynchronize());
         for (void* p : ctx->wbufs) (void)hipFree(p);
         ctx->wbufs.clear();
-        ctx->fc4_b3 = nullptr;
+        ctx->fc4_b3 = nullptr; ctx->ct_b3[0] = ctx->ct_b3[1] = nullptr;
     }
     ctx->committed = false;
     const int A = ctx->pi_dim;

@@ -109,6 +109,7 @@ struct DecAArgs {
     RowMask live;
     int parts;            // 1 = persistent, one image per workgroup pass; 8 = small launches, an image over eight workgroups (k_dec_a_s)
     int* queue;           // zero-initialised ticket counter of this launch: images beyond the first two per workgroup are claimed dynamically
+    const void* w1b3 = nullptr; const void* w2b3 = nullptr;      // option mfma_bf16x3: the two layers' weights as bf16 planes [tap][2][4][3][64 lanes][8] (bf16x3.hip)
 };
 // fused decoder, stage B: y2 -> ConvT(64,32,s2)+ReLU -> ConvT(32,1,s1)+Sigmoid -> per-image reduction (+ image store)
 struct DecBArgs {
@@ -142,6 +143,8 @@ void launch_enc_trunk(const EncArgs& a, hipStream_t st);
 void launch_fc4(const GemmArgs& a, hipStream_t st);      // Linear(256,16384)+ReLU+Dropout with the batch tile staged in LDS
 void launch_fc4_b3(const GemmArgs& a, hipStream_t st);   // the same on the bf16 pipe, operands split in three (opt-in experiment, bf16x3.hip)
 void pack_bf16x3(const float* W, const int* row_perm, int out, int in, uint16_t* dst);
+void launch_dec_a_b3(const DecAArgs& a, hipStream_t st);  // k_dec_a's two layers on the bf16 pipe, every operand through LDS (opt-in experiment)
+void pack_conv_bf16x3(const float* W_cicokk, int Cin, int Cout, uint16_t* dst);
 int init_bf16x3_kernels();
 void launch_dec_a(const DecAArgs& a, hipStream_t st);
 void launch_dec_b(const DecBArgs& a, hipStream_t st);
