@@ -74,6 +74,10 @@ int efe_commit_weights(efe_ctx* ctx);
  *                   layers 1 and 2, default 1, bit-identical to 0), "mid_unfused" (layer-by-layer transition MLP), "head_unfused" (the decoder / encoder dense heads as
  *                   one k_dense launch per layer instead of one k_head launch per head; same masks, fp32 summation order differs).  None of them removes work:
  *                   every setting computes the same quantities (fp32 summation order may differ where stated).
+ *   experiment    : "mfma_bf16x3" (0 / 1, default 0; Dynamic-dSprites geometry only).  1 = the decoder's Linear(256, 16384) and its first two
+ *                   ConvTranspose layers run on the bf16 matrix pipe with both operands split into three bf16 planes (six products per fp32
+ *                   product, fp32 accumulation: csrc/bf16x3.hip).  Inputs narrower than the reference's fp32 arithmetic, results inside the same
+ *                   tolerances (every fixture is run through it); never the default, never the benchmark's headline.
  *   development   : "poison" (pre-fill scratch with a byte), "trace" (synchronise and log every profiled launch), "arena_align", "check_rows"
  *                   (range-check efe_rows.ids against efe_rows.n_total on the host before every _rows call: one synchronisation per call) */
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value);
