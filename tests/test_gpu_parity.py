@@ -1302,6 +1302,14 @@ def test_bf16x3_every_decoder_fixture_at_unchanged_tolerances(golden, models_b3)
         test_planners_at_benchmark_depth_vs_reference(golden, models_b3, name)
 
 
+def test_bf16x3_large_launches_vs_oracle(models_b3, weights_cache):
+    """the launch sizes at which k_dec_a_b3 runs (the persistent kernel: more than 128 images per launch), against the oracle at the unchanged
+    tolerances: 1100 decoder rows, calculate_G over 150 rows x 4 samples, and the benchmarked configuration itself (128 rows x depth 5 x 10 samples)"""
+    test_decoder_many_rows_vs_oracle(models_b3, weights_cache)
+    test_calculate_G_many_rows_vs_oracle(models_b3, weights_cache)
+    test_full_size_cfg2_vs_oracle(models_b3, weights_cache)
+
+
 def test_bf16x3_vs_fp32_path_and_oracle_on_many_rows(models, weights_cache):
     """1100 decoder rows (several 64-row tiles + a ragged tail, every feature group): the experiment against the fp32 kernel (same masks,
     images within the sigmoid tolerance) and against the oracle; and it really is another kernel (not bit-identical)"""
