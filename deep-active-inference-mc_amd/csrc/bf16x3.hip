@@ -208,7 +208,16 @@ constexpr int DA3_W0 = (DA3_IMG + 255) & ~255;          // byte offset of weight
 constexpr int DA3_BIAS = DA3_W0 + 2 * DA3_SLAB;         // two bias vectors (fp32)
 constexpr size_t DA3_LDS = DA3_BIAS + 2 * 64 * sizeof(float);
 
-__global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
+// NTW = 32-pixel tiles per wave: 2 -> four waves (one per SIMD, 2 x 2 register tiles), 1 -> eight waves (two per SIMD, 2 x 1 tiles: nine
+// fragment reads per 12 MFMAs instead of 12 per 24, but a second wave on every SIMD fills the pipe while the first one stages, splits,
+// stores or waits at a barrier)
+#ifndef EFE_DA3_NTW
+#define EFE_DA3_NTW 1
+#endif
+template <int NTW>
+__global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
+    constexpr int NW = 8 / NTW, NTHR = 64 * NW, NPF = 4096 / NTHR, PP = 24 / NW;      // waves, threads, float4 of an image per thread, DMA pieces per wave and tap
+    constexpr int MF = 12 * NTW, NL = 6 + 3 * NTW;                                     // MFMAs and fragment reads of one 16-channel step
     extern __shared__ __attribute__((aligned(16))) unsigned char sm3[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,9 +226,7 @@ __global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
     const float4* bias4 = reinterpret_cast<const float4*>(sm3 + DA3_BIAS);
     if (tid < 16) reinterpret_cast<float4*>(sm3 + DA3_BIAS)[tid] = reinterpret_cast<const float4*>(a.b1)[tid];
     else if (tid < 32) reinterpret_cast<float4*>(sm3 + DA3_BIAS)[tid] = reinterpret_cast<const float4*>(a.b2)[tid - 16];
-    for (int i = tid; i < DA3_PXB / 4; i += 256) reinterpret_cast<uint32_t*>(sm3 + 256 * DA3_PXB)[i] = 0u;      // the zero pixel
-    // weight slab of tap index T (0 .. 17: layer 1 taps 0 .. 8, then layer 2's taps in the order the parities use them) -> buffer T & 1;
-    // 24 KiB = 6 float4 per thread, lane-linear
+    for (int i = tid; i < DA3_PXB / 4; i += NTHR) reinterpret_cast<uint32_t*>(sm3 + 256 * DA3_PXB)[i] = 0u;      // the zero pixel
     const float4* W1 = reinterpret_cast<const float4*>(a.w1b3);
     const float4* W2 = reinterpret_cast<const float4*>(a.w2b3);
     // packed tap index kh * 3 + kw of tap t of output parity par of the stride-2 layer (the order of ConvT2Addr, mfma_pipe.h)
@@ -228,13 +235,14 @@ __global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
         const int th = t / (1 + pw), tw = t - th * (1 + pw);
         return (ph ? (th ? 2 : 0) : 1) * 3 + (pw ? (tw ? 2 : 0) : 1);
     };
-    // a tap's 24 KiB of packed weights go global -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, destination = a
-    // wave-uniform base + lane * 16 -- exactly the fragment-major layout; no staging registers, no ds_write): wave w copies pieces 6 w .. 6 w + 5
-    const unsigned lds_w0 = (unsigned)(size_t)(sm3 + DA3_W0) + (unsigned)(6 * w) * 1024u;       // this wave's pieces inside weight buffer 0
+    // a tap's 24 KiB of packed weights (tap index T = 0 .. 17: layer 1's taps, then layer 2's in the order its parities use them) go
+    // global -> LDS buffer T & 1 by LDS-DMA: 1 KiB per wave-instruction, destination = a wave-uniform base + lane * 16 -- exactly the
+    // fragment-major layout; no staging registers, no ds_write.  Wave w copies pieces PP w .. PP w + PP - 1
+    const unsigned lds_w0 = (unsigned)(size_t)(sm3 + DA3_W0) + (unsigned)(PP * w) * 1024u;
     auto slab_dma = [&](const float4* src, int buf) {
-        const char* sp = reinterpret_cast<const char*>(src) + (size_t)(6 * w) * 1024 + lane * 16;
+        const char* sp = reinterpret_cast<const char*>(src) + (size_t)(PP * w) * 1024 + lane * 16;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) glds16(sp + i * 1024, lds_w0 + (unsigned)(buf * DA3_SLAB + i * 1024));
+        for (int i = 0; i < PP; ++i) glds16(sp + i * 1024, lds_w0 + (unsigned)(buf * DA3_SLAB + i * 1024));
     };
     // fp32 quad (4 consecutive channels c .. c + 3 of one pixel) -> the three planes of that pixel
     auto put_planes = [&](unsigned char* px, int c, const float v0, const float v1, const float v2, const float v3) {
@@ -244,14 +252,14 @@ __global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
         *reinterpret_cast<uint2*>(px + 128 + c * 2) = make_uint2(mid[0], mid[1]);
         *reinterpret_cast<uint2*>(px + 256 + c * 2) = make_uint2(lo[0], lo[1]);
     };
-    f32x4 pf[16];                                        // the next image: 64 KiB / 256 threads
+    f32x4 pf[NPF];                                       // the next image: 64 KiB / NTHR threads
     {
         const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)blockIdx.x * 4096;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) pf[it] = X[it * 256 + tid];
+        for (int it = 0; it < NPF; ++it) pf[it] = X[it * NTHR + tid];
     }
-    // this wave's 64 pixels: image rows 4 w .. 4 w + 3 as two 32-pixel tiles (rows 4 w + 2 nt, + 1)
-    const int pcol = j & 15, prow0 = 4 * w + (j >> 4);
+    // this wave's 32 NTW pixels: image rows 2 NTW w .. as NTW tiles of two rows each
+    const int pcol = j & 15, prow0 = 2 * NTW * w + (j >> 4);
     const unsigned char* abase = sm3 + DA3_W0 + lane * 16;
 
     for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
@@ -260,13 +268,13 @@ __global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
         __syncthreads();                                  // every wave is done with the previous image's planes
         if (live) {
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int idx = it * 256 + tid;           // pixel idx >> 4, channel quad idx & 15
+            for (int it = 0; it < NPF; ++it) {
+                const int idx = it * NTHR + tid;          // pixel idx >> 4, channel quad idx & 15
                 put_planes(sm3 + (size_t)(idx >> 4) * DA3_PXB, 4 * (idx & 15), pf[it][0], pf[it][1], pf[it][2], pf[it][3]);
             }
         }
         slab_dma(W1, 0);
-        f32x16 acc[2][2];
+        f32x16 acc[2][NTW];
         auto acc_init = [&](int boff) {                   // the accumulators start at the bias: register e of tile mt holds channel 32 mt + (e & 3) + 8 (e >> 2) + 4 g
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -274,54 +282,52 @@ __global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const float4 bb = bias4[boff + mt * 8 + 2 * g4 + g];
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) { acc[mt][nt][4 * g4] = bb.x; acc[mt][nt][4 * g4 + 1] = bb.y; acc[mt][nt][4 * g4 + 2] = bb.z; acc[mt][nt][4 * g4 + 3] = bb.w; }
+                    for (int nt = 0; nt < NTW; ++nt) { acc[mt][nt][4 * g4] = bb.x; acc[mt][nt][4 * g4 + 1] = bb.y; acc[mt][nt][4 * g4 + 2] = bb.z; acc[mt][nt][4 * g4 + 3] = bb.w; }
                 }
         };
-        // one tap: B views at pixel byte offsets pb[nt] (+ g * 16), weights in buffer T & 1 (staged during the previous tap); the next
-        // tap's slab is requested in front of the MFMAs and written behind them
         // one tap: B views at pixel byte offsets pb[nt] (+ g * 16), weights in buffer T & 1 (copied during the previous tap); the next tap's
-        // slab is copied during this one.  With ONE wave per SIMD nothing else fills the matrix pipe while this wave issues loads, so every
-        // LDS read and every DMA piece sits between two MFMAs (a burst of 12 ds_read_b128 in front of a step's 24 MFMAs cost as much time
-        // as the MFMAs: profiles/r5_dec_a_b3_ablation.txt): step ks issues, after every second MFMA, one of the 12 fragment reads of step
-        // ks + 1, and steps 0 .. 2 two DMA pieces each.
-        auto tap = [&](int T, const int (&pb)[2], const float4* next) {
+        // slab is copied during this one.  Every LDS read and every DMA piece sits between two MFMAs (with one wave per SIMD a burst of 12
+        // ds_read_b128 in front of a step's 24 MFMAs cost as much time as the MFMAs: profiles/r5_dec_a_b3_ablation.txt): fragment read l of
+        // step ks + 1 follows MFMA l MF / NL of step ks, the DMA pieces follow the middle MFMA of steps 0 .. 2.
+        auto tap = [&](int T, const int (&pb)[NTW], const float4* next) {
             glds_drain();                                 // this wave's pieces of slab T have landed ...
             __syncthreads();                              // ... and everybody's; nobody reads buffer (T + 1) & 1 any more
             const unsigned char* ab = abase + (T & 1) * DA3_SLAB;
-            const char* dsp = reinterpret_cast<const char*>(next) + (size_t)(6 * w) * 1024 + lane * 16;
+            const char* dsp = reinterpret_cast<const char*>(next) + (size_t)(PP * w) * 1024 + lane * 16;
             const unsigned ddp = lds_w0 + (unsigned)(((T + 1) & 1) * DA3_SLAB);
-            if (T == 14) {                                // the next image, requested over the last four taps (16 float4 per thread: held only from here)
+            if (T == 14) {                                // the next image, requested over the last four taps (held in registers only from here)
                 const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)(nimg < a.rows ? nimg : img) * 4096;
 #pragma unroll
-                for (int it = 0; it < 16; ++it) pf[it] = X[it * 256 + tid];
+                for (int it = 0; it < NPF; ++it) pf[it] = X[it * NTHR + tid];
             }
-            float4 af[2][2][3], bf[2][2][3];
+            float4 af[2][2][3], bf[2][NTW][3];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int p = 0; p < 3; ++p) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    af[0][t][p] = *reinterpret_cast<const float4*>(ab + ((t * 4 + 0) * 3 + p) * 1024);
-                    bf[0][t][p] = *reinterpret_cast<const float4*>(sm3 + pb[t] + p * 128);
-                }
+                for (int t = 0; t < 2; ++t) af[0][t][p] = *reinterpret_cast<const float4*>(ab + ((t * 4 + 0) * 3 + p) * 1024);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) bf[0][t][p] = *reinterpret_cast<const float4*>(sm3 + pb[t] + p * 128);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int cb = ks & 1, nb = cb ^ 1;
                 constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int q = 0; q < 12; ++q) {            // MFMAs 2 q, 2 q + 1 of the step's 24, then one load of the next step
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int m = 2 * q + u, pr = m >> 2, mt = (m >> 1) & 1, nt = m & 1;
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[cb][mt][PA[pr]]), __builtin_bit_cast(bf16x8, bf[cb][nt][PB[pr]]),
-                                                                              acc[mt][nt], 0, 0, 0);
-                    }
+                for (int m = 0; m < MF; ++m) {
+                    const int pr = m / (2 * NTW), mt = (m / NTW) & 1, nt = m % NTW;
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[cb][mt][PA[pr]]), __builtin_bit_cast(bf16x8, bf[cb][nt][PB[pr]]),
+                                                                          acc[mt][nt], 0, 0, 0);
                     if (ks < 3) {
-                        const int t = (q % 6) / 3, pl = q % 3;
-                        if (q < 6) af[nb][t][pl] = *reinterpret_cast<const float4*>(ab + ((t * 4 + ks + 1) * 3 + pl) * 1024);
-                        else bf[nb][t][pl] = *reinterpret_cast<const float4*>(sm3 + pb[t] + pl * 128 + (ks + 1) * 32);
-                        if (next != nullptr && (q == 3 || q == 9)) {
-                            const int i = 2 * ks + (q == 9);
-                            glds16(dsp + i * 1024, ddp + (unsigned)(i * 1024));
+#pragma unroll
+                        for (int l = 0; l < NL; ++l) {
+                            if (l * MF / NL != m) continue;
+                            if (l < 6) af[nb][l / 3][l % 3] = *reinterpret_cast<const float4*>(ab + (((l / 3) * 4 + ks + 1) * 3 + l % 3) * 1024);
+                            else bf[nb][(l - 6) / 3][(l - 6) % 3] = *reinterpret_cast<const float4*>(sm3 + pb[(l - 6) / 3] + ((l - 6) % 3) * 128 + (ks + 1) * 32);
+                        }
+                        if (next != nullptr) {
+#pragma unroll
+                            for (int i = 0; i < PP / 3; ++i)
+                                if (m == MF / 2 + 3 * i) glds16(dsp + ((PP / 3) * ks + i) * 1024, ddp + (unsigned)(((PP / 3) * ks + i) * 1024));
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -333,9 +339,9 @@ __global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
             const int kh = t / 3, kw = t - kh * 3;
-            int pb[2];
+            int pb[NTW];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NTW; ++nt) {
                 const int sy = prow0 + 2 * nt + 1 - kh, sx = pcol + 1 - kw;
                 const bool ok = sy >= 0 && sy < 16 && sx >= 0 && sx < 16;
                 pb[nt] = (ok ? sy * 16 + sx : 256) * DA3_PXB + g * 16;
@@ -345,8 +351,8 @@ __global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
         __syncthreads();                                  // every wave is done reading the input planes
         if (live) {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                unsigned char* px = sm3 + (size_t)(64 * w + 32 * nt + j) * DA3_PXB;
+            for (int nt = 0; nt < NTW; ++nt) {
+                unsigned char* px = sm3 + (size_t)(32 * NTW * w + 32 * nt + j) * DA3_PXB;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -367,9 +373,9 @@ __global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
             for (int t = 0; t < ntaps; ++t, ++T) {
                 const int th = t / (1 + pw), tw = t - th * (1 + pw);
                 const int da = (ph && th == 0) ? 1 : 0, db = (pw && tw == 0) ? 1 : 0;
-                int pb[2];
+                int pb[NTW];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < NTW; ++nt) {
                     const int sy = prow0 + 2 * nt + da, sx = pcol + db;
                     pb[nt] = ((sy < 16 && sx < 16) ? sy * 16 + sx : 256) * DA3_PXB + g * 16;
                 }
@@ -378,8 +384,8 @@ __global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
             }
             if (live) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    float4* yp = reinterpret_cast<float4*>(Y) + (size_t)par * 4096 + ((4 * w + 2 * nt) * 16 + j) * 2 + g;
+                for (int nt = 0; nt < NTW; ++nt) {
+                    float4* yp = reinterpret_cast<float4*>(Y) + (size_t)par * 4096 + ((2 * NTW * w + 2 * nt) * 16 + j) * 2 + g;
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -397,7 +403,7 @@ __global__ void __launch_bounds__(256, 1) k_dec_a_b3(const DecAArgs a) {
 
 void launch_dec_a_b3(const DecAArgs& a, hipStream_t st) {
     const int grid = a.rows < 256 ? a.rows : 256;        // persistent: one workgroup per CU
-    hipLaunchKernelGGL(k_dec_a_b3, dim3(grid), dim3(256), DA3_LDS, st, a);
+    hipLaunchKernelGGL(k_dec_a_b3<EFE_DA3_NTW>, dim3(grid), dim3(512 / EFE_DA3_NTW), DA3_LDS, st, a);
 }
 
 // conv weights for k_dec_a_b3: get(tap, co, ci) -> [tap][2 mt][4 ks][3 planes][64 lanes][8 bf16]
@@ -416,7 +422,7 @@ void pack_conv_bf16x3(const float* W_cicokk, int Cin, int Cout, uint16_t* dst) {
 }
 
 int init_bf16x3_kernels() {
-    if (hipFuncSetAttribute((const void*)k_dec_a_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DA3_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_dec_a_b3<EFE_DA3_NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DA3_LDS) != hipSuccess) return 1;
     return hipFuncSetAttribute((const void*)k_fc4_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS) != hipSuccess;
 }
 
