@@ -36,6 +36,7 @@ BUDGET = {
     'k_convt_p<1, 4>': 168, 'k_convt_p<1, 8>': 168, 'k_convt_p<2, 4>': 168, 'k_convt_p<2, 8>': 168,
     'k_conv_e<1, 4>': 168, 'k_conv_e<2, 16>': 168,
     'k_trans_fused': 256, 'k_head<16>': 256, 'k_head<32>': 256,
+    'k_fc4_b3': 256, 'k_dec_a_b3<1>': 256,                                      # the opt-in bf16 x 3 experiment: one 8-wave workgroup per CU = 2 waves per SIMD
 }
 
 
