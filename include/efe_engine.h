@@ -77,7 +77,8 @@ int efe_commit_weights(efe_ctx* ctx);
  *   experiment    : "mfma_bf16x3" (0 / 1, default 0; Dynamic-dSprites geometry only).  1 = the decoder's Linear(256, 16384) and its first two
  *                   ConvTranspose layers run on the bf16 matrix pipe with both operands split into three bf16 planes (six products per fp32
  *                   product, fp32 accumulation: csrc/bf16x3.hip).  Inputs narrower than the reference's fp32 arithmetic, results inside the same
- *                   tolerances (every fixture is run through it); never the default, never the benchmark's headline.
+ *                   tolerances (every fixture is run through it); never the default, never the benchmark's headline.  With it, results are no
+ *                   longer bit-identical across launch sizes (launches of <= 128 images keep the fp32 small-launch kernels), only within tolerance.
  *   development   : "poison" (pre-fill scratch with a byte), "trace" (synchronise and log every profiled launch), "arena_align", "check_rows"
  *                   (range-check efe_rows.ids against efe_rows.n_total on the host before every _rows call: one synchronisation per call) */
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value);
