@@ -197,9 +197,10 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
 //     a ds_read_b128 cover the 64 banks); layer 1's output is split and written back IN PLACE as layer 2's input, as in k_dec_a;
 //   * the weights of ONE tap (all 64 x 64, three planes, fragment-major = lane-linear: 24 KiB) in a double buffer, staged by the whole
 //     workgroup one tap ahead -- every wave reads the same fragments, so they cross the L1 once per workgroup instead of once per wave.
-// One workgroup of 4 waves per CU (150 KB of LDS), persistent over images (static stride, the next image prefetched into registers
-// during the contraction; one wave per SIMD has 512 registers).  A wave owns 64 channels x 64 pixels (2 x 2 tiles) like k_dec_a's:
-// per 16-channel step 12 ds_read_b128 feed 24 MFMAs (LDS at half its bandwidth).  y2 leaves in k_dec_a's fp32 layout: k_dec_b4 is unchanged.
+// One workgroup per CU (150 KB of LDS), persistent over images (static stride, the next image prefetched into registers over the last
+// four taps).  Shipped form: 8 waves, a wave owns 64 channels x 32 pixels (2 x 1 tiles: 9 ds_read_b128 per 12 MFMAs and 16-channel step);
+// the 4-wave 2 x 2 form (12 reads per 24 MFMAs, one wave per SIMD) is 2.5 % slower (tools/ubench/patches/da3_4waves.py).  y2 leaves in
+// k_dec_a's fp32 layout: k_dec_b4 is unchanged.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int DA3_PXB = 3 * 128 + 16;                   // bytes per staged pixel
 constexpr int DA3_IMG = 257 * DA3_PXB;                  // image + zero pixel
