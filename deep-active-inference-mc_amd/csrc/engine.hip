@@ -92,6 +92,8 @@ struct efe_ctx {
     int64_t mfma_bf16x3 = 0;       // OPT-IN EXPERIMENT (bf16x3.hip): Linear(256, 16384) of the decoder on the bf16 pipe, operands split in three bf16 planes
     uint16_t* fc4_b3 = nullptr;    // its packed planes (part of wbufs)
     uint16_t* ct_b3[2] = {nullptr, nullptr};      // po_net.13 / .15 (k_dec_a's layers) as bf16 planes
+    int64_t sim_split = 1;         // simulations of <= 16 episodes: the chain kernel on eight workgroups per 8 episodes (k_sim_chain<8>); 0 = one workgroup (A/B, bit-identical)
+    float* sim_xch = nullptr; int* sim_sync = nullptr;      // its exchange buffer and self-resetting counters (owned)
     int64_t check_rows = 0;        // development: range-check efe_rows.ids on the host before every _rows call
     int64_t last_macs = 0;
     const uint8_t* row_mask = nullptr; int row_mask_div = 1;      // efe_set_row_mask
@@ -703,6 +705,11 @@ int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channel
     if (hipMalloc((void**)&ctx->zeros, zeros_bytes) != hipSuccess || hipMemset(ctx->zeros, 0, zeros_bytes) != hipSuccess) { delete ctx; return 4; }
     ctx->owned.push_back(ctx->zeros);
     if (hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(ctx->zeros); delete ctx; return 6; }
+    {   // exchange buffer + counters of the split simulation chain (fused.hip k_sim_chain<8>): counters start at zero and re-arm themselves
+        const size_t xb = (size_t)SIM_MAX_SPLIT_GROUPS * 2 * 16 * 512 * sizeof(float), sb = (size_t)SIM_MAX_SPLIT_GROUPS * 4 * sizeof(int);
+        if (hipMalloc((void**)&ctx->sim_xch, xb) != hipSuccess || hipMalloc((void**)&ctx->sim_sync, sb) != hipSuccess || hipMemset(ctx->sim_sync, 0, sb) != hipSuccess) { delete ctx; return 4; }
+        ctx->owned.push_back(ctx->sim_xch); ctx->owned.push_back(ctx->sim_sync);
+    }
     *out = ctx;
     return 0;
 }
@@ -767,6 +774,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "poison")) { ctx->poison = value; return 0; }
     if (!strcmp(name, "trace")) { ctx->trace = value; return 0; }
     if (!strcmp(name, "check_rows")) { ctx->check_rows = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "sim_split")) { ctx->sim_split = value ? 1 : 0; return 0; }
     if (!strcmp(name, "mfma_bf16x3")) {       // opt-in experiment; the planes are packed now if the weights are already committed
         if (value && ctx->generic) return ctx->fail("mfma_bf16x3: the experiment covers the Dynamic-dSprites geometry only");
         ctx->mfma_bf16x3 = value ? 1 : 0;
@@ -1372,6 +1380,7 @@ int efe_simulate_rows(efe_ctx* ctx, const float* starting_s, int E, int depth, i
         sa.W = ctx->mid16; sa.H = ctx->top16; sa.s0 = starting_s; sa.E = E; sa.T = T; sa.use_means = use_means;
         sa.k0 = k0; sa.k1 = k1; sa.stage = nz->stage; sa.row_offset = nz->row_offset;
         sa.eps_inj = eps; sa.u_inj = u; sa.ids = rs.ids;
+        if (ctx->sim_split) { sa.xch = ctx->sim_xch; sa.sync = ctx->sim_sync; }
         sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0; sa.pi_dim = ctx->pi_dim; sa.tr = pre_tr;
         ctx->cls = PROF_MID;
         hipEvent_t e0 = ctx->prof_begin(st);

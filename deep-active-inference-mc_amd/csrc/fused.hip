@@ -126,6 +126,108 @@ __device__ __forceinline__ void trans_chain(const MlpW& W, float4* bufA, float4*
     __syncthreads();
 }
 
+// ---- the same chain with the two 512 x 512 layers SPLIT OVER NWG WORKGROUPS (k_sim_chain<NWG>, one-episode decisions) -------------------
+// Workgroup kw of a group computes feature tiles 4 kw .. 4 kw + 3 of layers 2 and 3 (one 16-feature tile per wave: an eighth of the weight
+// stream that bounds the one-workgroup form) and everything else redundantly.  The slices are exchanged through a small global buffer with
+// AGENT-SCOPE accesses (sc1: write-through stores, cache-bypassing loads) and a counter -- no release / acquire fences: on gfx950 those
+// write back and invalidate the XCD's whole L2 (the fenced form of round 4 was slower than one workgroup).  Every feature is contracted by
+// the same MFMA sequence over K as in trans_chain: bit-identical results.
+constexpr unsigned AUX_SC1 = 16u;                 // cache-policy bit 4 of the raw buffer intrinsics = sc1 on gfx940+ (agent scope)
+constexpr int XCH_ROW_F4 = 128;                   // exchange buffer: [16 rows][512 floats]
+
+// one 16-feature tile over KC = 32 chunks with the weight fragments EIGHT chunks ahead (a ring of eight statically indexed registers, the
+// loop fully unrolled): a single tile's four MFMAs per chunk (128 cycles) cannot cover the L2 round trip two chunks ahead, and in the split
+// chain nothing else runs on the SIMD.  Same accumulation order over K as gemm16<1>: bit-identical.
+__device__ __forceinline__ void gemm16_deep(f32x4& acc, const float4* __restrict__ Wp, int mt0, const float4* act, int n, int q, unsigned ln) {
+    constexpr int KC = 32, PD = 8;
+    const __amdgpu_buffer_rsrc_t wr = rsrc16(Wp);
+    float4 af[PD], bf[2];
+#pragma unroll
+    for (int p = 0; p < PD; ++p) af[p] = wfrag16(wr, ln, (unsigned)(mt0 * KC + p) * 64u);
+    bf[0] = act[aswz(n, q)];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        const float4 av = af[kc % PD], bv = bf[kc & 1];
+        if (kc + PD < KC) af[kc % PD] = wfrag16(wr, ln, (unsigned)(mt0 * KC + kc + PD) * 64u);
+        if (kc + 1 < KC) bf[(kc + 1) & 1] = act[aswz(n, 4 * (kc + 1) + q)];
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+}
+
+template <bool RELU, bool DROP>
+__device__ __forceinline__ float4 hidden16_slice(const float4* __restrict__ Wp, const float* __restrict__ bias, int mt0, int KC, const float4* act_in,
+                                                 int n, int q, unsigned ln, uint32_t k0, uint32_t k1, uint32_t tag, const RowKey& rk) {
+    f32x4 acc[1];
+    acc[0] = (f32x4)(0.f);
+    const float4 bq = *reinterpret_cast<const float4*>(bias + 16 * mt0 + 4 * q);
+    gemm16_deep(acc[0], Wp, mt0, act_in, n, q, ln);          // (KC = 32: the two 512-wide layers)
+    const int f = 16 * mt0 + 4 * q;
+    float v[4] = {acc[0][0] + bq.x, acc[0][1] + bq.y, acc[0][2] + bq.z, acc[0][3] + bq.w};
+    if (RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+    }
+    if (DROP) {
+        const uint4 rnd = noise_words(k0, k1, tag, (uint32_t)(f >> 7), rk.row, rk.stream, rk.stage);
+        const int wsel = (f >> 5) & 3;
+        const uint32_t word = wsel == 0 ? rnd.x : wsel == 1 ? rnd.y : wsel == 2 ? rnd.z : rnd.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((word >> ((f + e) & 31)) & 1u) ? v[e] * 2.0f : 0.0f;
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// all NWG workgroups of the group have stored their slice of xbuf -> the full [16][512] activation in LDS (act_out).  *bad is set when the
+// peers do not arrive within the spin bound (~0.3 s: the results are then poisoned by the caller, never silently wrong).
+template <int NWG>
+__device__ __forceinline__ void xchg_gather(const float* xbuf, int* flag, int target, float4* act_out, int tid, int* bad) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's slice stores are acknowledged (write-through)
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(1);
+        if (spins >= (1 << 18)) *bad = 1;
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t xr = rsrc16(xbuf);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 256 + tid, row = idx >> 7, c4 = idx & 127;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)idx * 16u, 0, AUX_SC1);
+        act_out[aswz(row, c4)] = __builtin_bit_cast(float4, v);
+    }
+    __syncthreads();
+}
+
+template <int NWG>
+__device__ __forceinline__ void trans_chain_x(const MlpW& W, float4* bufA, float4* bufB, int w, int n, int q, unsigned ln, uint32_t k0, uint32_t k1,
+                                              const RowKey& rk, int kw, float* xch, int* sync, int& xn, int tid, int* bad) {
+    hidden16<8, true, true>(W.w[0], W.b[0], 8 * w, 1, bufA, bufB, n, q, ln, k0, k1, TAG_MID + 0, rk);        // K = 16: every workgroup computes all of it
+    __syncthreads();
+    const int mt0 = 4 * kw + w;
+    {
+        const float4 v = hidden16_slice<true, true>(W.w[1], W.b[1], mt0, 32, bufB, n, q, ln, k0, k1, TAG_MID + 1, rk);
+        float* xb = xch + (size_t)(xn & 1) * (16 * 512);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc16(xb), (unsigned)((n * XCH_ROW_F4 + 4 * mt0 + q) * 16), 0, AUX_SC1);
+        xchg_gather<NWG>(xb, sync, NWG * (xn + 1), bufA, tid, bad);
+        ++xn;
+    }
+    {
+        const float4 v = hidden16_slice<true, true>(W.w[2], W.b[2], mt0, 32, bufA, n, q, ln, k0, k1, TAG_MID + 2, rk);
+        float* xb = xch + (size_t)(xn & 1) * (16 * 512);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc16(xb), (unsigned)((n * XCH_ROW_F4 + 4 * mt0 + q) * 16), 0, AUX_SC1);
+        xchg_gather<NWG>(xb, sync, NWG * (xn + 1), bufB, tid, bad);
+        ++xn;
+    }
+    if (w < 2) bufA[aswz(n, 4 * w + q)] = hidden16_slice<false, false>(W.w[3], W.b[3], w, 32, bufB, n, q, ln, k0, k1, 0u, rk);      // 512 -> 20 (+ padding), deep prefetch
+    __syncthreads();
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------
@@ -186,7 +288,10 @@ void launch_trans_fused(const TransFusedArgs& a, hipStream_t st) {
 // trajectory core ([2 groups][E * T rows][32]: group 0 = the given (mean, logvar), group 1 = the T2 transition), which then needs no
 // transition launch of its own (one-episode decisions: 39 us of a 0.6 ms iteration, on the critical path).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int SIM_FE = 8;              // episodes per workgroup
+// NWG = 1: one workgroup per 8 episodes (any batch size).  NWG = 8: the same group of 8 episodes on EIGHT workgroups that split the two wide
+// layers of the transition net (trans_chain_x): 237 -> ~100 us per launch for the one-episode planner, whose critical path it is.
+constexpr int SIM_FE = 8;              // episodes per workgroup (group)
+template <int NWG>
 __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 sm[];
     float4* bufA = sm;
@@ -199,9 +304,16 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
     const int n = lane & 15, q = lane >> 4;
     const int ne = n & 7, second = n >> 3;                          // tile row n = (episode slot ne, pass: 0 = SIM, 1 = T2)
     const unsigned ln = (unsigned)lane * 16u;
-    const int e0 = blockIdx.x * SIM_FE;
+    const int grp = NWG == 1 ? (int)blockIdx.x : (int)blockIdx.x / NWG, kw = NWG == 1 ? 0 : (int)blockIdx.x % NWG;
+    const int e0 = grp * SIM_FE;
     const int E = a.E, T = a.T;
     const uint32_t stage_ = a.stage;
+    const bool writer = kw == 0;                                    // (every workgroup of a group computes the same rollout; one writes it)
+    __shared__ int bad_;
+    if (tid == 0) bad_ = 0;
+    int xn = 0;                                                     // exchanges done (NWG > 1)
+    float* const xch = NWG == 1 ? nullptr : a.xch + (size_t)grp * (2 * 16 * 512);
+    int* const sync = NWG == 1 ? nullptr : a.sync + grp * 4;
     const uint32_t erow = global_row(a.ids, 1, min(e0 + ne, E - 1), a.row_offset);      // (episodes past E: any valid key, results discarded)
     if (tid < SIM_FE * 16) {
         const int rr = tid >> 4, k = tid & 15, e = e0 + rr;
@@ -241,7 +353,7 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
             for (int k = 0; k < A; ++k) {
                 const float oh = (k == act) ? 1.f : 0.f;
                 sact[tid * 8 + k] = oh;
-                if (e < E) {
+                if (e < E && writer) {
                     a.pi0[((size_t)e * T + t) * A + k] = oh;
                     if (t == 0 && a.Qpi0) a.Qpi0[(size_t)e * A + k] = bad ? oh : qq[k];
                 }
@@ -261,9 +373,10 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
         const RowKey rk = second ? RowKey{erow * (uint32_t)T + (uint32_t)t, stream_id(PASS_T2, 0u), stage_}
                                  : RowKey{erow, stream_id(PASS_SIM, (uint32_t)t), stage_};
         __syncthreads();
-        trans_chain(a.W, bufA, bufB, w, n, q, ln, a.k0, a.k1, rk);
+        if (NWG == 1) trans_chain(a.W, bufA, bufB, w, n, q, ln, a.k0, a.k1, rk);
+        else trans_chain_x<NWG>(a.W, bufA, bufB, w, n, q, ln, a.k0, a.k1, rk, kw, xch, sync, xn, tid, &bad_);
         // ---- both transitions into the trajectory core's tr rows: [pass][e * T + t][32] (mean 0..9, logvar 10..19, zero padding)
-        if (tid < 64 && e0 + ne < E && a.tr) {
+        if (tid < 64 && e0 + ne < E && a.tr && writer) {
             float4* dst = reinterpret_cast<float4*>(a.tr + ((size_t)second * E * T + (size_t)(e0 + ne) * T + t) * 32);
             dst[q] = bufA[aswz(n, q)];
             dst[4 + q] = bufA[aswz(n, 4 + q)];
@@ -278,18 +391,30 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
                                             : normal_elem(a.k0, a.k1, global_row(a.ids, 1, e, a.row_offset), stream_id(PASS_SIM, (uint32_t)t), stage_, k);
                 const float samp = eps * expf(lv * 0.5f) + mean;
                 const size_t oo = ((size_t)e * T + t) * 10 + k;
-                a.s0_traj[oo] = srow[rr * 16 + k];
-                a.ps1_traj[oo] = samp; a.mean_traj[oo] = mean; a.lv_traj[oo] = lv;
+                if (writer) {
+                    a.s0_traj[oo] = srow[rr * 16 + k];
+                    // (a peer workgroup that never arrived: the rollout is poisoned, not silently wrong)
+                    a.ps1_traj[oo] = samp; a.mean_traj[oo] = (NWG > 1 && bad_) ? __builtin_nanf("") : mean; a.lv_traj[oo] = lv;
+                }
                 srow[rr * 16 + k] = a.use_means ? mean : samp;          // each (row, k) is read and rewritten by this thread only
             }
         }
         __syncthreads();
     }
+    if (NWG > 1 && tid == 0) {
+        // the last workgroup of the group to finish re-arms the counters for the next launch (all eight have passed every exchange by then)
+        if (__hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NWG - 1) {
+            __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 void launch_sim_chain(const SimChainArgs& a, hipStream_t st) {
     const size_t lds = 2 * ACT_F4 * sizeof(float4) + (SIM_FE * 16 + SIM_FE * 8) * sizeof(float);
-    hipLaunchKernelGGL(k_sim_chain, dim3((a.E + SIM_FE - 1) / SIM_FE), dim3(256), lds, st, a);
+    const int groups = (a.E + SIM_FE - 1) / SIM_FE;
+    if (a.xch && a.sync && groups <= SIM_MAX_SPLIT_GROUPS) hipLaunchKernelGGL(k_sim_chain<8>, dim3(groups * 8), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(k_sim_chain<1>, dim3(groups), dim3(256), lds, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -433,7 +558,8 @@ int init_fused_kernels() {
     if (hipFuncSetAttribute((const void*)k_head<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * 64 * sizeof(float4)) != hipSuccess) return 1;
     const size_t lds = 2 * ACT_F4 * sizeof(float4) + (FR * 16 + FR * 8) * sizeof(float);
     if (hipFuncSetAttribute((const void*)k_trans_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ACT_F4 * sizeof(float4)) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)k_sim_chain, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_sim_chain<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_sim_chain<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
     return 0;
 }
 

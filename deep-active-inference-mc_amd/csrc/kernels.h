@@ -250,7 +250,11 @@ struct SimChainArgs {
     float* tr;             // nullable [2][E * T][32]: the trajectory core's transition rows (given T1 | T2 of the same input)
     int pi_dim;
     const int32_t* ids;                         // optional episode identities: episode slot e is episode ids[e] of the un-compacted batch
+    // optional (one-episode decisions): a group of 8 episodes on EIGHT workgroups that split the two wide transition layers; exchange buffer
+    // [groups][2][16][512] floats and self-resetting counters [groups][4] ints (zero at first use), both owned by the context
+    float* xch = nullptr; int* sync = nullptr;
 };
+constexpr int SIM_MAX_SPLIT_GROUPS = 2;          // launches of up to 16 episodes use the split form
 void launch_sim_chain(const SimChainArgs& a, hipStream_t st);
 int init_fused_kernels();
 

@@ -293,6 +293,32 @@ def test_unfused_transition_option_covers_every_path(models):
     assert not np.array_equal(sim[0], ref_sim[0]) or not np.array_equal(G, ref_G)      # the option really switched the kernels
 
 
+@pytest.mark.parametrize('E', [1, 3, 8, 11, 16])
+def test_split_simulation_chain_is_bit_identical(models, E):
+    """efe_simulate of <= 16 episodes runs the habit-policy chain on EIGHT workgroups per 8 episodes (k_sim_chain<8>: the two 512-wide
+    transition layers split by feature tiles, slices exchanged with agent-scope accesses and a counter) -- every output bit equals the
+    one-workgroup kernel's (option sim_split = 0), call after call (the counters re-arm themselves), with device and with injected noise"""
+    m = models(1234, 1.15, 37)
+    starts = PX.uniform_fill(13, (E, 10), 610, -1, 1)
+    outs = {}
+    try:
+        for split in (1, 0):
+            m.set_option('sim_split', split)
+            runs = []
+            for rep in range(3):
+                runs.append([c(t) for t in m.simulate_batch(starts, 5, False, stage=40 + rep)])
+            inject(m)
+            runs.append([c(t) for t in m.simulate_batch(starts, 4, True, stage=50)])
+            m.eps_source, m.u_source = None, None
+            outs[split] = runs
+    finally:
+        m.set_option('sim_split', 1)
+    for ra, rb in zip(outs[1], outs[0]):
+        for a_, b_ in zip(ra, rb):
+            assert np.isfinite(a_).all() and np.array_equal(a_, b_)
+    assert not np.array_equal(outs[1][0][0], outs[1][1][0])          # different stages: different draws
+
+
 def test_planner_replica_follows_engine_options(models):
     """engine options are per context: the replica the lock-step planner simulates on must compute with the options of the model it
     mirrors (reward_upstream_intent changes term0 / G) -- a planner with the simulations on the second stream equals the same planner

@@ -56,7 +56,7 @@ SSPILL = {
     'k_conv_e<1, 4>': 0, 'k_conv_e<2, 16>': 0,
     'k_enc_trunk': 26, 'k_head<16>': 25, 'k_head<32>': 22,      # (+4 / +10 with the row-identity pointer of ABI 4 among the kernel arguments)
     'k_final_g': 47,            # fallback of the generic decoder tail (option fuse_final_g = 0 / the resolution-32 variant)
-    'k_sim_chain': 131,         # latency-bound one-launch simulation chain (0.28 ms per planner iteration, beside the expansion)
+    'k_sim_chain<1>': 131, 'k_sim_chain<8>': 180,      # latency-bound one-launch simulation chain (one workgroup per 8 episodes / split over eight)
 }
 SSPILL_DEFAULT = 0
 
