@@ -177,10 +177,14 @@ def maxdiff(a, b):
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_grad_enabled(False)
-    manifest = {'torch': torch.__version__, 'numpy': np.__version__,
-                'shim': ['cv2 stub', 'qs_net[9]=Linear(576,256)', 'precision=float32'],
-                'noise': 'Philox4x32-10 injected via F.dropout / torch.randn_like / torch.multinomial patches',
-                'cases': {}}
+    # (merged into an existing manifest: the other generators -- make_golden_deep / _invalid / _thr / _stats -- add their cases to the same
+    # file, so the result does not depend on the order the generators are run in; oracle/regenerate_all.sh runs them all)
+    mpath0 = os.path.join(GOLD, 'MANIFEST.json')
+    manifest = json.load(open(mpath0)) if os.path.exists(mpath0) else {}
+    manifest.update({'torch': torch.__version__, 'numpy': np.__version__,
+                     'shim': ['cv2 stub', 'qs_net[9]=Linear(576,256)', 'precision=float32'],
+                     'noise': 'Philox4x32-10 injected via F.dropout / torch.randn_like / torch.multinomial patches'})
+    manifest.setdefault('cases', {})
     report = {}
 
     def save(name, **arrs):
