@@ -11,4 +11,5 @@ python -m oracle.make_golden_env        # environment (Game) capture
 python -m oracle.make_golden_invalid    # bare-except fallback of mcts_step_simulate
 python -m oracle.make_golden_thr        # the planner's early stops at benchmark depth (thresholds 0.5 / 0.4)
 python -m oracle.make_golden_stats      # SAMPLES of the unpatched reference under torch's own generator (statistical pin)
+python -m oracle.make_golden_stats_planner   # ... and 512 whole planner decisions under that generator
 python tests/golden/make_c_blob.py      # calcG_m4s1_g115.npz -> flat blob for tests/c_abi_smoke.c (needs no reference)

@@ -343,3 +343,35 @@ def test_device_noise_simulate_has_the_reference_distribution(model):
         Gs[k] = g; As[k] = _c(p).argmax(1)
     compare_simulate(ref, Gs, As, _c(q), 'engine simulate / stages', report)
     _dump(report)
+
+
+@pytest.mark.gpu
+def test_device_noise_planner_decisions_have_the_reference_distribution(model):
+    """one level up: whole DECISIONS.  512 runs of the reference planner (active_inference_mcts, /root/reference/src/mcts.py:150-195, its
+    default parameters at repeats 12 / depth 3 / threshold 0.3) under torch's own generator (oracle/make_golden_stats_planner.py) against 2 048 episodes of
+    the lock-step planner on the same frame in device-noise mode: the distribution of the early stop (repeats_done), of the most visited
+    root action, of the first action of the returned path, of the path length, and the mean root visit distribution"""
+    import daimc_amd
+    ref = load_golden('stats_planner')
+    p = daimc_amd.MCTS_Params()                                      # the reference's defaults (use_means True, C 1.0) ...
+    assert (p.use_means, p.C) == (bool(ref['use_means']), float(ref['C']))
+    p.repeats, p.simulation_depth, p.threshold = int(ref['repeats']), int(ref['simulation_depth']), float(ref['threshold'])      # ... 12 / 3 / 0.3
+    E, n_ref = 2048, len(ref['repeats_done'])
+    frames = torch.from_numpy(np.tile(ref['frame'], (E, 1, 1, 1)))
+    model._stage = 20000
+    out, visits = daimc_amd.active_inference_mcts_batch(model, frames, p, o_shape=(1, 64, 64))
+    report = []
+    R = p.repeats
+    reps = np.array([o_[1] for o_ in out]); plen = np.array([len(o_[0]) for o_ in out])
+    first = np.array([o_[0][0] if len(o_[0]) else -1 for o_ in out])
+    ref_first = np.where(ref['path_len'] > 0, ref['paths'][:, 0], -1)
+    same_frequencies(np.bincount(ref['repeats_done'], minlength=R + 1), n_ref, np.bincount(reps, minlength=R + 1), E, 'planner repeats_done', report)
+    same_frequencies(np.bincount(ref_first + 1, minlength=5), n_ref, np.bincount(first + 1, minlength=5), E, 'planner first action (0 = empty path)', report)
+    same_frequencies(np.bincount(ref['path_len'], minlength=R + 3), n_ref, np.bincount(plen, minlength=R + 3), E, 'planner path length', report)
+    v = visits.numpy()
+    ref_v = ref['root_N'] / ref['root_N'].sum(1, keepdims=True)
+    same_frequencies(np.bincount(ref_v.argmax(1), minlength=4), n_ref, np.bincount(v.argmax(1), minlength=4), E, 'planner most visited root action', report)
+    for a in range(4):
+        same_distribution(ref_v[:, a], v[:, a], f'planner root visit share[{a}]', report, ks=False)      # (a lattice-valued quantity: mean / variance only)
+    assert len(np.unique(reps)) >= 3 and 0 < (reps < R).mean() < 1              # the early stop is exercised AND not universal
+    _dump(report)
