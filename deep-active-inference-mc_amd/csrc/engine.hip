@@ -86,7 +86,8 @@ struct efe_ctx {
     // fused path, 1.6 MB with the final layer unfused); poison / trace: development only
     int64_t arena_align = 256;
     int64_t reward_intent = 0;     // option "reward_upstream_intent": 1 = the reward target the upstream NHWC code means (kernels.h reward_term), 0 = the shipped port's
-    int64_t enc_tiled = 1;         // generic path: LDS-tiled encoder layers 1 and 2 (k_conv_e); 0 = k_conv_g for every layer (A/B, parity of the fallback)
+    int64_t enc_tiled = 2;         // generic path, encoder layers 1 and 2: 2 = one kernel, conv1 kept in LDS (k_conv_e12); 1 = LDS-tiled, one launch per layer
+                                   // (k_conv_e); 0 = k_conv_g for every layer (A/B, parity of the fallbacks)
     int64_t dec_split = 1;         // dSprites path: decoder launches of <= 128 images run k_dec_b4 with four workgroups per image (0 = never: A/B)
     int64_t fuse_final_g = 1;      // generic path: last two decoder layers in one kernel (k_dec_bg); 0 = separate launches (A/B, parity tests of k_final_g)
     int64_t mfma_bf16x3 = 0;       // OPT-IN EXPERIMENT (bf16x3.hip): Linear(256, 16384) of the decoder on the bf16 pipe, operands split in three bf16 planes
@@ -401,14 +402,25 @@ int run_encoder_g(efe_ctx* ctx, const float* o8, int N, const NoiseCfg& nc, floa
             return rc;
         };
         const float* o4c = o8 + (size_t)m0 * hw[0] * hw[0] * GEN_IMG_LD;
-        if (conv_e(1, o4c, c1, ctx->g_enc1p, ctx->g_enc[0].bias, hw[0], hw[1])) {
-            // k_conv_g contracts 8 input channels per tap: widen the image first (this path: option enc_tiled = 0)
-            if (!o8w) o8w = ctx->allocT<float>((size_t)C * hw[0] * hw[0] * 8);
-            if (!o8w) return 1;
-            launch_nhwc4_to_8(o4c, o8w, (long)c * hw[0] * hw[0], st);
-            conv(ctx->g_enc[0], o8w, c1, c, hw[0], 8, hw[1], 32);
+        int sep12 = 1;                                    // layers 1 and 2 as one launch each
+        if (ctx->enc_tiled >= 2) {                        // ... or as one kernel, conv1's output kept in LDS
+            ConvE12Args e{};
+            e.in = o4c; e.out = c2; e.W1p = ctx->g_enc1p; e.b1 = ctx->g_enc[0].bias; e.W2p = ctx->g_enc[1].Wp; e.b2 = ctx->g_enc[1].bias;
+            e.n_img = c; e.H0 = e.W0 = hw[0]; e.H1 = e.W1 = hw[1]; e.H2 = e.W2 = hw[2]; e.live = live_of(nc, m0);
+            hipEvent_t e0 = ctx->prof_begin(st);
+            sep12 = launch_conv_e12(e, st);
+            ctx->prof_end(sep12 ? nullptr : e0, st);
         }
-        if (conv_e(2, c1, c2, ctx->g_enc[1].Wp, ctx->g_enc[1].bias, hw[1], hw[2])) conv(ctx->g_enc[1], c1, c2, c, hw[1], 32, hw[2], 32);
+        if (sep12) {
+            if (conv_e(1, o4c, c1, ctx->g_enc1p, ctx->g_enc[0].bias, hw[0], hw[1])) {
+                // k_conv_g contracts 8 input channels per tap: widen the image first (this path: option enc_tiled = 0)
+                if (!o8w) o8w = ctx->allocT<float>((size_t)C * hw[0] * hw[0] * 8);
+                if (!o8w) return 1;
+                launch_nhwc4_to_8(o4c, o8w, (long)c * hw[0] * hw[0], st);
+                conv(ctx->g_enc[0], o8w, c1, c, hw[0], 8, hw[1], 32);
+            }
+            if (conv_e(2, c1, c2, ctx->g_enc[1].Wp, ctx->g_enc[1].bias, hw[1], hw[2])) conv(ctx->g_enc[1], c1, c2, c, hw[1], 32, hw[2], 32);
+        }
         conv(ctx->g_enc[2], c2, c3, c, hw[2], 32, hw[3], 64);
         conv(ctx->g_enc[3], c3, c4, c, hw[3], 64, hw[4], 64);
         if (!ctx->head_unfused) head(ctx, true, c4, enc + (size_t)m0 * 32, c, nc, m0, st);
@@ -766,7 +778,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     EFE_LOCK(ctx);
     if (!strcmp(name, "dec_chunk")) { if (value < 1) return ctx->fail("dec_chunk < 1"); ctx->dec_chunk = value; return 0; }
     if (!strcmp(name, "reward_upstream_intent")) { ctx->reward_intent = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "enc_tiled")) { ctx->enc_tiled = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "enc_tiled")) { ctx->enc_tiled = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
     if (!strcmp(name, "fuse_final_g")) { ctx->fuse_final_g = value ? 1 : 0; return 0; }
     if (!strcmp(name, "dec_split")) { ctx->dec_split = value ? 1 : 0; return 0; }
     if (!strcmp(name, "dec_budget_g")) { if (value < (1 << 20)) return ctx->fail("dec_budget_g < 1 MiB"); ctx->dec_budget_g = value; return 0; }

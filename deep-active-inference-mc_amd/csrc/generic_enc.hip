@@ -141,6 +141,163 @@ __global__ void __launch_bounds__(256, 2) k_conv_e(const ConvEArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_conv_e12: layers 1 AND 2 in one kernel -- conv1's output (215 KB per image at 84 x 84: written once and read once by the pair of
+// kernels above, 80 % of their HBM traffic) never leaves the chip.  The conv1 rows a strip of conv2 rows needs are the conv2 input ring
+// of k_conv_e<2> (same slots, same de-interleaved columns), PRODUCED in place of fetched: a strip is an L1 phase (every wave computes
+// 32-pixel tiles of the strip's new conv1 rows, round-robin, and writes bias + ReLU as four float4 per lane into the ring) and the L2
+// phase of k_conv_e<2>, two barriers apart.  conv1's operands come straight from the NHWC4 image in global memory (16 B per pixel: a tap
+// is two dwords per lane, channels h and 2 + h; a wave's requests cover whole 128-byte lines, the 9 / 4 re-reads hit the L1), requested
+// one tile ahead -- the first tile of the NEXT strip before this strip's L2 phase -- so no image ring is needed and two workgroups fit
+// a CU.  Every conv1 / conv2 element sees the operations of k_conv_e<1> / <2> in the same order: bit-identical to the two launches.
+// ---------------------------------------------------------------------------------------------------------
+typedef unsigned u32x2e __attribute__((ext_vector_type(2)));
+#ifndef EFE_E12_EARLY
+#define EFE_E12_EARLY 0
+#endif
+#ifndef EFE_E12_PD
+#define EFE_E12_PD 4
+#endif
+constexpr int E12_ROUNDS = 5;
+constexpr int E12_PD = EFE_E12_PD;                  // weight fragments of the L2 phase requested this many 8-channel blocks ahead (a tap = 4 blocks = 1024 MFMA cycles)
+constexpr bool E12_EARLY = EFE_E12_EARLY != 0;      // request a block's operands before the previous strip's L2 phase instead of behind its barrier
+__global__ void __launch_bounds__(256, 2) k_conv_e12(const ConvE12Args a) {
+    extern __shared__ __attribute__((aligned(16))) float4 sx[];        // [NR ring rows][W1 slots][9]: conv1 + ReLU, 32 channels + 1 pad quad
+    constexpr int PS4 = 9;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int img = blockIdx.x;
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    const int W0 = a.W0, W1 = a.W1, W2 = a.W2, H2 = a.H2, TY = a.TY;
+    const int NR = 2 * TY + 1, WE = (W1 + 1) >> 1;
+    const char* ximg = reinterpret_cast<const char*>(a.in + (size_t)img * a.H0 * W0 * GEN_IMG_LD);
+    const unsigned rowb = (unsigned)W0 * GEN_IMG_LD * 4u;           // bytes of an image row
+    float2 w1[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w1[t] = reinterpret_cast<const float2*>(a.W1p)[t * 64 + lane];
+    float4 bq1[4], bq2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { bq1[g] = *reinterpret_cast<const float4*>(a.b1 + 8 * g + 4 * h); bq2[g] = *reinterpret_cast<const float4*>(a.b2 + 8 * g + 4 * h); }
+    const float4* Wl = reinterpret_cast<const float4*>(a.W2p);
+    float* dst = a.out + (size_t)img * H2 * W2 * 32;
+
+    // ---- L1: tile T of a block of new conv1 rows = its pixels 32 T .. 32 T + 31 (row-major over the block)
+    auto l1_req = [&](float (&v)[18], int T, int first_row, int npx) {
+        const int p = T * 32 + j;
+        const int rk = (int)__umulhi((unsigned)p, a.magicW1), x = p - rk * W1;
+        // image pixel (2 R, 2 x), channels 2 h and 2 h + 1: ONE dwordx2 per tap and lane (the two halves of a wave fetch whole pixels; as two
+        // dwords per tap -- channels h and 2 + h, what the MFMA steps consume -- the requests cost 28 cycles each in the texture path and a
+        // quarter of the kernel's time).  A lane without a pixel reads the block's first pixel (its tile stores nothing for it).
+        // (plain global loads, uniform row base + 32-bit lane offset: this hipcc lowers __builtin_amdgcn_raw_buffer_load_b64 to ONE dword)
+        const unsigned off = p < npx ? (unsigned)(2 * rk) * rowb + (unsigned)(2 * x * GEN_IMG_LD + 2 * h) * 4u : (unsigned)(2 * h) * 4u;
+        const char* r0 = ximg + (size_t)(2 * first_row) * rowb;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t - 3 * kh;
+            const float2 q = *reinterpret_cast<const float2*>(r0 + (size_t)kh * rowb + (off + (unsigned)(kw * GEN_IMG_LD * 4)));
+            v[2 * t] = q.x; v[2 * t + 1] = q.y;
+        }
+    };
+    auto l1_tile = [&](const float (&v)[18], int T, int npx, int slot0) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // lane half 0 holds channels (0, 1) of its pixel, half 1 channels (2, 3); the MFMA steps contract (0 | 1) and (2 | 3) -- the
+            // order of k_conv_e<1> and k_conv_g: v_permlane32_swap exchanges the upper half of the first register with the lower half of the second
+            // (as inline assembly with its own wait states: through __builtin_amdgcn_permlane32_swap this hipcc fed the FIRST result to both MFMAs)
+            float c01 = v[2 * t], c23 = v[2 * t + 1];
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c01), "+v"(c23));
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[t].x, c01, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[t].y, c23, acc, 0, 0, 0);
+        }
+        const int p = T * 32 + j;
+        if (p < npx) {                                  // bias + ReLU; register e holds channel (e & 3) + 8 (e >> 2) + 4 h = quad 2 (e >> 2) + h
+            const int rk = (int)__umulhi((unsigned)p, a.magicW1), x = p - rk * W1;
+            int r = slot0 + rk;
+            r = r >= NR ? r - NR : r;
+            r = r >= NR ? r - NR : r;
+            float4* op = sx + (r * W1 + ((x & 1) ? WE + (x >> 1) : (x >> 1))) * PS4 + h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 o;
+                o.x = fmaxf(acc[4 * g] + bq1[g].x, 0.f); o.y = fmaxf(acc[4 * g + 1] + bq1[g].y, 0.f);
+                o.z = fmaxf(acc[4 * g + 2] + bq1[g].z, 0.f); o.w = fmaxf(acc[4 * g + 3] + bq1[g].w, 0.f);
+                op[2 * g] = o;
+            }
+        }
+    };
+    // The operands of ALL of a wave's tiles of a block (at most E12_ROUNDS: the ring holds <= 80 KB = 568 pixels = 18 tiles) are
+    // requested together, so a block exposes one memory latency instead of one per tile.
+    float v[E12_ROUNDS][18];
+    auto l1_req_all = [&](int first_row, int nrows) {
+        const int npx = nrows * W1;
+#pragma unroll
+        for (int r = 0; r < E12_ROUNDS; ++r)
+            if ((w + 4 * r) * 32 < npx) l1_req(v[r], w + 4 * r, first_row, npx);
+    };
+    auto l1_phase = [&](int nrows, int slot0) {
+        const int npx = nrows * W1;
+#pragma unroll
+        for (int r = 0; r < E12_ROUNDS; ++r)
+            if ((w + 4 * r) * 32 < npx) l1_tile(v[r], w + 4 * r, npx, slot0);
+    };
+    // strip 0: conv1 rows 0 .. 2 TY -> ring slots 0 .. NR - 1
+    l1_req_all(0, NR);
+    l1_phase(NR, 0);
+    // this lane's output pixel of a strip
+    const int q = w * 32 + j;
+    const int yl = (int)__umulhi((unsigned)q, a.magicW2), x2 = q - yl * W2;
+    __syncthreads();
+
+    int rs0 = 0;                                       // ring slot of conv1 row 2 y0
+    for (int y0 = 0; y0 < H2; y0 += TY) {
+        const int nrows = min(TY, H2 - y0);
+        const bool more = y0 + TY < H2;
+        const bool busy = w * 32 < nrows * W2;          // wave-uniform
+        // the next strip's new conv1 rows 2 (y0 + TY) + 1 .. : their first tile is requested now, computed behind the barrier
+        const int nfirst = 2 * (y0 + TY) + 1, nnew = 2 * min(TY, H2 - y0 - TY);
+        if (more && E12_EARLY) l1_req_all(nfirst, nnew);
+        if (busy) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const bool pvx = q < nrows * W2;
+            auto base_of = [&](int t) -> int {          // LDS float4 index of tap t's operand for this lane's pixel
+                const int kh = t / 3, kw = t - 3 * kh;
+                int r = rs0 + 2 * (pvx ? yl : 0) + kh;
+                r = r >= NR ? r - NR : r;
+                r = r >= NR ? r - NR : r;
+                const int xx = pvx ? x2 : 0;
+                return (r * W1 + (kw == 1 ? WE + xx : xx + (kw >> 1))) * PS4;
+            };
+            f32x16 (&acc1)[1][1] = reinterpret_cast<f32x16 (&)[1][1]>(acc);
+            tap_loop_kc_pd<1, 1, 4, E12_PD>(acc1, 9, Wl, sx, h, [&](int t, int (&bs)[1], int (&sw)[1], int& wt) {
+                wt = t; bs[0] = base_of(t); sw[0] = 0;
+            }, PackedWIdx{1, 4, 0});
+            if (pvx) {
+                float* op = dst + ((size_t)(y0 + yl) * W2 + x2) * 32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 v;
+                    v.x = fmaxf(acc[4 * g] + bq2[g].x, 0.f); v.y = fmaxf(acc[4 * g + 1] + bq2[g].y, 0.f);
+                    v.z = fmaxf(acc[4 * g + 2] + bq2[g].z, 0.f); v.w = fmaxf(acc[4 * g + 3] + bq2[g].w, 0.f);
+                    *reinterpret_cast<float4*>(op + 8 * g) = v;
+                }
+            }
+        }
+        if (!more) break;
+        __syncthreads();                                   // every wave is done reading the rows that are replaced
+        if (!E12_EARLY) l1_req_all(nfirst, nnew);
+        l1_phase(nnew, rs0);                               // new row k -> slot (rs0 + 2 TY + 1 + k) mod NR = (rs0 + k) mod NR
+        rs0 += 2 * TY;                                      // row 2 (y0 + TY) = the kept row
+        rs0 = rs0 >= NR ? rs0 - NR : rs0;
+        __syncthreads();
+    }
+}
+
 static int conv_e_ty(const ConvEArgs& a) {
     int ty = 128 / a.Wout;
     if (ty > a.Hout) ty = a.Hout;
@@ -149,9 +306,11 @@ static int conv_e_ty(const ConvEArgs& a) {
 }
 static size_t conv_e_lds(const ConvEArgs& a, int L, int ty) { return (size_t)(2 * ty + 1) * a.Win * (L == 1 ? 1 : 9) * sizeof(float4); }
 constexpr size_t CONV_E_MAX_LDS = 96 * 1024;
+constexpr size_t CONV_E12_MAX_LDS = 80 * 1024;
 int init_generic_enc_kernels() {
     if (hipFuncSetAttribute((const void*)k_conv_e<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONV_E_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_conv_e<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONV_E_MAX_LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_conv_e12, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONV_E12_MAX_LDS) != hipSuccess) return 1;
     return 0;
 }
 // 0 = launched; 1 = this layer / geometry is outside the kernel's limits (the caller uses k_conv_g)
@@ -166,6 +325,22 @@ int launch_conv_e(ConvEArgs a, int layer, hipStream_t st) {
     a.magicWout = (unsigned)((0x100000000ull + (unsigned)a.Wout - 1) / (unsigned)a.Wout);
     if (layer == 1) hipLaunchKernelGGL((k_conv_e<1, 4>), dim3((unsigned)a.n_img), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((k_conv_e<2, 16>), dim3((unsigned)a.n_img), dim3(256), lds, st, a);
+    return 0;
+}
+
+// layers 1 + 2 fused.  0 = launched; 1 = outside the kernel's limits (the caller launches the layers one by one)
+int launch_conv_e12(ConvE12Args a, hipStream_t st) {
+    if (a.W2 < 2 || a.W2 > 128 || a.H2 < 1 || a.W1 > 255 || a.H1 < 2 * a.H2 + 1 || a.W1 < 2 * a.W2 + 1) return 1;
+    int ty = 128 / a.W2;
+    if (ty > a.H2) ty = a.H2;
+    // the conv1 ring of a strip: at most 80 KB, so that two workgroups share a CU
+    while (ty > 1 && (size_t)(2 * ty + 1) * a.W1 * 9 * sizeof(float4) > CONV_E12_MAX_LDS) --ty;
+    a.TY = ty;
+    const size_t lds = (size_t)(2 * ty + 1) * a.W1 * 9 * sizeof(float4);
+    if (lds > CONV_E12_MAX_LDS) return 1;
+    a.magicW1 = (unsigned)((0x100000000ull + (unsigned)a.W1 - 1) / (unsigned)a.W1);
+    a.magicW2 = (unsigned)((0x100000000ull + (unsigned)a.W2 - 1) / (unsigned)a.W2);
+    hipLaunchKernelGGL(k_conv_e12, dim3((unsigned)a.n_img), dim3(256), lds, st, a);
     return 0;
 }
 

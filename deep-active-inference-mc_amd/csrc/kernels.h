@@ -295,6 +295,17 @@ struct ConvEArgs {
     RowMask live;
 };
 int launch_conv_e(ConvEArgs a, int layer, hipStream_t st);     // non-zero: outside the kernel's limits (use k_conv_g)
+// the two layers in one kernel, conv1's output kept in LDS (generic_enc.hip: k_conv_e12)
+struct ConvE12Args {
+    const float* in;                    // NHWC4 image [n][H0 * W0][4]
+    float* out;                         // [n][H2 * W2][32]
+    const float* W1p; const float* b1;  // layer 1 as ConvEArgs::Wp / bias of layer 1
+    const float* W2p; const float* b2;  // layer 2 as ConvEArgs::Wp / bias of layer 2
+    int n_img, H0, W0, H1, W1, H2, W2;
+    int TY; unsigned magicW1, magicW2;          // set by launch_conv_e12
+    RowMask live;
+};
+int launch_conv_e12(ConvE12Args a, hipStream_t st);             // non-zero: outside the kernel's limits (launch the layers one by one)
 int init_generic_enc_kernels();
 int launch_dec_bg(DecBGArgs a, hipStream_t st);                 // non-zero: geometry outside the kernel's limits
 bool dec_bg_ok(int Hin, int Win, int C);                        // the fused kernel takes this geometry (decided before scratch is sized)

@@ -190,6 +190,15 @@ __device__ __forceinline__ void tap_loop_kc(f32x16 (&acc)[MT][NT], const int nta
     p.run(acc, ntaps, Wl, sm, h, addr, widx);
 }
 
+// chunk count and prefetch distance both explicit
+template <int MT, int NT, int KC, int PD, class AddrFn, class WIdx>
+__device__ __forceinline__ void tap_loop_kc_pd(f32x16 (&acc)[MT][NT], const int ntaps, const float4* __restrict__ Wl,
+                                               const float4* sm, const int h, AddrFn addr, WIdx widx) {
+    TapPipe<MT, NT, KC, PD> p;
+    p.begin(Wl, sm, h, addr, widx);
+    p.run(acc, ntaps, Wl, sm, h, addr, widx);
+}
+
 // packed weights [tap][mtiles][kcn chunks][64 lanes] with a tile offset
 struct PackedWIdx {
     int mtiles, kcn, mt0;

@@ -345,22 +345,25 @@ def test_reward_upstream_intent_generic(pair):
 
 @pytest.mark.parametrize('A2,C2,R2', [(3, 3, 84), (4, 1, 48), (3, 3, 64), (5, 2, 128), (2, 3, 36), (3, 3, 32)])
 def test_tiled_encoder_layers_equal_direct_kernel(A2, C2, R2):
-    """k_conv_e (LDS-tiled encoder layers 1 and 2, option enc_tiled = 1, the default) against k_conv_g on every layer: the same fp32
-    contraction per output element in the same tap / channel order -- bit-identical -- on every strip shape, 1..3 input channels, with a
-    row mask, and against the oracle (via the other tests of this file, which run the default)"""
+    """k_conv_e12 (encoder layers 1 + 2 in one kernel, conv1 kept in LDS: option enc_tiled = 2, the default) and k_conv_e (LDS-tiled, one
+    launch per layer: 1) against k_conv_g on every layer (0): the same fp32 contraction per output element in the same tap / channel order
+    -- bit-identical -- on every strip shape, 1..3 input channels, with a row mask, and against the oracle (via the other tests of this
+    file, which run the default)"""
     import daimc_amd
     w = synth.make_weights(93 + R2, 1.15, A2, C2, R2)
     m = daimc_amd.ActiveInferenceModel(10, A2, 0.0, 1.0, 1.0, colour_channels=C2, resolution=R2, device='cuda:0', seed=8, init_weights=False)
     m.load_flat_weights(w)
     M = 7
     fr = synth.make_frames_rgb(16, M, C2, R2)
-    s1, m1, l1 = m.model_down.encoder_with_sample(fr, stage=3, pass_=PX.PASS_E1)
-    m.set_option('enc_tiled', 0)
+    outs = {}
     try:
-        s0, m0_, l0 = m.model_down.encoder_with_sample(fr, stage=3, pass_=PX.PASS_E1)
+        for mode in (2, 1, 0):          # 2 = the default: layers 1 + 2 in one kernel (k_conv_e12), 1 = k_conv_e per layer, 0 = k_conv_g
+            m.set_option('enc_tiled', mode)
+            outs[mode] = m.model_down.encoder_with_sample(fr, stage=3, pass_=PX.PASS_E1)
     finally:
-        m.set_option('enc_tiled', 1)
-    assert torch.equal(m1, m0_) and torch.equal(l1, l0) and torch.equal(s1, s0)
+        m.set_option('enc_tiled', 2)
+    for mode in (1, 0):
+        assert all(torch.equal(x, y) for x, y in zip(outs[2], outs[mode])), mode
 
 
 @pytest.mark.parametrize('fuse', [1, 0])
