@@ -585,6 +585,9 @@ def bench_generic(a, device, rk, steps, warmup, with_cpu, min_total_s=2.0):
                 continue
             e = {'kernel': names[cname], 'ms': round(ms, 3), 'launches': int(n)}
             mc = macs.get(cname, 0)
+            if cname == 'dec_a_convT1_convT2' and 'convT1_generic' not in kern:
+                mc += macs['convT1_generic']                        # no ConvT1 launch of its own: k_convt_12 ran both layers (one class)
+                e['kernel'] = 'k_convt_12 (ConvT 64->64 s1 + ReLU + ConvT 64->64 s2 + ReLU, fused)'
             if cname == 'dec_b_convT3_final_reduce' and 'final_layer_generic' not in names:
                 mc += macs['final_layer_generic']                   # fused ConvT3 + final layer: one class
             if mc and ms > 0:

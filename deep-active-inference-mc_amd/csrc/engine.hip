@@ -86,6 +86,7 @@ struct efe_ctx {
     // fused path, 1.6 MB with the final layer unfused); poison / trace: development only
     int64_t arena_align = 256;
     int64_t reward_intent = 0;     // option "reward_upstream_intent": 1 = the reward target the upstream NHWC code means (kernels.h reward_term), 0 = the shipped port's
+    int64_t ct_fuse12 = 1;         // generic path, decoder ConvT layers 1 and 2: 1 = one kernel, layer 1's output kept in LDS (k_convt_12); 0 = one launch per layer
     int64_t enc_tiled = 2;         // generic path, encoder layers 1 and 2: 2 = one kernel, conv1 kept in LDS (k_conv_e12); 1 = LDS-tiled, one launch per layer
                                    // (k_conv_e); 0 = k_conv_g for every layer (A/B, parity of the fallbacks)
     int64_t dec_split = 1;         // dSprites path: decoder launches of <= 128 images run k_dec_b4 with four workgroups per image (0 = never: A/B)
@@ -335,10 +336,22 @@ int run_decoder_g(efe_ctx* ctx, const float* dec_in, int N, const NoiseCfg& nc, 
         cur_m0 = m0;
         ctx->cls = PROF_DEC_FC4;
         fc(ctx, ctx->g_fc4, hA + (size_t)m0 * 256, 256, 0, x4, B * B * 64, c, true, true, TAG_DEC + 3, nc, m0, st);
-        ctx->cls = PROF_CT1;
-        conv(ctx->g_ct[0], x4, y1, c, B, 64, B, 64, 1);
-        ctx->cls = PROF_CT2;
-        conv(ctx->g_ct[1], y1, y2, c, B, 64, H2, 64, 2);
+        int sep12 = 1;                                    // the first two transposed layers as one launch each
+        if (ctx->ct_fuse12) {                             // ... or as one kernel, layer 1's output kept in LDS (class PROF_CT2)
+            ctx->cls = PROF_CT2;
+            ConvT12Args f{};
+            f.in = x4; f.out = y2; f.W1p = ctx->g_ct[0].Wp; f.b1 = ctx->g_ct[0].bias; f.W2p = ctx->g_ct[1].Wp; f.b2 = ctx->g_ct[1].bias;
+            f.n_img = c; f.Hin = B; f.Win = B; f.live = live_of(nc, m0);
+            hipEvent_t e0 = ctx->prof_begin(st);
+            sep12 = launch_convt_12(f, st);
+            ctx->prof_end(sep12 ? nullptr : e0, st);
+        }
+        if (sep12) {
+            ctx->cls = PROF_CT1;
+            conv(ctx->g_ct[0], x4, y1, c, B, 64, B, 64, 1);
+            ctx->cls = PROF_CT2;
+            conv(ctx->g_ct[1], y1, y2, c, B, 64, H2, 64, 2);
+        }
         ctx->cls = PROF_CT3;
         if (fused) {        // ConvT(64,32,s2) + ReLU + ConvT(32,C,s1) + Sigmoid + per-image sums in one kernel: y3 never exists
             DecBGArgs f{};
@@ -778,6 +791,7 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     EFE_LOCK(ctx);
     if (!strcmp(name, "dec_chunk")) { if (value < 1) return ctx->fail("dec_chunk < 1"); ctx->dec_chunk = value; return 0; }
     if (!strcmp(name, "reward_upstream_intent")) { ctx->reward_intent = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "ct_fuse12")) { ctx->ct_fuse12 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "enc_tiled")) { ctx->enc_tiled = value < 0 ? 0 : value > 2 ? 2 : value; return 0; }
     if (!strcmp(name, "fuse_final_g")) { ctx->fuse_final_g = value ? 1 : 0; return 0; }
     if (!strcmp(name, "dec_split")) { ctx->dec_split = value ? 1 : 0; return 0; }

@@ -240,6 +240,249 @@ __global__ void __launch_bounds__(256, 3) k_convt_p(const ConvGArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_convt_12: ConvTranspose2d(64, 64, k3, s1, p1) + ReLU AND ConvTranspose2d(64, 64, k3, s2, p1, op1) + ReLU in one kernel
+// (/root/reference/src/torchmodel.py:120-123): the strips of k_convt_p<1> and k_convt_p<2>, interleaved, with layer 1's output kept
+// in a SECOND pixel ring in LDS instead of written to and fetched from HBM (y1: 113 KB per image at base 21).  Round i of an image:
+//     A(i)   = layer 1 for its rows i TH .. i TH + TH - 1 (the stride-1 pass of k_convt_p over the x ring), bias + ReLU written into
+//              half (i & 1) of the y1 ring (2 TH rows)
+//     barrier; the x rows of A(i + 1), requested during A(i), go into the x ring
+//     B(i-1) = layer 2 for the input rows (i - 1) TH .. i TH - 1 (the two stride-2 passes over the y1 ring; its halo row i TH is the first
+//              row A(i) just wrote), stored to y2
+//     barrier
+// i.e. two barriers per round and NS + 1 rounds per image, where the two kernels had two per strip each.  A row of y1 below the image
+// is never read: the views of B point at the zero region for it.  Every element sees the operations of the two launches in the same
+// order (bias as start value, taps and channel blocks in the order of the pass tables): bit-identical results.
+// ---------------------------------------------------------------------------------------------------------
+template <int NPF>
+__global__ void __launch_bounds__(256, 2) k_convt_12(const ConvT12Args a) {
+    __shared__ int cl_off[128];                      // per strip pixel: byte offset of its (first-parity) output pixel for r0 = 0
+    extern __shared__ float4 cl_x[];                 // [x ring RPa][y1 ring RYa][16 zero slots][1 dummy slot] x 17 float4
+    constexpr int KC = 8, C4 = 16, PS4 = 17, Cin = 64, MTL = 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int Win = a.Win, Hin = a.Hin, Wout = 2 * Win;
+    const int TH = 64 / Win;
+    const int NS = (Hin + TH - 1) / TH;
+    const int img = blockIdx.x;
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    const int SPX = TH * Win;                          // pixels of a strip
+    const int RP = (TH + 2) * Win, RPa = (RP + 15) & ~15;      // x ring: rows r0 - 1 .. r0 + TH
+    const int RY = 2 * SPX, YB = RPa, ZP = RPa + ((RY + 15) & ~15);
+    const int npix_img = Hin * Win;
+    const float* src = a.in + (size_t)img * npix_img * Cin;
+    const int c4 = tid & (C4 - 1), ppt = tid >> 4, pstep = 16;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, npix_img * Cin * 4, 0x00020000);
+    auto fetch = [&](int P, bool in_block) -> float4 {            // pixel P of the image: zeros above / below it
+        const bool ok = in_block && P >= 0 && P < npix_img;
+        const unsigned off = ok ? (unsigned)((P * Cin + 4 * c4) * 4) : 0x80000000u;
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+    };
+    // round 0's x rows -1 .. TH -> slots 0 .. RP - 1; the zero region
+    for (int pp0 = ppt; pp0 < RP; pp0 += 8 * pstep) {
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fetch(pp0 + i * pstep - Win, pp0 + i * pstep < RP);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (pp0 + i * pstep < RP) cl_x[(pp0 + i * pstep) * PS4 + c4] = v[i];
+    }
+    for (int i = tid; i < 16 * PS4; i += 256) cl_x[ZP * PS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 128) {
+        const int rw = tid / Win, xw = tid - rw * Win;
+        cl_off[tid] = rw < TH ? (2 * rw * Wout + 2 * xw) * 64 * 4 : 0x40000000;     // bytes; the sentinel is outside every image
+    }
+    const int nt = wave & 1, mt = wave >> 1;
+    // (the wave's feature tile is part of the resource base: every fragment offset below is a compile-time constant -- as scalar
+    // expressions of mt hipcc kept ~30 of them in SGPRs and spilled them to VGPR lanes)
+    const __amdgpu_buffer_rsrc_t wr1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W1p) + mt * (KC * 256), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2p) + mt * (KC * 256), 0, 0x7fffffff, 0x00020000);
+    const unsigned wl = (unsigned)lane * 16u;
+    // first weight fragments of the upcoming pass (see k_convt_p): table row 2 = the stride-1 pass (layer 1), rows 0 / 1 = the stride-2 passes (layer 2)
+    constexpr int ptp_[3][9] = {{4, 5, 3, 0, 0, 0, 0, 0, 0}, {7, 8, 6, 1, 2, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};
+    float4 fa[9], fb[3];
+    auto preload = [&](int P) {
+        const int n = P == 0 ? 3 : P == 1 ? 6 : 9;
+        const __amdgpu_buffer_rsrc_t wr = P == 2 ? wr1 : wr2;
+#pragma unroll
+        for (int m = 0; m < 9; ++m)
+            if (m < n) fa[m] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)((ptp_[P][m] * MTL * KC) * 64) * 16u, 0));
+        if (P == 0) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) fb[m] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)((ptp_[0][m] * MTL * KC + 1) * 64) * 16u, 0));
+        }
+    };
+    preload(2);
+    __syncthreads();
+
+    const int q = nt * 32 + j;
+    const bool qv = q < SPX;
+    const int qq = qv ? q : 0;
+    const int row = qq / Win, x = qq - row * Win;
+    const int co = mt * 32 + j;
+    const float bias1 = a.b1[co], bias2 = a.b2[co];
+    const int img_floats = 4 * npix_img * 64;
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)img * img_floats, 0, img_floats * 4, 0x00020000);
+    const int strip_floats = 2 * TH * Wout * 64;
+    float* const y1f = reinterpret_cast<float*>(cl_x);
+    const int ydummy = (ZP + 16) * (PS4 * 4) + lane;   // float index of this lane's dummy slot (one more pixel slot behind the zero region)
+
+    // one pass over this wave's tile: the contraction of k_convt_p (fragment / view schedule unchanged)
+    float4 pf[NPF];
+    int pp0 = 0;
+    int rA0 = 0; bool moreA = false;
+    auto request_next = [&]() {                        // the x rows rA0 + TH + 1 .. rA0 + 2 TH of round i + 1: one contiguous block of SPX pixels
+        const int P0 = (rA0 + TH + 1) * Win;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) pf[i] = fetch(P0 + pp0 + i * pstep, pp0 + i * pstep < SPX);
+    };
+    auto run_pass = [&](auto PC, const int (&vb)[9], auto epilogue) {
+        constexpr int P = decltype(PC)::value;
+        constexpr int NMP = P == 0 ? 3 : P == 1 ? 6 : 9, NVP = P == 0 ? 2 : P == 1 ? 4 : 9, NAC = P == 2 ? 1 : 2;
+        constexpr int pvw[3][9] = {{0, 0, 1, 0, 0, 0, 0, 0, 0}, {0, 0, 1, 2, 2, 3, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};
+        constexpr int ptp[3][9] = {{4, 5, 3, 0, 0, 0, 0, 0, 0}, {7, 8, 6, 1, 2, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};
+        constexpr int pac[3][9] = {{0, 1, 1, 0, 0, 0, 0, 0, 0}, {0, 1, 1, 0, 1, 1, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
+        constexpr int vlast[3][9] = {{1, 2, 0, 0, 0, 0, 0, 0, 0}, {1, 2, 4, 5, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5, 6, 7, 8}};
+        constexpr int AD = P == 0 ? 2 : 1;
+        const __amdgpu_buffer_rsrc_t wr = P == 2 ? wr1 : wr2;
+        const float bias = P == 2 ? bias1 : bias2;
+        f32x16 ac[NAC];
+#pragma unroll
+        for (int p = 0; p < NAC; ++p)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ac[p][e] = bias;
+        auto step = [&](float4 (&av)[NMP], float4 (&bv)[NVP], int kc) {
+#pragma unroll
+            for (int m = 0; m < NMP; ++m) {
+                const float4 b = bv[pvw[P][m]];
+                f32x16& c = ac[pac[P][m]];
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, av[m].x, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, av[m].y, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, av[m].z, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, av[m].w, c, 0, 0, 0);
+                if (kc + AD < KC) {
+                    const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(wr, wl, (unsigned)((ptp[P][m] * MTL * KC + kc + AD) * 64) * 16u, 0);
+                    av[m] = __builtin_bit_cast(float4, v);
+                }
+#pragma unroll
+                for (int v = 0; v < NVP; ++v)
+                    if (vlast[P][v] == m && kc + 1 < KC) bv[v] = cl_x[vb[v] + 2 * (kc + 1)];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        float4 a0[NMP], a1[AD == 2 ? NMP : 1], bv[NVP];
+#pragma unroll
+        for (int m = 0; m < NMP; ++m) a0[m] = fa[m];
+        if (AD == 2) {
+#pragma unroll
+            for (int m = 0; m < NMP; ++m) a1[m % (AD == 2 ? NMP : 1)] = fb[m % 3];
+        }
+#pragma unroll
+        for (int v = 0; v < NVP; ++v) bv[v] = cl_x[vb[v]];
+        for (int kc = 0; kc < KC; kc += 2) {
+            if (P == 2 && kc + 2 >= KC && moreA) request_next();      // behind the layer-1 pass's last fragment request
+            __builtin_amdgcn_sched_barrier(0);
+            step(a0, bv, kc);
+            if constexpr (AD == 2) step(a1, bv, kc + 1); else step(a0, bv, kc + 1);
+        }
+        epilogue(ac);
+    };
+
+    int bs = Win;                                      // x-ring slot of pixel (rA0, 0)
+    for (int i = 0; i <= NS; ++i) {
+        rA0 = i * TH;
+        const bool doA = i < NS, doB = i > 0;
+        moreA = i + 1 < NS;
+        pp0 = ppt; asm volatile("" : "+v"(pp0));       // (laundered per round: the prefetch offsets are loop invariants hipcc would keep in registers)
+        if (doA) {
+            const int nq = min(TH, Hin - rA0) * Win;
+            if (nt * 32 < nq) {
+                int vb[9];
+#pragma unroll
+                for (int v = 0; v < 9; ++v) {
+                    const int dy = 1 - v / 3, dx = 1 - v % 3;
+                    int nat = bs + q + dy * Win + dx;
+                    if (nat < 0) nat += RPa;
+                    if (nat >= RPa) nat -= RPa;
+                    const bool ok = qv && x + dx >= 0 && x + dx < Win;
+                    vb[v] = (ok ? nat : ZP + (nat & 15)) * PS4 + h;
+                }
+                const int ybase = (YB + (i & 1) * SPX) * (PS4 * 4) + co;          // float index of (this half's pixel 0, channel co)
+                run_pass(std::integral_constant<int, 2>{}, vb, [&](f32x16 (&ac)[1]) {
+                    preload(0);                              // layer 2's first fragments, ahead of the ring writes
+                    // C/D layout: column = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (pixel of the tile)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {            // (a pixel outside the strip goes to a dummy slot: an address select, not a branch per element)
+                        const int qa = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        y1f[qa < nq ? ybase + qa * (PS4 * 4) : ydummy] = fmaxf(ac[0][e], 0.0f);
+                    }
+                });
+            } else {
+                if (moreA) request_next();
+                preload(0);
+            }
+        } else {
+            preload(0);
+        }
+        __syncthreads();                                   // A(i)'s rows are in the y1 ring; nobody reads the x ring any more
+        if (moreA) {                                       // the x rows of A(i + 1) take the slots of the TH oldest rows
+            int nb = bs + (TH + 1) * Win;
+            if (nb >= RPa) nb -= RPa;
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const int pp = pp0 + k * pstep;
+                int sl = nb + pp;
+                if (sl >= RPa) sl -= RPa;
+                if (pp < SPX) cl_x[sl * PS4 + c4] = pf[k];
+            }
+        }
+        bs += SPX;
+        if (bs >= RPa) bs -= RPa;
+        if (doB) {
+            const int s = i - 1, rB0 = s * TH;
+            const int nq = min(TH, Hin - rB0) * Win;
+            if (nt * 32 < nq) {
+                int vb[9];
+                const int hb = (s & 1) * SPX;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int dy = v >> 1, dx = v & 1;
+                    int nat = hb + q + dy * Win + dx;
+                    if (nat >= RY) nat -= RY;
+                    const bool ok = qv && x + dx < Win && rB0 + row + dy < Hin;
+                    vb[v] = (ok ? YB + nat : ZP + (nat & 15)) * PS4 + h;
+                }
+#pragma unroll
+                for (int v = 4; v < 9; ++v) vb[v] = vb[0];
+                auto store = [&](auto PC, auto& ac) {
+                    constexpr int P = decltype(PC)::value;
+                    const unsigned sbase = (unsigned)(s * strip_floats + co) * 4u;
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int4 off = *reinterpret_cast<const int4*>(cl_off + nt * 32 + 8 * g4 + 4 * h);
+                        const unsigned offs[4] = {(unsigned)off.x, (unsigned)off.y, (unsigned)off.z, (unsigned)off.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned o = offs[k] + sbase;
+#pragma unroll
+                            for (int pw = 0; pw < 2; ++pw)
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(ac[pw][4 * g4 + k], 0.0f)), yr, o, (unsigned)((P * Wout + pw) * 64) * 4u, 0);
+                        }
+                    }
+                };
+                run_pass(std::integral_constant<int, 0>{}, vb, [&](f32x16 (&ac)[2]) { preload(1); store(std::integral_constant<int, 0>{}, ac); });
+                run_pass(std::integral_constant<int, 1>{}, vb, [&](f32x16 (&ac)[2]) { preload(2); store(std::integral_constant<int, 1>{}, ac); });
+            } else {
+                preload(2);
+            }
+        } else {
+            preload(2);
+        }
+        __syncthreads();                                   // B(i - 1) is done with the half A(i + 1) overwrites; the x ring is complete
+    }
+}
+
 static size_t convt_p_lds(const ConvGArgs& a) {
     const int ntw = 4 / a.mtiles, TH = (32 * ntw) / a.Win, padt = a.mode == 1 ? 1 : 0;
     const int RPa = ((TH + padt + 1) * a.Win + 15) & ~15;
@@ -269,6 +512,22 @@ void launch_convt_p(const ConvGArgs& a, hipStream_t st) {
         if (small) hipLaunchKernelGGL((k_convt_p<2, 4>), grid, blk, lds, st, a);
         else hipLaunchKernelGGL((k_convt_p<2, 8>), grid, blk, lds, st, a);
     }
+}
+
+// layers 1 + 2 fused (64 -> 64 -> 64 channels).  0 = launched; 1 = outside the kernel's limits (the caller launches the layers one by one)
+constexpr size_t CONVT_12_MAX_LDS = 80 * 1024;             // two workgroups per CU
+static size_t convt_12_lds(const ConvT12Args& a) {
+    const int TH = 64 / a.Win, SPX = TH * a.Win;
+    const int RPa = ((TH + 2) * a.Win + 15) & ~15, RYa = (2 * SPX + 15) & ~15;
+    return (size_t)(RPa + RYa + 16 + 1) * 17 * sizeof(float4);      // rings, zero region, one dummy slot
+}
+int launch_convt_12(const ConvT12Args& a, hipStream_t st) {
+    if (a.Win < 2 || a.Win > 64 || a.Hin < 1) return 1;
+    const int TH = 64 / a.Win, npf = (TH * a.Win * 16 + 255) / 256;
+    const size_t lds = convt_12_lds(a);
+    if (lds > CONVT_12_MAX_LDS || npf > 4) return 1;
+    hipLaunchKernelGGL((k_convt_12<4>), dim3((unsigned)a.n_img), dim3(256), lds, st, a);
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -744,6 +1003,7 @@ static size_t dec_bg_lds(int Win, int TH, int C) {
 }
 constexpr size_t DEC_BG_MAX_LDS = 96 * 1024;
 int init_generic_dec_kernels() {
+    if (hipFuncSetAttribute((const void*)k_convt_12<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONVT_12_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_dec_bg<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_BG_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_dec_bg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_BG_MAX_LDS) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void*)k_dec_bg<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC_BG_MAX_LDS) != hipSuccess) return 1;

@@ -272,6 +272,15 @@ struct ConvGArgs {
 void launch_conv_g(const ConvGArgs& a, hipStream_t st);
 bool convt_p_ok(const ConvGArgs& a);                            // generic_dec.hip: the LDS-tiled ConvTranspose kernel takes this layer
 void launch_convt_p(const ConvGArgs& a, hipStream_t st);
+// ConvT(64,64,s1) + ReLU + ConvT(64,64,s2) + ReLU in one kernel, layer 1's output kept in LDS (generic_dec.hip: k_convt_12)
+struct ConvT12Args {
+    const float* in; float* out;        // [n][Hin * Win][64] -> [n][4 Hin * Win][64], NHWC
+    const float* W1p; const float* b1;  // layer 1 as ConvGArgs::Wp / bias (packed [9][2][8][64][4])
+    const float* W2p; const float* b2;  // layer 2
+    int n_img, Hin, Win;
+    RowMask live;
+};
+int launch_convt_12(const ConvT12Args& a, hipStream_t st);      // non-zero: outside the kernel's limits (launch the layers one by one)
 // fused last two decoder layers of the generic path (generic_dec.hip): y2 [rows][Hin * Win][64] NHWC -> per-image sums (+ stored images)
 struct DecBGArgs {
     const float* y2;

@@ -632,7 +632,8 @@ class ActiveInferenceModel:
         e = self._ready()
         return e.ops.action_posterior(e.h, e.tensor(sum_G).reshape(-1), int(single_values), float(temperature))
 
-    # (generic geometry: the decoder's layers are separate launches -- convT1_generic, dec_a_... = ConvT2, dec_b_... = ConvT3, final_layer_generic)
+    # (generic geometry: convT1_generic + dec_a_... = ConvT1, ConvT2 as one launch each -- or, by default, only dec_a_... = both layers in k_convt_12;
+    #  dec_b_... = ConvT3 (+ the final layer when fused); final_layer_generic)
     PROF_CLASSES = ('transition_mlp', 'dec_dense_small', 'dec_dense_16384', 'convT1_generic', 'dec_a_convT1_convT2',
                     'dec_b_convT3_final_reduce', 'final_layer_generic', 'encoder', 'other')
 
@@ -640,7 +641,7 @@ class ActiveInferenceModel:
         """PROF_CLASSES name -> kernel description for the launches of the generic-geometry path (bench.py per-class table)"""
         names = {'dec_dense_16384': 'k_fc4 (Linear 256 -> 64 base^2)', 'convT1_generic': 'k_convt_p<1> (ConvT 64->64 s1)',
                  'dec_a_convT1_convT2': 'k_convt_p<2> (ConvT 64->64 s2)', 'dec_b_convT3_final_reduce': 'k_convt_p<2> (ConvT 64->32 s2)',
-                 'final_layer_generic': 'k_final_g (ConvT 32->C + sigmoid + reductions)', 'encoder': 'encoder (k_conv_e layers 1-2, k_conv_g layers 3-4, dense head)',
+                 'final_layer_generic': 'k_final_g (ConvT 32->C + sigmoid + reductions)', 'encoder': 'encoder (k_conv_e12 layers 1-2, k_conv_g layers 3-4, dense head)',
                  'transition_mlp': 'k_trans_fused', 'dec_dense_small': 'k_head (decoder head 10 -> 256 -> 256 -> 256, one launch)'}
         if getattr(self, '_opts', {}).get('fuse_final_g', 1) and self.resolution != 32:
             names['dec_b_convT3_final_reduce'] = 'k_dec_bg (ConvT 64->32 s2 + ReLU + ConvT 32->C + sigmoid + per-image sums, fused)'

@@ -319,6 +319,37 @@ def test_fused_last_layers_equal_separate_launches(A2, C2, R2):
     np.testing.assert_allclose(c(Tf[1]), c(Tu[1]), atol=1e-4)       # term1 reads the encoder's view of the stored images (a few ulp apart)
 
 
+@pytest.mark.parametrize('A2,C2,R2', [(3, 3, 84), (4, 1, 48), (3, 3, 64), (5, 2, 128), (2, 3, 36), (3, 3, 32)])
+def test_fused_first_transposed_layers_are_bit_identical(A2, C2, R2):
+    """k_convt_12 (ConvT1 + ReLU + ConvT2 + ReLU in one kernel, layer 1's output kept in an LDS ring: option ct_fuse12 = 1, the default)
+    against one launch per layer (k_convt_p<1>, k_convt_p<2> through y1 in HBM): the same MFMA sequence per element -- identical bits of
+    every output of calculate_G, stored images included -- on every strip shape (base 21, 12, 16, 32 (outside the fused kernel's LDS
+    limit: both runs take the separate launches), 9, 8), with a row mask"""
+    import daimc_amd
+    w = synth.make_weights(95 + R2, 1.15, A2, C2, R2)
+    m = daimc_amd.ActiveInferenceModel(10, A2, 0.0, 1.0, 1.0, colour_channels=C2, resolution=R2, device='cuda:0', seed=6, init_weights=False)
+    m.load_flat_weights(w)
+    m.eps_source, m.u_source = PX.normals, PX.uniforms
+    M, st = 7, 4
+    s0 = PX.uniform_fill(4, (M, 10), 63, -1.2, 1.2)
+    pi0 = np.eye(A2, dtype=np.float32)[np.arange(M) % A2]
+    from daimc_amd.model import Rows
+    mask = torch.tensor([1, 1, 0, 1, 1, 1, 0], dtype=torch.uint8, device=m.device)
+    outs = {}
+    try:
+        for mode in (1, 0):
+            m.set_option('ct_fuse12', mode)
+            full = m.calculate_G(s0, pi0, samples=2, stage=st)
+            part = m.calculate_G(s0, pi0, samples=2, stage=st, rows=Rows(mask=mask))
+            outs[mode] = [full[0], *full[1], full[4], part[0]]
+    finally:
+        m.set_option('ct_fuse12', 1)
+    live = mask.bool()
+    for x, y in zip(outs[1][:-1], outs[0][:-1]):
+        assert torch.equal(x, y)
+    assert torch.equal(outs[1][-1][live], outs[0][-1][live]) and torch.equal(outs[1][-1][live], outs[1][0][live])
+
+
 def test_reward_upstream_intent_generic(pair):
     """the upstream-intent reward target (option reward_upstream_intent) on the generic geometry: rows 0..2, left half = 1,
     summed over channels -- against oracle.efe_oracle.check_reward_upstream_intent, through check_reward and through calculate_G"""

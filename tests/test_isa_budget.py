@@ -33,7 +33,7 @@ BUDGET = {
     'k_dec_b4<1>': 256, 'k_dec_b4<4>': 256, 'k_dec_a': 256, 'k_dec_a_s': 256, 'k_fc4<1>': 256, 'k_fc4<2>': 256,                            # 2 workgroups x 4 waves per CU
     'k_dec_bg<1>': 256, 'k_dec_bg<2>': 256, 'k_dec_bg<3>': 256,
     'k_enc_trunk': 168,                                                         # 3 workgroups per CU
-    'k_convt_p<1, 4>': 168, 'k_convt_p<1, 8>': 168, 'k_convt_p<2, 4>': 168, 'k_convt_p<2, 8>': 168,
+    'k_convt_p<1, 4>': 168, 'k_convt_p<1, 8>': 168, 'k_convt_p<2, 4>': 168, 'k_convt_p<2, 8>': 168, 'k_convt_12<4>': 256,
     'k_conv_e<1, 4>': 168, 'k_conv_e<2, 16>': 168, 'k_conv_e12': 256,
     'k_trans_fused': 256, 'k_head<16>': 256, 'k_head<32>': 256,
     'k_fc4_b3': 256, 'k_dec_a_b3<1>': 256,                                      # the opt-in bf16 x 3 experiment: one 8-wave workgroup per CU = 2 waves per SIMD
@@ -52,7 +52,7 @@ def test_hot_kernel_fits_its_occupancy_target(kernels, name):
 SSPILL = {
     'k_dec_bg<1>': 0, 'k_dec_bg<2>': 0, 'k_dec_bg<3>': 0,
     'k_dec_b4<1>': 2, 'k_dec_b4<4>': 4, 'k_dec_a': 0, 'k_dec_a_s': 0, 'k_fc4<1>': 0, 'k_fc4<2>': 0, 'k_trans_fused': 0,
-    'k_convt_p<1, 4>': 0, 'k_convt_p<1, 8>': 0, 'k_convt_p<2, 4>': 0, 'k_convt_p<2, 8>': 5,
+    'k_convt_p<1, 4>': 0, 'k_convt_p<1, 8>': 0, 'k_convt_p<2, 4>': 0, 'k_convt_p<2, 8>': 5, 'k_convt_12<4>': 0,
     'k_conv_e<1, 4>': 0, 'k_conv_e<2, 16>': 0, 'k_conv_e12': 0,
     'k_enc_trunk': 26, 'k_head<16>': 25, 'k_head<32>': 22,      # (+4 / +10 with the row-identity pointer of ABI 4 among the kernel arguments)
     'k_final_g': 47,            # fallback of the generic decoder tail (option fuse_final_g = 0 / the resolution-32 variant)
