@@ -71,8 +71,10 @@ int efe_commit_weights(efe_ctx* ctx);
  *                   1 for image rows h < H/2, every pixel counts; pinned by the oracle).  1 = what the upstream NHWC code means:
  *                   only the top three rows count, target 1 on their left half; dSprites: mean over those 192 pixels * 10, other geometries: sum.
  *   A / B         : "fuse_final_g" (generic path: last two decoder layers in one kernel, default 1), "sim_split" (efe_simulate of <= 16 episodes: the habit-policy chain on eight workgroups per 8 episodes that split
- *                   the two wide transition layers, default 1, bit-identical to 0), "enc_tiled" (generic path: LDS-tiled encoder
- *                   layers 1 and 2, default 1, bit-identical to 0), "mid_unfused" (layer-by-layer transition MLP), "head_unfused" (the decoder / encoder dense heads as
+ *                   the two wide transition layers, default 1, bit-identical to 0), "enc_tiled" (generic path, encoder layers 1 and 2: 2 = one
+ *                   kernel with conv1 kept in LDS (default), 1 = LDS-tiled, one launch per layer, 0 = the direct kernel for every layer; bit-identical),
+ *                   "ct_fuse12" (generic path: the decoder's first two ConvTranspose layers in one kernel, layer 1's output kept in LDS, default 1,
+ *                   bit-identical to 0), "mid_unfused" (layer-by-layer transition MLP), "head_unfused" (the decoder / encoder dense heads as
  *                   one k_dense launch per layer instead of one k_head launch per head; same masks, fp32 summation order differs).  None of them removes work:
  *                   every setting computes the same quantities (fp32 summation order may differ where stated).
  *   experiment    : "mfma_bf16x3" (0 / 1, default 0; Dynamic-dSprites geometry only).  1 = the decoder's Linear(256, 16384) and its first two

@@ -22,6 +22,7 @@ PEAK_TF = 157.3          # fp32 MFMA, MI355X_MICROARCH.md
 # algorithmic MACs per decoder image / row: dSprites kernels, and the generic path at BASELINE configs[4] (3 x 84 x 84)
 MACS = {'k_dec_b4<1>': 20054016, 'k_dec_b4<4>': 20054016, 'k_dec_a': 18874368, 'k_dec_a_s': 18874368, 'k_fc4<2>': 4194304, 'k_fc4<1>': 4194304}
 MACS_G84 = {'k_dec_bg<3>': 21 * 21 * 4 * 9 * 64 * 32 + 84 * 84 * 9 * 32 * 3, 'k_convt_p<1, 4>': 21 * 21 * 9 * 64 * 64, 'k_convt_p<2, 4>': 21 * 21 * 9 * 64 * 64,
+            'k_convt_12<4>': 2 * 21 * 21 * 9 * 64 * 64,
             'k_fc4<2>': 256 * 64 * 21 * 21}
 
 
