@@ -323,8 +323,8 @@ def test_fused_last_layers_equal_separate_launches(A2, C2, R2):
 def test_fused_first_transposed_layers_are_bit_identical(A2, C2, R2):
     """k_convt_12 (ConvT1 + ReLU + ConvT2 + ReLU in one kernel, layer 1's output kept in an LDS ring: option ct_fuse12 = 1, the default)
     against one launch per layer (k_convt_p<1>, k_convt_p<2> through y1 in HBM): the same MFMA sequence per element -- identical bits of
-    every output of calculate_G, stored images included -- on every strip shape (base 21, 12, 16, 32 (outside the fused kernel's LDS
-    limit: both runs take the separate launches), 9, 8), with a row mask"""
+    every output of calculate_G, stored images included -- on every strip shape (base 21, 12, 16, 32, 9, 8: strips of 3, 5, 4, 2, 7, 8
+    rows), with a row mask"""
     import daimc_amd
     w = synth.make_weights(95 + R2, 1.15, A2, C2, R2)
     m = daimc_amd.ActiveInferenceModel(10, A2, 0.0, 1.0, 1.0, colour_channels=C2, resolution=R2, device='cuda:0', seed=6, init_weights=False)
