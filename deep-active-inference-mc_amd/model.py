@@ -408,8 +408,9 @@ class ActiveInferenceModel:
 
     def set_option(self, name, value):
         """efe_set_option: launch-group sizes (dec_chunk, enc_chunk, dec_chunk_g, dec_budget_g), reward_upstream_intent (0 / 1: the reward
-        target the upstream NHWC code means instead of the shipped port's NCHW broadcast), fuse_final_g (generic path:
-        last two decoder layers in one kernel, default 1), poison / trace / arena_align (development)"""
+        target the upstream NHWC code means instead of the shipped port's NCHW broadcast), A/B switches that leave the
+        results unchanged (generic path: fuse_final_g, ct_fuse12, enc_tiled; sim_split, mid_unfused, head_unfused), the mfma_bf16x3
+        experiment, poison / trace / arena_align / check_rows (development) -- the list with defaults: include/efe_engine.h"""
         e = self._engine
         e.check(e.lib.efe_set_option(e.ctx, name.encode(), int(value)))
         self._opts = dict(getattr(self, '_opts', {}), **{name: int(value)})
