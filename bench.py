@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 MAC_TRANS, MAC_DEC, MAC_ENC, MAC_HABIT = 541_696, 43_256_320, 3_868_960, 18_176      # per network row
 MAC_ROLLOUT = 6_739_934_560          # 51 encoder + 100 transition + 150 decoder passes
 MAC_DECB_ROW = 18_874_368 + 1_179_648   # k_dec_b: ConvTranspose2d(64,32,3,s2) 32*32*9*64*32 + ConvTranspose2d(32,1,3,s1) 64*64*9*32
+ALG_BYTES_DECB_IMAGE = 262144 + 4 + 16384 / 3   # k_dec_b per image: y2 read, one sum written, every third image (the D1 pass) stored
 PEAK_FP32_MFMA_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, fp32 in / fp32 acc
 DOM = 'dec_b_convT3_final_reduce'
 
@@ -172,10 +173,14 @@ def natural_key(path):
     return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.basename(path))]
 
 
-def committed_traffic(kernel='k_dec_b'):
-    """HBM bytes per image of the dominant kernel from the newest committed PMC profile (profiles/rN_vM_rocprof_summary.txt,
-    newest = highest (round, version) in natural order).  -> (bytes_per_image, file name) or (None, None)"""
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_v*_rocprof_summary.txt')), key=natural_key)
+def committed_traffic(kernel='k_dec_b', geometry='dsprites'):
+    """HBM bytes per image of the dominant kernel from the newest committed PMC profile OF THE SAME GEOMETRY: the dSprites headline
+    reads profiles/rN_vM_rocprof_summary.txt, the 3 x 84 x 84 leg profiles/rN_vM_ai_rocprof_summary.txt (both files key their
+    dominant kernel 'k_dec_b'; the experiment profiles rN_vM_b3_* are never used).  Newest = highest (round, version) in natural
+    order.  -> (bytes_per_image, file name) or (None, None)"""
+    pat = {'dsprites': r'^r\d+_v\d+_rocprof_summary\.txt$', 'animalai': r'^r\d+_v\d+_ai_rocprof_summary\.txt$'}[geometry]
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_rocprof_summary.txt')) if re.match(pat, os.path.basename(f))),
+                   key=natural_key)
     for best in reversed(files):
         m_ = re.search(r'== HBM traffic \(JSON\) ==\n(\{.*\})', open(best).read())
         if not m_:
@@ -334,7 +339,9 @@ class Ranks:
     def info(self):
         if not self.on:
             return {}
-        return {'rccl_ranks': int(self.dist.get_world_size()), 'backend': str(self.dist.get_backend())}
+        # (rccl_ranks only when the group really is RCCL: the one-device launcher rehearsal runs over gloo and says so)
+        n, be = int(self.dist.get_world_size()), str(self.dist.get_backend())
+        return {'rccl_ranks' if be == 'nccl' else 'ranks': n, 'backend': be}
 
     def check_devices(self, model, local, share_device):
         """rank r really runs on GPU r: the engine context's own device (efe_get_device) is the local rank's, and no two ranks of the job hold
@@ -602,6 +609,14 @@ def bench_generic(a, device, rk, steps, warmup, with_cpu, min_total_s=2.0):
                            'frac': dom.get('frac_of_fp32_mfma_peak', 0.0), 'traffic': None, 'launches': dom['launches'],
                            'avg_launch_ms': dom['ms'] / max(dom['launches'], 1), 'whole_step_frac': tf / world / PEAK_FP32_MFMA_TF}
     out['roofline'].update(clk.report(out['roofline']['frac']))
+    if 'launches' in out['roofline'] and (C, R) == (3, 84):
+        bpi, src = committed_traffic('k_dec_b', 'animalai')       # the 3 x 84 x 84 profile (tools/gpu_profile.sh <tag> --workload animalai)
+        if bpi is not None:
+            n_l = max(out['roofline']['launches'], 1)
+            out['roofline']['traffic'] = bpi * imgs / n_l
+            out['roofline']['traffic_unit'] = 'bytes per launch'
+            out['roofline']['traffic_from_profile'] = {'bytes_per_image': bpi, 'images_per_launch': imgs / n_l, 'file': 'profiles/' + src,
+                                                       'how': 'rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE in separate passes, per image x images per launch'}
     if with_cpu and rank_of(rk) == 0:
         out['cpu_baseline'] = cpu_baseline_generic(A, C, R, D, S)
         out['speedup_vs_cpu_baseline'] = value / out['cpu_baseline']['value']
@@ -783,10 +798,16 @@ def main():
                                'flops_per_launch': 2 * MAC_DECB_ROW * rows_per_launch,
                                'timing': 'HIP events on the launch stream around the kernel, 10 un-timed steps after the timed regions'}
             out['roofline'].update(clk.report(ach / PEAK_FP32_MFMA_TF))
-            bpi, src = committed_traffic('k_dec_b')
-            if bpi is not None:          # not measured in this run: PMC counters need rocprofv3 around the process
-                out['roofline']['traffic_from_profile'] = {'bytes_per_launch': bpi * rows_per_launch, 'file': 'profiles/' + src,
-                                                           'how': 'rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, per image x images per launch'}
+            # traffic = HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE in their own rocprofv3 passes, corrected as
+            # MI355X_MICROARCH.md prescribes).  Counters need rocprofv3 around the process, so the figure is the one of the newest COMMITTED
+            # profile of the same kernel and geometry (tools/gpu_profile.sh + tools/prof_summary.py), per image x the images of this launch
+            bpi, src = committed_traffic('k_dec_b', 'dsprites')
+            if bpi is not None:
+                out['roofline']['traffic'] = bpi * rows_per_launch
+                out['roofline']['traffic_unit'] = 'bytes per launch'
+                out['roofline']['traffic_over_algorithmic'] = bpi / ALG_BYTES_DECB_IMAGE
+                out['roofline']['traffic_from_profile'] = {'bytes_per_image': bpi, 'images_per_launch': rows_per_launch, 'file': 'profiles/' + src,
+                                                           'how': 'rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE in separate passes, per image x images per launch'}
             tot = sum(v[0] for v in breakdown.values())
             macs = class_macs_per_step(R, D, S)
             kern = {}

@@ -11,9 +11,9 @@ EXPORTS = ['efe_create', 'efe_destroy', 'efe_last_error', 'efe_abi_version', 'ef
            'efe_rollout', 'efe_trajectory', 'efe_simulate', 'efe_action_posterior', 'efe_last_call_macs',
            'efe_prof_enable', 'efe_prof_classes', 'efe_prof_read', 'efe_env_reset', 'efe_env_step', 'efe_env_render',
            'efe_check_reward', 'efe_reparameterize', 'efe_mcts_select', 'efe_mcts_expand', 'efe_mcts_backprop', 'efe_mcts_stop',
-           'efe_build_id', 'efe_reserve', 'efe_rollout_scratch_bytes', 'efe_arena_stats', 'efe_env_new_image', 'efe_create_cfg', 'efe_get_config', 'efe_get_device', 'efe_set_row_mask',
+           'efe_build_id', 'efe_reserve', 'efe_rollout_scratch_bytes', 'efe_arena_stats', 'efe_env_new_image', 'efe_create_cfg', 'efe_get_config', 'efe_get_device', 'efe_ctx_alive',
            'efe_calculate_g_rows', 'efe_simulate_rows', 'efe_mcts_step']
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class EfeMctsTree(C.Structure):
@@ -99,7 +99,7 @@ def load():
     lib.efe_trajectory.argtypes = [p, f32p, f32p, f32p, f32p, f32p, i, nzp, f32p, f32p, p]; lib.efe_trajectory.restype = i
     lib.efe_simulate.argtypes = [p, f32p, i, i, i, nzp, f32p, f32p, f32p, f32p, f32p, p]; lib.efe_simulate.restype = i
     lib.efe_reserve.argtypes = [p, C.c_int64]; lib.efe_reserve.restype = i
-    lib.efe_set_row_mask.argtypes = [p, p, i]; lib.efe_set_row_mask.restype = i
+    lib.efe_ctx_alive.argtypes = [p]; lib.efe_ctx_alive.restype = i
     lib.efe_rollout_scratch_bytes.argtypes = [p, i, i, i]; lib.efe_rollout_scratch_bytes.restype = C.c_int64
     lib.efe_arena_stats.argtypes = [p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.efe_arena_stats.restype = i
     lib.efe_env_new_image.argtypes = [p, f32p, i, nzp, p]; lib.efe_env_new_image.restype = i

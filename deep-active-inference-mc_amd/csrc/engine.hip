@@ -10,6 +10,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 #include "../../include/efe_engine.h"
 #include "kernels.h"
@@ -94,11 +95,11 @@ struct efe_ctx {
     int64_t mfma_bf16x3 = 0;       // OPT-IN EXPERIMENT (bf16x3.hip): Linear(256, 16384) of the decoder on the bf16 pipe, operands split in three bf16 planes
     uint16_t* fc4_b3 = nullptr;    // its packed planes (part of wbufs)
     uint16_t* ct_b3[2] = {nullptr, nullptr};      // po_net.13 / .15 (k_dec_a's layers) as bf16 planes
+    bool arch_gfx950 = false;      // hipDeviceProp_t.gcnArchName starts with gfx950 (checked at creation)
     int64_t sim_split = 1;         // simulations of <= 16 episodes: the chain kernel on eight workgroups per 8 episodes (k_sim_chain<8>); 0 = one workgroup (A/B, bit-identical)
-    float* sim_xch = nullptr; int* sim_sync = nullptr;      // its exchange buffer and self-resetting counters (owned)
+    float* sim_xch = nullptr; int* sim_sync = nullptr;      // its exchange buffer and arrival counters / sticky timeout flag (owned; zeroed on the stream before every split launch)
     int64_t check_rows = 0;        // development: range-check efe_rows.ids on the host before every _rows call
     int64_t last_macs = 0;
-    const uint8_t* row_mask = nullptr; int row_mask_div = 1;      // efe_set_row_mask
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline)
     unsigned prof = 0;        // bitmask of ProfClass values to time
     int cls = PROF_OTHER;
@@ -222,7 +223,7 @@ struct NoiseCfg {
     GroupMap gm{1, 1, {0, 0, 0}, 0, 0};
     int rows_per_group = 1;
     uint32_t row_offset = 0;
-    const uint8_t* mask = nullptr;      // liveness of the logical rows (efe_set_row_mask), entry = row / mask_div
+    const uint8_t* mask = nullptr;      // liveness of the logical rows (efe_rows.mask), entry = row / mask_div
     int mask_div = 1;
 };
 inline RowMask live_of(const NoiseCfg& nc, int m0) { return RowMask{nc.mask, nc.mask_div, m0, nc.rows_per_group, nc.mask ? nc.gm.ids : nullptr}; }
@@ -679,7 +680,33 @@ int finish(efe_ctx* ctx) {          // calls that use no engine scratch (environ
     return 0;
 }
 
-#define EFE_LOCK(ctx) std::lock_guard<std::mutex> lock_((ctx)->mu)
+// Registry of live contexts: efe_create_cfg adds, efe_destroy removes.  Every entry point checks its handle against it before touching
+// the object (EFE_LOCK), so a stale or made-up efe_ctx* is an error return, not a dereference of freed memory (efe_ctx_alive exports the
+// test for bindings that carry the handle as an integer: csrc/torch_ops.cpp).
+std::mutex g_live_mu;
+std::unordered_set<const efe_ctx*> g_live;
+inline bool ctx_alive(const efe_ctx* c) {
+    if (!c) return false;
+    std::lock_guard<std::mutex> l(g_live_mu);
+    return g_live.count(c) != 0;
+}
+// An entry point makes the context's device current (hipSetDevice) for its launches / allocations and puts the CALLER's device back on
+// every exit: in a process that drives several GPUs a call on a context of GPU 1 must not leave the thread on GPU 1.
+struct DeviceScope {
+    int prev = -1;
+    explicit DeviceScope(int dev) { int cur = -1; if (hipGetDevice(&cur) == hipSuccess && cur != dev) prev = cur; }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+// frees everything a context owns (device of the context current); also the failure paths of efe_create_cfg
+void release_ctx(efe_ctx* ctx) {
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->done_ev) (void)hipEventDestroy(ctx->done_ev);
+    for (void* p : ctx->owned) (void)hipFree(p);
+    for (void* p : ctx->wbufs) (void)hipFree(p);
+    for (auto& b : ctx->arena.blocks) (void)hipFree(b.first);
+    delete ctx;
+}
+#define EFE_LOCK(ctx) if (!ctx_alive(ctx)) return 1; std::lock_guard<std::mutex> lock_((ctx)->mu); DeviceScope dev_scope_((ctx)->device)
 
 }  // namespace
 
@@ -688,7 +715,9 @@ int finish(efe_ctx* ctx) {          // calls that use no engine scratch (environ
 // =====================================================================================================
 extern "C" {
 
-int efe_abi_version(void) { return 5; }
+int efe_abi_version(void) { return 6; }
+
+int efe_ctx_alive(const efe_ctx* ctx) { return ctx_alive(ctx) ? 1 : 0; }
 
 // efe_build_id(): the digest of the sources this library was compiled from -- a generated translation unit (build.py writes it at
 // link time, so an edit of one kernel file recompiles that file only)
@@ -702,12 +731,18 @@ int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channel
     if (s_dim != 10 || pi_dim < 2 || pi_dim > 6 || channels < 1 || channels > 3 || resolution < 32 || resolution > 128 || resolution % 4) return 7;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return 2;
+    DeviceScope dev_scope_(device);                 // the caller's current device is restored on every exit
     if (hipSetDevice(device) != hipSuccess) return 3;
     if (init_small_kernels() || init_decoder_kernels() || init_fused_kernels() || init_generic_kernels() || init_bf16x3_kernels()) return 5;       // per device: a second context on another GPU needs them too
     efe_ctx* ctx = new efe_ctx();
     ctx->device = device;
     ctx->pi_dim = pi_dim; ctx->chan = channels; ctx->res = resolution;
     ctx->generic = !(channels == 1 && resolution == 64);
+    {   // the split simulation chain's cross-workgroup exchange (fused.hip: sc1 accesses, no fences) is validated on gfx950 only
+        hipDeviceProp_t prop;
+        ctx->arch_gfx950 = hipGetDeviceProperties(&prop, device) == hipSuccess && !strncmp(prop.gcnArchName, "gfx950", 6);
+        if (!ctx->arch_gfx950) ctx->sim_split = 0;
+    }
     ctx->last_s1 = resolution == 32;
     ctx->base = ctx->last_s1 ? resolution / 2 : resolution / 4;
     ctx->enc_hw[0] = resolution;
@@ -727,32 +762,37 @@ int efe_create_cfg(efe_ctx** out, int device, int s_dim, int pi_dim, int channel
     // rows beyond the batch read their K operand values from this block (k_dense / k_conv_g): it must cover the longest contraction,
     // the encoder head's 64 * h4 * h4 inputs (3136 floats at resolution 128 -- an 8 KiB block was read past its end there)
     const size_t zeros_bytes = std::max<size_t>(8192, ((size_t)ctx->enc_hw[4] * ctx->enc_hw[4] * 64 + 64) * sizeof(float));
-    if (hipMalloc((void**)&ctx->zeros, zeros_bytes) != hipSuccess || hipMemset(ctx->zeros, 0, zeros_bytes) != hipSuccess) { delete ctx; return 4; }
+    // (every buffer enters ctx->owned right behind its hipMalloc and every failure path below releases through release_ctx(): nothing leaks)
+    if (hipMalloc((void**)&ctx->zeros, zeros_bytes) != hipSuccess) { release_ctx(ctx); return 4; }
     ctx->owned.push_back(ctx->zeros);
-    if (hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming) != hipSuccess) { (void)hipFree(ctx->zeros); delete ctx; return 6; }
-    {   // exchange buffer + counters of the split simulation chain (fused.hip k_sim_chain<8>): counters start at zero and re-arm themselves
+    if (hipMemset(ctx->zeros, 0, zeros_bytes) != hipSuccess) { release_ctx(ctx); return 4; }
+    if (hipEventCreateWithFlags(&ctx->done_ev, hipEventDisableTiming) != hipSuccess) { ctx->done_ev = nullptr; release_ctx(ctx); return 6; }
+    {   // exchange buffer + counters of the split simulation chain (fused.hip k_sim_chain<8>)
         const size_t xb = (size_t)SIM_MAX_SPLIT_GROUPS * 2 * 16 * 512 * sizeof(float), sb = (size_t)SIM_MAX_SPLIT_GROUPS * 4 * sizeof(int);
-        if (hipMalloc((void**)&ctx->sim_xch, xb) != hipSuccess || hipMalloc((void**)&ctx->sim_sync, sb) != hipSuccess || hipMemset(ctx->sim_sync, 0, sb) != hipSuccess) { delete ctx; return 4; }
-        ctx->owned.push_back(ctx->sim_xch); ctx->owned.push_back(ctx->sim_sync);
+        if (hipMalloc((void**)&ctx->sim_xch, xb) != hipSuccess) { release_ctx(ctx); return 4; }
+        ctx->owned.push_back(ctx->sim_xch);
+        if (hipMalloc((void**)&ctx->sim_sync, sb) != hipSuccess) { release_ctx(ctx); return 4; }
+        ctx->owned.push_back(ctx->sim_sync);
+        if (hipMemset(ctx->sim_sync, 0, sb) != hipSuccess) { release_ctx(ctx); return 4; }
     }
+    { std::lock_guard<std::mutex> l(g_live_mu); g_live.insert(ctx); }
     *out = ctx;
     return 0;
 }
 
 void efe_destroy(efe_ctx* ctx) {
-    if (!ctx) return;
+    {   // leaves the registry first: a second efe_destroy of the same handle, or any later call with it, is refused instead of touching freed memory
+        std::lock_guard<std::mutex> l(g_live_mu);
+        if (!ctx || !g_live.erase(ctx)) return;
+    }
+    DeviceScope dev_scope_(ctx->device);
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    if (ctx->done_ev) (void)hipEventDestroy(ctx->done_ev);
-    for (void* p : ctx->owned) (void)hipFree(p);
-    for (void* p : ctx->wbufs) (void)hipFree(p);
-    for (auto& b : ctx->arena.blocks) (void)hipFree(b.first);
-    delete ctx;
+    release_ctx(ctx);
 }
 
 int efe_get_config(efe_ctx* ctx, int* s_dim, int* pi_dim, int* channels, int* resolution) {
-    if (!ctx) return 1;
+    if (!ctx_alive(ctx)) return 1;
     if (s_dim) *s_dim = S_DIM;
     if (pi_dim) *pi_dim = ctx->pi_dim;
     if (channels) *channels = ctx->chan;
@@ -761,7 +801,7 @@ int efe_get_config(efe_ctx* ctx, int* s_dim, int* pi_dim, int* channels, int* re
 }
 
 int efe_get_device(efe_ctx* ctx, int* device, char* pci_bus_id, int pci_bus_id_len) {
-    if (!ctx) return 1;
+    if (!ctx_alive(ctx)) return 1;
     if (device) *device = ctx->device;
     if (pci_bus_id && pci_bus_id_len > 0) {
         pci_bus_id[0] = 0;
@@ -770,10 +810,10 @@ int efe_get_device(efe_ctx* ctx, int* device, char* pci_bus_id, int pci_bus_id_l
     return 0;
 }
 
-const char* efe_last_error(efe_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* efe_last_error(efe_ctx* ctx) { return !ctx ? "null context" : ctx_alive(ctx) ? ctx->err.c_str() : "stale or invalid context handle"; }
 
 int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const int64_t* shape, int ndim) {
-    if (!ctx || !key || !data_host || !shape || ndim < 1 || ndim > 4) return 1;
+    if (!key || !data_host || !shape || ndim < 1 || ndim > 4) return 1;
     EFE_LOCK(ctx);
     HostTensor t;
     size_t n = 1;
@@ -787,7 +827,7 @@ int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const 
 static int pack_fc4_b3(efe_ctx* ctx);
 
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
-    if (!ctx || !name) return 1;
+    if (!name) return 1;
     EFE_LOCK(ctx);
     if (!strcmp(name, "dec_chunk")) { if (value < 1) return ctx->fail("dec_chunk < 1"); ctx->dec_chunk = value; return 0; }
     if (!strcmp(name, "reward_upstream_intent")) { ctx->reward_intent = value ? 1 : 0; return 0; }
@@ -800,11 +840,20 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!strcmp(name, "poison")) { ctx->poison = value; return 0; }
     if (!strcmp(name, "trace")) { ctx->trace = value; return 0; }
     if (!strcmp(name, "check_rows")) { ctx->check_rows = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "sim_split")) { ctx->sim_split = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "sim_split")) {
+        // the fence-free exchange of k_sim_chain<8> relies on gfx950's sc1 = agent-scope write-through / L2-bypassing accesses: refused elsewhere
+        if (value && !ctx->arch_gfx950) return ctx->fail("sim_split: validated on gfx950 only (this device is another architecture)");
+        ctx->sim_split = value ? 1 : 0; return 0;
+    }
     if (!strcmp(name, "mfma_bf16x3")) {       // opt-in experiment; the planes are packed now if the weights are already committed
         if (value && ctx->generic) return ctx->fail("mfma_bf16x3: the experiment covers the Dynamic-dSprites geometry only");
+        // (packed from ctx->raw only while raw IS the committed set -- efe_set_weight clears `committed`, the next commit packs the planes
+        // with everything else; the option is on only after every plane exists: a failure part-way leaves the experiment off, not half-enabled)
+        if (value && ctx->committed && !ctx->fc4_b3) {
+            HIPCHK(hipSetDevice(ctx->device));
+            if (pack_fc4_b3(ctx)) { ctx->fc4_b3 = nullptr; ctx->ct_b3[0] = ctx->ct_b3[1] = nullptr; ctx->mfma_bf16x3 = 0; return 1; }
+        }
         ctx->mfma_bf16x3 = value ? 1 : 0;
-        if (value && ctx->committed && !ctx->fc4_b3) { HIPCHK(hipSetDevice(ctx->device)); if (pack_fc4_b3(ctx)) return 1; }
         return 0;
     }
     if (!strcmp(name, "arena_align")) { if (value < 256 || (value & (value - 1))) return ctx->fail("arena_align must be a power of two >= 256"); ctx->arena_align = value; return 0; }
@@ -837,7 +886,6 @@ static int pack_fc4_b3(efe_ctx* ctx) {
 }
 
 int efe_commit_weights(efe_ctx* ctx) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     // a re-commit replaces the packed buffers of the previous one: wait for work that may still read them, then free them
@@ -1008,7 +1056,6 @@ int efe_commit_weights(efe_ctx* ctx) {
 }
 
 int efe_env_reset(efe_ctx* ctx, float* state, float* last_r, int E, const efe_noise* nz, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     if (!state || !last_r || !nz || E < 1) return ctx->fail("efe_env_reset: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1017,7 +1064,6 @@ int efe_env_reset(efe_ctx* ctx, float* state, float* last_r, int E, const efe_no
 }
 
 int efe_env_new_image(efe_ctx* ctx, float* state, int E, const efe_noise* nz, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     if (!state || !nz || E < 1) return ctx->fail("efe_env_new_image: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1027,7 +1073,6 @@ int efe_env_new_image(efe_ctx* ctx, float* state, int E, const efe_noise* nz, vo
 
 int efe_env_step(efe_ctx* ctx, float* state, float* last_r, const int32_t* actions, int E, int repeats, const efe_noise* nz,
                  int32_t* round_changed, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     if (!state || !last_r || !actions || !nz || E < 1 || repeats < 1) return ctx->fail("efe_env_step: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1038,7 +1083,6 @@ int efe_env_step(efe_ctx* ctx, float* state, float* last_r, const int32_t* actio
 
 int efe_env_render(efe_ctx* ctx, const float* state, const float* last_r, const uint8_t* imgs, int64_t n_imgs, float* frames,
                    int32_t* err, int E, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     if (!state || !last_r || !imgs || !frames || n_imgs < 1 || E < 1) return ctx->fail("efe_env_render: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1058,7 +1102,6 @@ int mcts_tree(efe_ctx* ctx, const efe_mcts_tree* t, MctsTree& o) {
 int efe_mcts_select(efe_ctx* ctx, const efe_mcts_tree* tree, const uint8_t* active, float C, int use_prior, int max_depth,
                     int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf, float* leaf_s, float* leaf_s_rep,
                     void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     MctsTree t;
     if (mcts_tree(ctx, tree, t)) return 1;
@@ -1071,7 +1114,6 @@ int efe_mcts_select(efe_ctx* ctx, const efe_mcts_tree* tree, const uint8_t* acti
 
 int efe_mcts_expand(efe_ctx* ctx, const efe_mcts_tree* tree, int32_t* n_nodes, const int32_t* nodes, const uint8_t* mask, const float* G,
                     const float* ps_next, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     MctsTree t;
     if (mcts_tree(ctx, tree, t)) return 1;
@@ -1084,7 +1126,6 @@ int efe_mcts_expand(efe_ctx* ctx, const efe_mcts_tree* tree, int32_t* n_nodes, c
 int efe_mcts_backprop(efe_ctx* ctx, const efe_mcts_tree* tree, const int32_t* path_nodes, const int32_t* path_act, const int32_t* path_len,
                       const int32_t* leaf, const uint8_t* active, const float* sims, int n_sims, const float* q0, int max_depth,
                       float* g_out, uint8_t* active_out, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     MctsTree t;
     if (mcts_tree(ctx, tree, t)) return 1;
@@ -1099,7 +1140,6 @@ int efe_mcts_step(efe_ctx* ctx, const efe_mcts_tree* tree, const int32_t* prev_p
                   const float* q0, float* prev_g_out, uint8_t* prev_active_out, uint8_t* active, int32_t* stop_at, int repeat, float threshold,
                   int32_t* n_active, float C, int use_prior, int max_depth, int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf,
                   float* leaf_s, float* leaf_s_rep, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     MctsTree t;
     if (mcts_tree(ctx, tree, t)) return 1;
@@ -1115,7 +1155,6 @@ int efe_mcts_step(efe_ctx* ctx, const efe_mcts_tree* tree, const int32_t* prev_p
 
 int efe_mcts_stop(efe_ctx* ctx, const efe_mcts_tree* tree, uint8_t* active, int32_t* stop_at, int repeat, float threshold,
                   int32_t* n_active, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     MctsTree t;
     if (mcts_tree(ctx, tree, t)) return 1;
@@ -1128,7 +1167,6 @@ int efe_mcts_stop(efe_ctx* ctx, const efe_mcts_tree* tree, uint8_t* active, int3
 int64_t efe_last_call_macs(efe_ctx* ctx) { return ctx ? ctx->last_macs : 0; }
 
 int efe_prof_enable(efe_ctx* ctx, int on) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     ctx->prof = (on < 0) ? 0xFFFFFFFFu : (unsigned)on;       // < 0 = all classes, otherwise a bitmask (bit c = class c)
     ctx->ev_used = 0;
@@ -1139,7 +1177,7 @@ int efe_prof_enable(efe_ctx* ctx, int on) {
 int efe_prof_classes(void) { return PROF_NCLS; }
 
 int efe_prof_read(efe_ctx* ctx, double* ms, int64_t* launches) {
-    if (!ctx || !ms || !launches) return 1;
+    if (!ms || !launches) return 1;
     EFE_LOCK(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipDeviceSynchronize());
@@ -1157,7 +1195,6 @@ int efe_prof_read(efe_ctx* ctx, double* ms, int64_t* launches) {
 // ---- network level -------------------------------------------------------------------------------------
 int efe_transition(efe_ctx* ctx, const float* pi, const float* s0, int M, const efe_noise* nz, const float* eps,
                    float* ps1, float* mean, float* logvar, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
@@ -1176,7 +1213,6 @@ int efe_transition(efe_ctx* ctx, const float* pi, const float* s0, int M, const 
 }
 
 int efe_decoder(efe_ctx* ctx, const float* s, int M, const efe_noise* nz, float* po, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
@@ -1198,7 +1234,6 @@ int efe_decoder(efe_ctx* ctx, const float* s, int M, const efe_noise* nz, float*
 }
 
 int efe_encoder(efe_ctx* ctx, const float* o, int M, const efe_noise* nz, const float* eps, float* s, float* mean, float* logvar, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
@@ -1221,7 +1256,6 @@ int efe_encoder(efe_ctx* ctx, const float* o, int M, const efe_noise* nz, const 
 }
 
 int efe_habit(efe_ctx* ctx, const float* s, int M, float* logits, float* q, float* logq, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
@@ -1237,7 +1271,6 @@ int efe_habit(efe_ctx* ctx, const float* s, int M, float* logits, float* q, floa
 }
 
 int efe_check_reward(efe_ctx* ctx, const float* o, int M, float* out, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     if (!o || !out || M < 1) return ctx->fail("efe_check_reward: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1248,7 +1281,6 @@ int efe_check_reward(efe_ctx* ctx, const float* o, int M, float* out, void* stre
 
 int efe_reparameterize(efe_ctx* ctx, const float* mean, const float* logvar, int M, int n, const efe_noise* nz, const float* eps,
                        float* out, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     if (!mean || !logvar || !nz || !out || M < 1 || n < 1) return ctx->fail("efe_reparameterize: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1258,10 +1290,10 @@ int efe_reparameterize(efe_ctx* ctx, const float* mean, const float* logvar, int
 }
 
 // ---- EFE level -----------------------------------------------------------------------------------------
-// the row set of a call: argument if given, else the context's (deprecated) efe_set_row_mask state
+// the row set of a call (efe_rows; NULL = every row, identity)
 struct RowSet { const uint8_t* mask; const int32_t* ids; int div; };
 static int row_set(efe_ctx* ctx, const efe_rows* rows, int n_rows, int fixed_div, RowSet& out, const char* who, hipStream_t st) {
-    if (!rows) { out = RowSet{ctx->row_mask, nullptr, fixed_div > 0 ? fixed_div : ctx->row_mask_div}; return 0; }
+    if (!rows) { out = RowSet{nullptr, nullptr, fixed_div > 0 ? fixed_div : 1}; return 0; }
     const int div = fixed_div > 0 ? fixed_div : rows->rows_per_entry;
     if (div < 1 || ((rows->mask || rows->ids) && n_rows % div != 0)) { ctx->fail((std::string(who) + ": efe_rows.rows_per_entry must divide the row count").c_str()); return 1; }
     const int n_entries = n_rows / div;
@@ -1292,7 +1324,6 @@ int efe_calculate_g(efe_ctx* ctx, const float* s0, const float* pi0, int M, int 
 int efe_calculate_g_rows(efe_ctx* ctx, const float* s0, const float* pi0, int M, int samples, int mean_mode, const efe_noise* nz,
                          const float* eps, const efe_rows* rows, float* G, float* terms, float* ps1, float* ps1_mean, float* po1,
                          float* t2parts, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
@@ -1314,7 +1345,6 @@ int efe_calculate_g_rows(efe_ctx* ctx, const float* s0, const float* pi0, int M,
 
 int efe_rollout(efe_ctx* ctx, const float* o, const float* pi, int M, int steps, int samples, int calc_mean, int per_stage_mean,
                 const efe_noise* nz, const float* eps, float* sum_G, float* sum_terms, float* po1, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
@@ -1362,7 +1392,6 @@ static int trajectory_impl(efe_ctx* ctx, const float* s0_traj, const float* ps1_
 
 int efe_trajectory(efe_ctx* ctx, const float* s0_traj, const float* ps1_traj, const float* ps1_mean_traj, const float* ps1_logvar_traj,
                    const float* pi0_traj, int T, const efe_noise* nz, const float* eps, float* G, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
@@ -1381,7 +1410,6 @@ int efe_simulate(efe_ctx* ctx, const float* starting_s, int E, int depth, int us
 
 int efe_simulate_rows(efe_ctx* ctx, const float* starting_s, int E, int depth, int use_means, const efe_noise* nz,
                       const float* eps, const float* u, const efe_rows* rows, float* G_mean, float* pi0, float* Qpi0, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     hipStream_t st = (hipStream_t)stream;
     if (check_ready(ctx, st)) return 1;
@@ -1406,7 +1434,11 @@ int efe_simulate_rows(efe_ctx* ctx, const float* starting_s, int E, int depth, i
         sa.W = ctx->mid16; sa.H = ctx->top16; sa.s0 = starting_s; sa.E = E; sa.T = T; sa.use_means = use_means;
         sa.k0 = k0; sa.k1 = k1; sa.stage = nz->stage; sa.row_offset = nz->row_offset;
         sa.eps_inj = eps; sa.u_inj = u; sa.ids = rs.ids;
-        if (ctx->sim_split) { sa.xch = ctx->sim_xch; sa.sync = ctx->sim_sync; }
+        if (ctx->sim_split && (E + SIM_FE - 1) / SIM_FE <= SIM_MAX_SPLIT_GROUPS) {
+            // the split form's arrival counters and sticky timeout flag start every launch at zero, whatever the previous launch did
+            sa.xch = ctx->sim_xch; sa.sync = ctx->sim_sync;
+            if (hipMemsetAsync(ctx->sim_sync, 0, (size_t)SIM_MAX_SPLIT_GROUPS * 4 * sizeof(int), st) != hipSuccess) return ctx->fail("efe_simulate: sim_sync memset failed");
+        }
         sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0; sa.pi_dim = ctx->pi_dim; sa.tr = pre_tr;
         ctx->cls = PROF_MID;
         hipEvent_t e0 = ctx->prof_begin(st);
@@ -1422,7 +1454,6 @@ int efe_simulate_rows(efe_ctx* ctx, const float* starting_s, int E, int depth, i
 }
 
 int efe_action_posterior(efe_ctx* ctx, const float* sum_G, int n_groups, int n, float temperature, float* P, float* logP, void* stream) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     if (!sum_G || !P || !logP || n_groups < 1 || n < 1 || n > 8) return ctx->fail("efe_action_posterior: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1430,17 +1461,8 @@ int efe_action_posterior(efe_ctx* ctx, const float* sum_G, int n_groups, int n, 
     return finish(ctx);
 }
 
-int efe_set_row_mask(efe_ctx* ctx, const uint8_t* mask, int rows_per_entry) {
-    if (!ctx) return 1;
-    EFE_LOCK(ctx);
-    if (mask && rows_per_entry < 1) return ctx->fail("efe_set_row_mask: rows_per_entry < 1");
-    ctx->row_mask = mask; ctx->row_mask_div = mask ? rows_per_entry : 1;
-    return 0;
-}
-
 // ---- scratch management --------------------------------------------------------------------------------
 int efe_reserve(efe_ctx* ctx, int64_t bytes) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     if (bytes < 0) return ctx->fail("efe_reserve: bytes < 0");
     HIPCHK(hipSetDevice(ctx->device));
@@ -1462,7 +1484,7 @@ int efe_reserve(efe_ctx* ctx, int64_t bytes) {
 int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples) {
     // mirrors the allocations of efe_rollout (run_encoder for the root, run_core: run_mid per stage, run_decoder, run_encoder);
     // tests/test_gpu_parity.py::test_reserve_no_growth keeps it honest
-    if (!ctx || M < 1 || steps < 1 || samples < 1) return 0;
+    if (!ctx_alive(ctx) || M < 1 || steps < 1 || samples < 1) return 0;
     const size_t A = (size_t)ctx->arena_align;
     const int64_t dec_chunk = ctx->dec_chunk, enc_chunk = ctx->enc_chunk;
     auto al = [A](size_t b) { return (b + A - 1) / A * A; };
@@ -1499,7 +1521,6 @@ int64_t efe_rollout_scratch_bytes(efe_ctx* ctx, int M, int steps, int samples) {
 }
 
 int efe_arena_stats(efe_ctx* ctx, int64_t* capacity_bytes, int64_t* high_water_bytes, int64_t* grow_count) {
-    if (!ctx) return 1;
     EFE_LOCK(ctx);
     size_t have = 0;
     for (auto& b : ctx->arena.blocks) have += b.second;

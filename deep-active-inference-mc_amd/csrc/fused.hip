@@ -132,7 +132,8 @@ __device__ __forceinline__ void trans_chain(const MlpW& W, float4* bufA, float4*
 // AGENT-SCOPE accesses (sc1: write-through stores, cache-bypassing loads) and a counter -- no release / acquire fences: on gfx950 those
 // write back and invalidate the XCD's whole L2 (the fenced form of round 4 was slower than one workgroup).  Every feature is contracted by
 // the same MFMA sequence over K as in trans_chain: bit-identical results.
-constexpr unsigned AUX_SC1 = 16u;                 // cache-policy bit 4 of the raw buffer intrinsics = sc1 on gfx940+ (agent scope)
+constexpr unsigned AUX_SC1 = 16u;                 // cache-policy bit 4 of the raw buffer intrinsics = sc1 on gfx940+ (agent scope: write-through stores, loads that miss the
+                                                  // XCD-local L2); the engine enables the split chain on gfx950 only (efe_create_cfg checks gcnArchName)
 constexpr int XCH_ROW_F4 = 128;                   // exchange buffer: [16 rows][512 floats]
 
 // one 16-feature tile over KC = 32 chunks with the weight fragments EIGHT chunks ahead (a ring of eight statically indexed registers, the
@@ -181,17 +182,24 @@ __device__ __forceinline__ float4 hidden16_slice(const float4* __restrict__ Wp, 
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// all NWG workgroups of the group have stored their slice of xbuf -> the full [16][512] activation in LDS (act_out).  *bad is set when the
-// peers do not arrive within the spin bound (~0.3 s: the results are then poisoned by the caller, never silently wrong).
+// all NWG workgroups of the group have stored their slice of xbuf -> the full [16][512] activation in LDS (act_out).
+// A peer that does not arrive within the spin bound (~0.3 s) must never produce a silently wrong rollout: the workgroup that timed out
+// raises the group's STICKY flag (sync[2], agent scope) before it goes on -- i.e. before it publishes any further slice or arrival -- and
+// every workgroup re-reads the flag behind each gather: *bad is set in all of them, whichever one saw the timeout, and the writer poisons
+// every output of the launch (k_sim_chain's epilogue).  The counters are zeroed on the stream in front of every split launch
+// (engine.hip), so a launch that was cut short cannot leave the next one's barriers open.
 template <int NWG>
-__device__ __forceinline__ void xchg_gather(const float* xbuf, int* flag, int target, float4* act_out, int tid, int* bad) {
+__device__ __forceinline__ void xchg_gather(const float* xbuf, int* sync, int target, float4* act_out, int tid, int* bad) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's slice stores are acknowledged (write-through)
     __syncthreads();
     if (tid == 0) {
-        __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(1);
-        if (spins >= (1 << 18)) *bad = 1;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(1);
+        int sticky = 0;
+        if (spins >= (1 << 18)) sticky = 1 | __hip_atomic_fetch_or(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (returning form: complete before the next arrival)
+        else sticky = __hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sticky) *bad = 1;
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t xr = rsrc16(xbuf);
@@ -290,7 +298,6 @@ void launch_trans_fused(const TransFusedArgs& a, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------
 // NWG = 1: one workgroup per 8 episodes (any batch size).  NWG = 8: the same group of 8 episodes on EIGHT workgroups that split the two wide
 // layers of the transition net (trans_chain_x): 237 -> ~100 us per launch for the one-episode planner, whose critical path it is.
-constexpr int SIM_FE = 8;              // episodes per workgroup (group)
 template <int NWG>
 __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float4 sm[];
@@ -393,19 +400,31 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
                 const size_t oo = ((size_t)e * T + t) * 10 + k;
                 if (writer) {
                     a.s0_traj[oo] = srow[rr * 16 + k];
-                    // (a peer workgroup that never arrived: the rollout is poisoned, not silently wrong)
-                    a.ps1_traj[oo] = samp; a.mean_traj[oo] = (NWG > 1 && bad_) ? __builtin_nanf("") : mean; a.lv_traj[oo] = lv;
+                    a.ps1_traj[oo] = samp; a.mean_traj[oo] = mean; a.lv_traj[oo] = lv;
                 }
                 srow[rr * 16 + k] = a.use_means ? mean : samp;          // each (row, k) is read and rewritten by this thread only
             }
         }
         __syncthreads();
     }
-    if (NWG > 1 && tid == 0) {
-        // the last workgroup of the group to finish re-arms the counters for the next launch (all eight have passed every exchange by then)
-        if (__hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NWG - 1) {
-            __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (NWG > 1) {
+        // A timeout anywhere in the group (the sticky flag, re-read once more: a peer may have raised it behind this workgroup's last
+        // gather) poisons EVERY output of the group's episodes -- trajectory arrays, transition rows, the first step's habit posterior --
+        // so that G of these episodes is NaN, never a finite number computed from a partial exchange.
+        if (tid == 0 && __hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) bad_ = 1;
+        __syncthreads();
+        if (bad_ && writer) {
+            const float qnan = __builtin_nanf("");
+            for (int i = tid; i < SIM_FE * T * 10; i += 256) {
+                const int e = e0 + i / (T * 10);
+                if (e < E) { const size_t oo = (size_t)e0 * T * 10 + i; a.ps1_traj[oo] = qnan; a.mean_traj[oo] = qnan; a.lv_traj[oo] = qnan; a.s0_traj[oo] = qnan; }
+            }
+            if (a.tr)
+                for (int i = tid; i < 2 * SIM_FE * T * 32; i += 256) {
+                    const int pass = i / (SIM_FE * T * 32), r = i - pass * (SIM_FE * T * 32), e = e0 + r / (T * 32);
+                    if (e < E) a.tr[(size_t)pass * E * T * 32 + (size_t)e0 * T * 32 + r] = qnan;
+                }
+            if (a.Qpi0 && tid < SIM_FE * A && e0 + tid / A < E) a.Qpi0[(size_t)e0 * A + tid] = qnan;
         }
     }
 }

@@ -50,7 +50,7 @@ __device__ __forceinline__ uint2 group_key(const GroupMap& gm, int g) {
     return make_uint2(stream_id(pass, gm.sample0 + (uint32_t)samp), gm.stage0 + (uint32_t)t);
 }
 
-// Optional liveness mask of the logical rows of a call (efe_set_row_mask: the lock-step planner's early-stopped episodes): image m of
+// Optional liveness mask of the logical rows of a call (efe_rows.mask: the lock-step planner's early-stopped episodes): image m of
 // a launch belongs to logical row (m0 + m) % rows_per_group and is evaluated iff mask == nullptr or mask[row / div] != 0.  The
 // per-image kernels (decoder stages, encoder trunk) skip dead images; the outputs of dead rows are unspecified.
 struct RowMask {
@@ -254,6 +254,7 @@ struct SimChainArgs {
     // [groups][2][16][512] floats and self-resetting counters [groups][4] ints (zero at first use), both owned by the context
     float* xch = nullptr; int* sync = nullptr;
 };
+constexpr int SIM_FE = 8;                        // episodes per group of the simulation chain kernel
 constexpr int SIM_MAX_SPLIT_GROUPS = 2;          // launches of up to 16 episodes use the split form
 void launch_sim_chain(const SimChainArgs& a, hipStream_t st);
 int init_fused_kernels();

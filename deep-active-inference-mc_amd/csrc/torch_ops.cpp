@@ -27,14 +27,25 @@ namespace {
 using at::Tensor;
 using OptT = c10::optional<Tensor>;
 
+// The integer handle is checked against the engine's registry of live contexts (efe_ctx_alive: efe_create adds, efe_destroy removes), so a
+// stale or made-up handle is a RuntimeError, not a dereference of freed memory.  CTX() also notes the context's device: every tensor of
+// the call must live on it (in() below) -- the launch stream is torch's current stream of THAT device.
+thread_local int tl_ctx_device = -1;
 efe_ctx* CTX(int64_t h) {
     TORCH_CHECK(h != 0, "efe: null engine context");
-    return reinterpret_cast<efe_ctx*>(static_cast<intptr_t>(h));
+    efe_ctx* c = reinterpret_cast<efe_ctx*>(static_cast<intptr_t>(h));
+    TORCH_CHECK(efe_ctx_alive(c), "efe: stale or invalid engine context handle ", h, " (the context was destroyed, or this is not a handle of efe_create)");
+    int dev = -1;
+    TORCH_CHECK(efe_get_device(c, &dev, nullptr, 0) == 0, "efe: efe_get_device failed");
+    tl_ctx_device = dev;
+    return c;
 }
 void ok(efe_ctx* c, int rc) { TORCH_CHECK(rc == 0, "efe engine: ", efe_last_error(c)); }
 
 Tensor in(const Tensor& t, const char* name) {
     TORCH_CHECK(t.is_cuda(), "efe: ", name, " must be a HIP device tensor (there is no CPU fallback)");
+    TORCH_CHECK((int)t.device().index() == tl_ctx_device, "efe: ", name, " is on device ", (int)t.device().index(), ", the engine context lives on device ",
+                tl_ctx_device, " (one context per device: create the model on the tensor's device)");
     TORCH_CHECK(t.scalar_type() == at::kFloat, "efe: ", name, " must be float32");
     return t.contiguous();
 }
@@ -53,6 +64,7 @@ void rows_arg(RowsArg& ra, const OptT& mask, const OptT& ids, int64_t rows_per_e
     ra.r.rows_per_entry = (int32_t)rows_per_entry;
     if (hm) {
         TORCH_CHECK(mask->is_cuda() && mask->scalar_type() == at::kByte && mask->is_contiguous(), "efe: row mask must be a contiguous uint8 HIP tensor");
+        TORCH_CHECK((int)mask->device().index() == tl_ctx_device, "efe: row mask on device ", (int)mask->device().index(), ", engine context on device ", tl_ctx_device);
         TORCH_CHECK(hi || mask->numel() >= n_entries, "efe: row mask has ", mask->numel(), " entries, the call has ", n_entries);
         // the mask is indexed by entry ID: it must cover the whole un-compacted batch (n_total; with ids and no n_total the bound is unknown here)
         TORCH_CHECK(n_total <= 0 || mask->numel() >= n_total, "efe: row mask has ", mask->numel(), " entries, the un-compacted batch has ", n_total);
@@ -61,6 +73,7 @@ void rows_arg(RowsArg& ra, const OptT& mask, const OptT& ids, int64_t rows_per_e
     }
     if (hi) {
         TORCH_CHECK(ids->is_cuda() && ids->scalar_type() == at::kInt && ids->is_contiguous(), "efe: row ids must be a contiguous int32 HIP tensor");
+        TORCH_CHECK((int)ids->device().index() == tl_ctx_device, "efe: row ids on device ", (int)ids->device().index(), ", engine context on device ", tl_ctx_device);
         TORCH_CHECK(ids->numel() == n_entries, "efe: row ids has ", ids->numel(), " entries, the call has ", n_entries);
         ra.ik = *ids; ra.r.ids = ra.ik.data_ptr<int32_t>();
     }
@@ -68,7 +81,10 @@ void rows_arg(RowsArg& ra, const OptT& mask, const OptT& ids, int64_t rows_per_e
     ra.r.n_total = (int32_t)n_total;
     ra.ptr = &ra.r;
 }
-void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+void* stream_of(const Tensor& t) {
+    TORCH_CHECK((int)t.device().index() == tl_ctx_device, "efe: tensor on device ", (int)t.device().index(), ", engine context on device ", tl_ctx_device);
+    return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream();
+}
 efe_noise noise(int64_t seed, int64_t stage, int64_t pass, int64_t sample, int64_t row_offset) {
     efe_noise nz;
     nz.seed = (uint64_t)seed; nz.stage = (uint32_t)stage; nz.pass = (uint32_t)pass; nz.sample = (uint32_t)sample;

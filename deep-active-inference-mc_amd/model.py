@@ -375,22 +375,6 @@ class ActiveInferenceModel:
         e.check(e.lib.efe_reserve(e.ctx, need))
         return need
 
-    def set_row_mask(self, mask, rows_per_entry=1):
-        """DEPRECATED (context state: every following call on this model sees the mask) -- pass rows=Rows(mask=...) to the call instead.
-        Liveness mask for the following calculate_G / simulate_batch calls (efe_set_row_mask): `mask` is a uint8 tensor on this
-        device, one byte per entry, read when the kernels run; calculate_G row r belongs to entry r // rows_per_entry,
-        simulate_batch episode e to entry e.  Dead rows are skipped by the decoder / encoder kernels and return unspecified
-        values; live rows are bit-identical to an unmasked call.  None clears the mask.  The caller keeps `mask` alive."""
-        e = self._ready()
-        if mask is None:
-            self._row_mask = None
-            e.check(e.lib.efe_set_row_mask(e.ctx, None, 1))
-            return
-        if mask.dtype != torch.uint8 or mask.device != self.device or not mask.is_contiguous():
-            raise ValueError('set_row_mask: a contiguous uint8 tensor on the model device is required')
-        self._row_mask = mask
-        e.check(e.lib.efe_set_row_mask(e.ctx, C.c_void_p(mask.data_ptr()), int(rows_per_entry)))
-
     def engine_device(self):
         """-> (HIP device index, PCI bus id) of the engine context (efe_get_device): the GPU the kernels of this model run on"""
         e = self._engine

@@ -49,9 +49,14 @@ int efe_get_config(efe_ctx* ctx, int* s_dim, int* pi_dim, int* channels, int* re
 /* the HIP device the context was created on (efe_create's `device`) and the PCI bus id string of that device ("0000:c1:00.0"; buf may be
  * NULL): what a multi-GPU launcher checks so that rank r really owns GPU r (bench.py gathers them and refuses two ranks on one device) */
 int efe_get_device(efe_ctx* ctx, int* device, char* pci_bus_id, int pci_bus_id_len);
-void efe_destroy(efe_ctx* ctx);
+void efe_destroy(efe_ctx* ctx);                                  /* a handle that is not live (already destroyed, never created) is ignored */
 const char* efe_last_error(efe_ctx* ctx);
-int efe_abi_version(void);                                       /* 5 (history of the versions: INTEGRATION.md section 4) */
+/* 1 if `ctx` is a live context of this process (created by efe_create[_cfg], not yet destroyed), else 0; never dereferences the pointer.
+ * The library keeps a registry of its contexts and EVERY entry point checks its handle against it first (a stale handle is return code 1,
+ * not a use of freed memory); bindings that carry the handle as an integer (torch.ops.efe.*, ctypes) use this to raise a proper error.
+ * Every entry point also restores the CALLER's current HIP device before it returns (the context's device is current only inside the call). */
+int efe_ctx_alive(const efe_ctx* ctx);
+int efe_abi_version(void);                                       /* 6 (history of the versions: INTEGRATION.md section 4) */
 /* hex digest of the sources this library was compiled from (build.py stamps it; the Python loader refuses a library whose
  * digest differs from the sources next to it, so a stale shipped binary fails loudly). */
 const char* efe_build_id(void);
@@ -106,15 +111,13 @@ int efe_arena_stats(efe_ctx* ctx, int64_t* capacity_bytes, int64_t* high_water_b
  *          When stated, a call with more entries than n_total (no ids) fails, and with the development option "check_rows" = 1 the
  *          ids are copied back and range-checked before the launch (one synchronisation: a stale or corrupt id would otherwise be a
  *          silent out-of-bounds read of `mask` and a wrong noise key).
- * A NULL efe_rows* means "all rows, identity" -- except that a mask installed with the DEPRECATED efe_set_row_mask (context state: every
- * efe_calculate_g / efe_simulate on the context sees it until cleared; kept as a shim for ABI 3 callers) then applies. */
+ * A NULL efe_rows* means "all rows, identity" (the context-state shim efe_set_row_mask of ABI 2 - 5 is gone in ABI 6: the row set is an argument). */
 typedef struct efe_rows {
     const uint8_t* mask;
     const int32_t* ids;
     int32_t rows_per_entry;
     int32_t n_total;
 } efe_rows;
-int efe_set_row_mask(efe_ctx* ctx, const uint8_t* mask, int rows_per_entry);      /* deprecated: pass efe_rows to the _rows entry points */
 
 typedef struct efe_noise {
     uint64_t seed;

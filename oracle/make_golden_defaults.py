@@ -1,0 +1,171 @@
+"""ORACLE tooling -- runs ONLY in the build container (needs /root/reference).
+
+The reference planner at ITS OWN DEFAULTS and with several simulations per iteration, captured from
+`/root/reference/src/mcts.py:137-195` with the shim and the noise injection of oracle/make_golden.py (imported, not repeated):
+
+  mcts_defaults        `MCTS_Params()` UNTOUCHED (mcts.py:139-148: C 1.0, threshold 0.5, repeats 300, simulation_repeats 1,
+                       simulation_depth 3, use_means True -> Node.expand calls calculate_G_mean) on 6 frames chosen from the
+                       `--probe` table so that the default threshold stops some episodes early and lets others run long
+  mcts_defaults_full   the same parameters with the early stop out of reach (threshold 2.0 > 1 - 1/pi_dim): EVERY episode runs all
+                       300 iterations -> 1 205-node trees (the lock-step planner's capacity 1 + 4 (repeats + 2)), path / history
+                       arrays at 6 x the size of the benchmark-depth captures
+  mcts_simrep2_s10     simulation_repeats = 2 (mcts.py:185-189: the MEAN of the simulations is back-propagated and recorded, the leaf's
+                       Qpi is the LAST simulation's) at the benchmark's depth: 10-sample expansions, depth-5 simulations, 50 iterations,
+                       threshold 0.5 (early stops included)
+
+Episode e draws its noise at global rows 4e+a (expansions), e (root encode, simulate steps) and e*depth+t (trajectory); one noise stage
+per engine-level call in the reference's call order (root encode, root expansion, then per iteration the expansion and each simulation).
+Fixtures hold tensors only.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_defaults            (about 6 minutes)
+        PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_defaults --probe    the stop statistic per iteration, stop disabled
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import philox as PX
+from oracle import synth
+from oracle.make_golden import load_reference, GOLD
+
+WSEED, NSEED, GAIN = 1234, 7, 1.15
+DEFAULTS = dict(C=1.0, threshold=0.5, repeats=300, simulation_repeats=1, simulation_depth=3, use_habit=False, use_means=True,
+                using_prior_for_exploration=False)
+
+
+def run_case(model, inj, ref_mcts, state, *, frames, samples, stage0, configure, record_stat=None):
+    """`configure(params)` edits a fresh MCTS_Params() (None: untouched).  -> dict of arrays, report"""
+    orig_expand, orig_init, orig_ct = ref_mcts.Node.expand, ref_mcts.Node.__init__, ref_mcts.calc_threshold
+    created = []
+
+    def expand_s(self, use_means=False, samples=samples):        # the reference planner hard-wires expand(samples=1) (mcts.py:172,184)
+        return orig_expand(self, use_means=use_means, samples=samples)
+
+    def init_capture(self, *a, **k):
+        orig_init(self, *a, **k)
+        created.append(self)
+
+    def calc_threshold_rec(P, axis):                             # a recording wrapper: returns the reference's value
+        v = orig_ct(P, axis)
+        if record_stat is not None:
+            record_stat.append(float(v))
+        return v
+    ref_mcts.Node.expand, ref_mcts.Node.__init__, ref_mcts.calc_threshold = expand_s, init_capture, calc_threshold_rec
+    E = frames.shape[0]
+    p0 = ref_mcts.MCTS_Params()
+    if configure is not None:
+        configure(p0)
+    R, depth = int(p0.repeats), int(p0.simulation_depth)
+    fp = np.full((E, R + 2), -1, dtype=np.int64)
+    ap = np.full((E, R, 40), -1, dtype=np.int8)                  # (a path of 300 iterations is far shorter than R + 2; asserted below)
+    ag = np.zeros((E, R), dtype=np.float64); npaths = np.zeros(E, dtype=np.int64)
+    repd = np.zeros(E, dtype=np.int64); expl = np.zeros(E, dtype=np.int64); rootN = np.zeros((E, 4), dtype=np.float32)
+    nodes = np.zeros(E, dtype=np.int64); maxlen = np.zeros(E, dtype=np.int64)
+    try:
+        for e in range(E):
+            params = ref_mcts.MCTS_Params()
+            if configure is None:
+                assert all(getattr(params, k) == v for k, v in DEFAULTS.items()), vars(params)
+            else:
+                configure(params)
+            state['ro'], state['episode'] = 4 * e, e
+            inj.stage = stage0
+            inj.p_enc(PX.PASS_ROOT, 0, inj.stage, e, with_eps=False); inj.stage += 1
+            del created[:]
+            frame = torch.from_numpy(frames[e, 0][:, :, None].copy())
+            t = time.time()
+            path, reps, explored, all_paths, all_G = ref_mcts.active_inference_mcts(model, frame, params, o_shape=(1, 64, 64))
+            assert not inj.q
+            fp[e, :len(path)] = [int(x) for x in path]
+            for i, p_ in enumerate(all_paths):
+                assert len(p_) <= ap.shape[2]
+                ap[e, i, :len(p_)] = [int(x) for x in p_]
+            ag[e, :len(all_G)] = all_G
+            npaths[e], repd[e], expl[e] = len(all_paths), reps, explored
+            rootN[e] = created[0].N.numpy()
+            nodes[e] = len(created); maxlen[e] = max(len(p_) for p_ in all_paths)
+            print(f'episode {e}: {time.time() - t:.1f} s, reps {reps}, nodes {len(created)}, longest path {maxlen[e]}, final {path}', flush=True)
+    finally:
+        ref_mcts.Node.expand, ref_mcts.Node.__init__, ref_mcts.calc_threshold = orig_expand, orig_init, orig_ct
+        state['ro'], state['episode'] = 0, 0
+    arrs = dict(frames=frames, episodes=E, samples=samples, repeats=R, simulation_depth=depth, simulation_repeats=int(p0.simulation_repeats),
+                use_means=int(bool(p0.use_means)), threshold=float(p0.threshold), C=float(p0.C), stage=stage0,
+                using_prior_for_exploration=int(bool(p0.using_prior_for_exploration)), use_habit=int(bool(p0.use_habit)),
+                final_path=fp, all_paths=ap, all_paths_G=ag, n_paths=npaths, repeats_done=repd, states_explored=expl, root_N=rootN,
+                n_nodes=nodes, wseed=WSEED, gain=GAIN, nseed=NSEED)
+    return arrs, dict(reps=[int(x) for x in repd], nodes=[int(x) for x in nodes], longest_path=[int(x) for x in maxlen])
+
+
+# frames of the default-parameter cases: the first six of synth.make_frames(FRAME_SEED, PROBE_N).  `--probe` (all 16 frames, stop
+# disabled, statistic recorded) says where each threshold would stop them:
+#   threshold 0.5  stops at [300, 21, 145, 65, 177, 233, 21, 21, 300, 141, 21, 21, 161, 29, 45, 300]
+#   threshold 0.4  stops at [251, 14, 28, 42, 105, 48, 14, 14, 300, 31, 14, 14, 99, 19, 25, 300]
+# -> at the reference's default 0.5, frames 0 - 5 give one episode that never stops, three that run >= 145 iterations, two early stops
+FRAME_SEED, PROBE_N = 31, 16
+PICKED = [0, 1, 2, 3, 4, 5]
+
+
+def no_stop(p):
+    p.threshold = 2.0
+
+
+def simrep2(p):
+    p.repeats, p.simulation_depth, p.use_means, p.simulation_repeats, p.threshold = 50, 5, False, 2, 0.5
+
+
+def save(name, arrs, manifest):
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **{k: np.asarray(v) for k, v in arrs.items()})
+    manifest['cases'][name] = sorted(arrs.keys())
+
+
+def main():
+    torch.set_grad_enabled(False)
+    model, inj, ref_mcts, state = load_reference(synth.make_weights(WSEED, GAIN), NSEED)
+    all_frames = synth.make_frames(FRAME_SEED, PROBE_N)
+    if '--probe' in sys.argv:
+        stat = []
+        arrs, rep = run_case(model, inj, ref_mcts, state, frames=all_frames, samples=1, stage0=1000, configure=no_stop, record_stat=stat)
+        s = np.array(stat).reshape(PROBE_N, 300)
+        for t in (0.3, 0.4, 0.45, 0.5, 0.55, 0.6):
+            print('threshold', t, 'stops at', [int(np.argmax(r > t)) if (r > t).any() else 300 for r in s])
+        return
+    mpath = os.path.join(GOLD, 'MANIFEST.json')
+    manifest = json.load(open(mpath))
+    report = {}
+    frames = all_frames[PICKED]
+    stat = []
+    arrs, report['mcts_defaults'] = run_case(model, inj, ref_mcts, state, frames=frames, samples=1, stage0=1000, configure=None, record_stat=stat)
+    reps = report['mcts_defaults']['reps']
+    assert any(r >= 150 for r in reps) and any(r < 150 for r in reps), reps
+    ts = np.full((len(PICKED), 300), np.nan, dtype=np.float32)          # one check per started iteration (+ the one that stops the episode)
+    k = 0
+    for e, r in enumerate(reps):
+        n = r + 1 if r < 300 else 300
+        ts[e, :n] = stat[k:k + n]
+        k += n
+    assert k == len(stat)
+    arrs['thr_stat'] = ts
+    save('mcts_defaults', arrs, manifest)
+    arrs, report['mcts_defaults_full'] = run_case(model, inj, ref_mcts, state, frames=frames[:3], samples=1, stage0=1000, configure=no_stop)
+    assert all(r == 300 for r in report['mcts_defaults_full']['reps'])
+    save('mcts_defaults_full', arrs, manifest)
+    arrs, report['mcts_simrep2_s10'] = run_case(model, inj, ref_mcts, state, frames=synth.make_frames(32, 4), samples=10, stage0=2000, configure=simrep2)
+    save('mcts_simrep2_s10', arrs, manifest)
+    manifest['default_planner_cases'] = ('mcts_defaults, mcts_defaults_full, mcts_simrep2_s10: oracle/make_golden_defaults.py '
+                                         '(same shim and injection as make_golden.py)')
+    with open(mpath, 'w') as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print(json.dumps(report, indent=1))
+
+
+if __name__ == '__main__':
+    main()

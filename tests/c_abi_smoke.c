@@ -179,12 +179,10 @@ int main(int argc, char** argv) {
             if (efe_calculate_g_rows(ctx, ds, dpi, M, S, 0, &nz, NULL, &trows, dG, dT, dps1, dmean, dpo1, NULL, NULL) == 0) { fprintf(stderr, "n_total < entries accepted\n"); return 1; }
             HIP(hipFree(dids));
         }
-        /* the deprecated context-state form still works */
-        CHECK(efe_set_row_mask(ctx, dmask, 4));
-        CHECK(efe_calculate_g(ctx, ds, dpi, M, S, 0, &nz, NULL, dG, dT, dps1, dmean, dpo1, NULL, NULL));
-        CHECK(efe_set_row_mask(ctx, NULL, 1));
-        HIP(hipMemcpy(hGm, dG, M * 4, hipMemcpyDeviceToHost));
-        for (int i = 4; i < M; ++i) if (hGm[i] != hG[0][i]) { fprintf(stderr, "efe_set_row_mask changed a live row\n"); return 1; }
+        /* ABI 6: the context-state shim efe_set_row_mask is gone -- the masked call above left no state behind: a plain call is complete */
+        /* ... and a handle that is not a live context is refused by every entry point instead of dereferenced (the registry behind efe_ctx_alive) */
+        if (!efe_ctx_alive(ctx) || efe_ctx_alive(NULL) || efe_ctx_alive((const efe_ctx*)hG)) { fprintf(stderr, "efe_ctx_alive wrong\n"); return 1; }
+        if (efe_calculate_g((efe_ctx*)hG, ds, dpi, M, S, 0, &nz, NULL, dG, dT, dps1, dmean, dpo1, NULL, NULL) == 0) { fprintf(stderr, "a made-up handle was accepted\n"); return 1; }
         CHECK(efe_calculate_g(ctx, ds, dpi, M, S, 0, &nz, NULL, dG, dT, dps1, dmean, dpo1, NULL, NULL));     /* dG complete again for the posterior */
         HIP(hipFree(dmask));
     }

@@ -242,7 +242,7 @@ def test_other_geometries_networks(A2, C2, R2):
 
 
 def test_row_mask_generic_geometry(pair):
-    """efe_set_row_mask on the generic path (ConvT / final-layer kernels skip dead images): live rows bit-identical"""
+    """efe_rows.mask on the generic path (ConvT / final-layer kernels skip dead images): live rows bit-identical"""
     m, _ = pair
     Eps = 4
     M = A * Eps
@@ -250,18 +250,12 @@ def test_row_mask_generic_geometry(pair):
     pi0 = np.eye(A, dtype=np.float32)[np.arange(M) % A]
     ref = m.calculate_G(s0, pi0, samples=2, stage=6)
     alive = torch.tensor([0, 1, 1, 0], dtype=torch.uint8, device=m.device)
-    try:
-        m.set_row_mask(alive, A)
-        out = m.calculate_G(s0, pi0, samples=2, stage=6)
-    finally:
-        m.set_row_mask(None)
+    from daimc_amd.model import Rows
+    out = m.calculate_G(s0, pi0, samples=2, stage=6, rows=Rows(mask=alive, rows_per_entry=A))
     rows = alive.bool().repeat_interleave(A)
     assert torch.equal(out[0][rows], ref[0][rows]) and torch.equal(out[2][rows], ref[2][rows]) and torch.equal(out[4][rows], ref[4][rows])
     assert torch.equal(m.calculate_G(s0, pi0, samples=2, stage=6)[0], ref[0])
-    # ABI 4: the row set as an argument of the call, and a compacted call (entries 1, 2 only) -- the generic kernels read the mask at the entry id
-    from daimc_amd.model import Rows
-    out2 = m.calculate_G(s0, pi0, samples=2, stage=6, rows=Rows(mask=alive, rows_per_entry=A))
-    assert torch.equal(out2[0][rows], ref[0][rows]) and torch.equal(out2[4][rows], ref[4][rows])
+    # a compacted call (entries 1, 2 only) -- the generic kernels read the mask at the entry id
     keep = torch.nonzero(alive).flatten()
     kr = (keep[:, None] * A + torch.arange(A, device=m.device)[None]).reshape(-1)
     s0d, pid = torch.from_numpy(s0).to(m.device), torch.from_numpy(pi0).to(m.device)

@@ -559,6 +559,73 @@ def test_planners_at_benchmark_depth_vs_reference(golden, models, name):
         _check_deep(g, e, out1[0], v1[0])
 
 
+def _fixture_params(g):
+    """MCTS_Params with every field the new fixtures store (oracle/make_golden_defaults.py)"""
+    import daimc_amd
+    p = daimc_amd.MCTS_Params()
+    p.repeats, p.simulation_depth, p.simulation_repeats = int(g['repeats']), int(g['simulation_depth']), int(g['simulation_repeats'])
+    p.use_means, p.threshold, p.C, p.samples = bool(g['use_means']), float(g['threshold']), float(g['C']), int(g['samples'])
+    p.using_prior_for_exploration, p.use_habit = bool(g['using_prior_for_exploration']), bool(g['use_habit'])
+    return p
+
+
+@pytest.mark.parametrize('name', ['mcts_defaults', 'mcts_defaults_full', 'mcts_simrep2_s10'])
+def test_planner_at_the_reference_defaults_and_with_two_simulations(golden, models, name):
+    """The reference planner's OWN default call (mcts.py:139-148: 300 repeats, simulation depth 3, use_means -> calculate_G_mean expansions,
+    threshold 0.5; `MCTS_Params()` untouched on both sides) and simulation_repeats = 2 (mcts.py:185-189), captured from the reference
+    (oracle/make_golden_defaults.py).  mcts_defaults: six episodes that stop before iterations 300 (never), 21, 145, 65, 177, 233;
+    mcts_defaults_full: the stop out of reach, 1 205-node trees = the lock-step planner's node capacity, 300-entry path history;
+    mcts_simrep2_s10: 10-sample expansions, depth-5 simulations, two simulations per iteration, one early stop.
+    Compared: repeats_done, states_explored, every path, the G history, the final path, the root visit counts -- through the lock-step
+    planner on all episodes, the single-episode API (host Node tree) and each episode alone on the device planner."""
+    import daimc_amd
+    g = golden(name)
+    m = inject(_model(g, models))
+    p = _fixture_params(g)
+    if name == 'mcts_defaults':
+        d = daimc_amd.MCTS_Params()
+        assert all(getattr(p, k) == getattr(d, k) for k in vars(d)), 'the fixture is the reference default call'
+        p = d                                                     # literally the untouched default object
+    E = int(g['episodes'])
+    frames = torch.from_numpy(g['frames'])
+    m._stage = int(g['stage'])
+    out, visits = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
+    planner = next(pl for pl in m._planners.values() if pl.E == E and pl.p.repeats == p.repeats and pl.p.simulation_repeats == p.simulation_repeats)
+    assert planner.cap == 1 + 4 * (p.repeats + 2) and int(planner.n_nodes.max()) == int(g['n_nodes'].max()) <= planner.cap
+    for e in range(E):
+        _check_deep(g, e, out[e], visits[e])
+    # episode 0 through the reference-shaped single-episode API on the host Node tree (all its noise rows start at 0) ...
+    m._stage = int(g['stage'])
+    p.host_tree = True
+    _check_deep(g, 0, daimc_amd.active_inference_mcts(m, frames[0], p, o_shape=(1, 64, 64)))
+    p.host_tree = False
+    # ... and the longest-running and the earliest-stopping episode alone on the device planner at their global episode offsets
+    for e in sorted({int(np.argmax(g['repeats_done'])), int(np.argmin(g['repeats_done']))}):
+        m._stage = int(g['stage'])
+        out1, v1 = daimc_amd.active_inference_mcts_batch(m, frames[e:e + 1], p, o_shape=(1, 64, 64), episode_offset=e)
+        _check_deep(g, e, out1[0], v1[0])
+
+
+@pytest.mark.parametrize('name', ['mcts_defaults', 'mcts_simrep2_s10'])
+def test_lockstep_batch_of_64_at_the_reference_defaults_contains_the_reference_episodes(golden, models, name):
+    """the same captures inside a 64-episode lock-step batch (second stream + replica context, lagged host check, compaction of the episodes
+    the default threshold stops): the fixture's episodes are bit-for-bit the reference's whatever the other episodes do"""
+    import daimc_amd
+    g = golden(name)
+    m = inject(_model(g, models))
+    p = _fixture_params(g)
+    E, E0 = 64, int(g['episodes'])
+    frames = torch.cat([torch.from_numpy(g['frames']), torch.from_numpy(synth.make_frames(79, E - E0))], 0)
+    m._stage = int(g['stage'])
+    out, visits = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
+    planner = next(pl for pl in m._planners.values() if pl.E == E and pl.p.repeats == p.repeats and pl.p.simulation_repeats == p.simulation_repeats)
+    assert planner.overlap and planner._ids is not None and len(planner._ids[1]) < E          # stopped episodes were compacted out
+    for e in range(E0):
+        _check_deep(g, e, out[e], visits[e])
+    np.testing.assert_allclose(visits.sum(1).numpy(), 1.0, rtol=1e-6)
+    assert all(o_[2] == len(o_[3]) * p.simulation_depth * p.simulation_repeats for o_ in out)
+
+
 def test_batched_mcts_episode_invariance(models):
     """episode e planned inside a batch of 3 == planned alone with episode_offset = e (global noise keys):
     the property that lets episodes shard across GPUs with identical results"""
@@ -989,6 +1056,52 @@ def test_full_size_cfg2_vs_oracle(models, weights_cache):
     np.testing.assert_allclose(c(po1d), opo1.numpy(), rtol=1e-4, atol=2e-4)
 
 
+def test_custom_op_boundary_refuses_stale_handles_and_foreign_devices(weights_cache):
+    """torch.ops.efe.* take the engine context as an integer handle: a handle that is not a live context (destroyed, made up) is a
+    RuntimeError from the registry check (efe_ctx_alive), not a dereference of freed memory; a tensor on another device than the context's
+    is refused; and a call leaves the caller's current HIP device as it found it (include/efe_engine.h, ABI 6)."""
+    import ctypes as C
+    import gc
+    import daimc_amd
+    from daimc_amd import _lib
+    lib, ops = _lib.load(), _lib.load_ops()
+    m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=3, init_weights=False)
+    m.load_flat_weights(weights_cache(1234, 1.15))
+    s = torch.zeros(4, 10, device='cuda:0')
+    h = m._ready().h
+    assert lib.efe_ctx_alive(C.c_void_p(h)) == 1
+    q_live = ops.habit(h, s)[1]
+    assert torch.isfinite(q_live).all()
+    del m
+    gc.collect()
+    assert lib.efe_ctx_alive(C.c_void_p(h)) == 0                   # the context left the registry when it was destroyed
+    for bad in (h, h + 64, 0xdead0000, -1):
+        with pytest.raises(RuntimeError):
+            ops.habit(bad, s)
+    with pytest.raises(RuntimeError):
+        ops.habit(0, s)
+    # the C ABI itself refuses them too (return code 1, "stale or invalid context handle"), and a second destroy is a no-op
+    assert lib.efe_habit(C.c_void_p(h), C.c_void_p(s.data_ptr()), 4, None, None, None, None) == 1
+    assert b'stale' in lib.efe_last_error(C.c_void_p(h))
+    lib.efe_destroy(C.c_void_p(h))
+    # device discipline
+    m2 = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=3, init_weights=False)
+    m2.load_flat_weights(weights_cache(1234, 1.15))
+    with pytest.raises(NotImplementedError):
+        ops.habit(m2._ready().h, torch.zeros(4, 10))                # CPU tensors: no CPU kernel is registered (no fallback)
+    if torch.cuda.device_count() >= 2:
+        with pytest.raises(RuntimeError, match='device'):
+            ops.habit(m2._ready().h, torch.zeros(4, 10, device='cuda:1'))
+        m3 = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:1', seed=3, init_weights=False)
+        m3.load_flat_weights(weights_cache(1234, 1.15))
+        torch.cuda.set_device(0)
+        q3 = m3.model_top.encode_s(torch.zeros(4, 10, device='cuda:1'))[1]
+        assert torch.cuda.current_device() == 0                    # the call ran on GPU 1 and put the caller's device back
+        assert torch.equal(q3.cpu(), q_live.cpu())
+    dev = C.c_int(-1)
+    assert lib.efe_get_device(m2._engine.ctx, C.byref(dev), None, 0) == 0 and dev.value == 0
+
+
 def test_reserve_no_growth(models):
     """efe_reserve + efe_rollout_scratch_bytes: after reserving for a rollout size, calls at that size never grow the arena"""
     import daimc_amd
@@ -1071,7 +1184,7 @@ def test_torch_ops_are_the_dispatch_path(models):
 
 
 # ------------------------------------------------------------------------------------------------------
-# efe_set_row_mask: early-stopped episodes are skipped by the per-image kernels, live rows do not change
+# efe_rows.mask: early-stopped episodes are skipped by the per-image kernels, live rows do not change
 # ------------------------------------------------------------------------------------------------------
 def test_row_mask_live_rows_are_bit_identical(models):
     m = models(1234, 1.15, 33)
@@ -1083,12 +1196,9 @@ def test_row_mask_live_rows_are_bit_identical(models):
     ref = m.calculate_G(s0, pi0, samples=3, stage=4)
     rsim = m.simulate_batch(starts, 3, use_means=False, stage=9)
     alive = torch.tensor([1, 0, 1, 1, 0], dtype=torch.uint8, device=m.device)
-    try:
-        m.set_row_mask(alive, A)
-        out = m.calculate_G(s0, pi0, samples=3, stage=4)
-        osim = m.simulate_batch(starts, 3, use_means=False, stage=9)
-    finally:
-        m.set_row_mask(None)
+    from daimc_amd.model import Rows
+    out = m.calculate_G(s0, pi0, samples=3, stage=4, rows=Rows(mask=alive, rows_per_entry=A))
+    osim = m.simulate_batch(starts, 3, use_means=False, stage=9, rows=Rows(mask=alive))
     rows = alive.bool().repeat_interleave(A)
     assert torch.equal(out[0][rows], ref[0][rows])                       # G
     for k in range(3):
@@ -1096,11 +1206,12 @@ def test_row_mask_live_rows_are_bit_identical(models):
     assert torch.equal(out[2][rows], ref[2][rows]) and torch.equal(out[4][rows], ref[4][rows])      # ps1, po1
     ep = alive.bool()
     assert torch.equal(osim[0][ep], rsim[0][ep]) and torch.equal(osim[1][ep], rsim[1][ep])
-    # and after clearing the mask everything is evaluated again
+    # the mask belonged to those calls only (ABI 6: no context state): a plain call evaluates everything again
     again = m.calculate_G(s0, pi0, samples=3, stage=4)
     assert torch.equal(again[0], ref[0])
+    assert not hasattr(m, 'set_row_mask')
     with pytest.raises(ValueError):
-        m.set_row_mask(torch.ones(5, dtype=torch.float32, device=m.device), A)
+        Rows(mask=torch.ones(5, dtype=torch.float32, device=m.device), rows_per_entry=A)
 
 
 def test_batched_mcts_skipping_stopped_episodes_changes_nothing(models):
@@ -1161,7 +1272,7 @@ def test_small_launch_image_split_is_bit_identical(models):
 
 def test_rows_are_an_argument_of_the_call_not_context_state(models):
     """ABI 4 (efe_rows): the liveness mask and the row identities belong to ONE call.  A masked call leaves the next plain call on the same
-    context untouched (with efe_set_row_mask it saw the mask until someone cleared it); a COMPACTED call -- only the live entries, as a
+    context untouched (with the efe_set_row_mask shim of ABI 2 - 5 it saw the mask until someone cleared it); a COMPACTED call -- only the live entries, as a
     dense batch with their ids -- returns bit for bit the rows of the full batch (noise keys follow the entry id, not the slot), for
     calculate_G, calculate_G_mean and simulate_batch, with device noise and with injected noise."""
     from daimc_amd.model import Rows

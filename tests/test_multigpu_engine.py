@@ -137,7 +137,7 @@ def test_bench_launcher_at_n_ranks_on_one_device(n):
     rehearsal of the 8-GPU line, which needs a multi-GPU node).  Without --share-device the same command REFUSES to put two ranks on one
     GPU (bench.py Ranks.check_devices: efe_get_device of every rank's engine context, gathered)."""
     d = _bench_line(['--gpus', str(n), '--share-device', '--no-extras', '--no-prof', '--steps', '2', '--warmup', '1', '--min-seconds', '0.5'], 1200)
-    assert d['n_gpus'] == n and d['rccl_ranks'] == n and d['backend'] == 'gloo' and d.get('share_device') is True
+    assert d['n_gpus'] == n and d['ranks'] == n and 'rccl_ranks' not in d and d['backend'] == 'gloo' and d.get('share_device') is True
     assert len(d['per_rank_ms_per_step']) == n and d['all_gather_ms'] > 0 and d['scaling'] == 'weak'
     assert len(d['devices']) == n and all(dev[0] == 0 and dev[1] == d['devices'][0][1] and len(dev[1]) >= 7 for dev in d['devices'])
     assert d['cpu_baseline']['value'] > 0

@@ -231,6 +231,47 @@ def test_oracle_planner_early_stop_at_benchmark_depth_vs_reference(golden, weigh
     _check_planner_fixture(g, e, (got[0], got[1], got[2], got[3], got[4], got[5].numpy()))
 
 
+def _params_of(g, MO):
+    return MO.Params(repeats=int(g['repeats']), simulation_depth=int(g['simulation_depth']), simulation_repeats=int(g['simulation_repeats']),
+                     use_means=bool(g['use_means']), threshold=float(g['threshold']), C=float(g['C']), samples=int(g['samples']))
+
+
+@pytest.mark.parametrize('name,e', [('mcts_defaults', 4), ('mcts_defaults', 1), ('mcts_defaults_full', 2)])
+def test_oracle_planner_at_the_reference_defaults(golden, weights_cache, name, e):
+    """the reference planner with MCTS_Params() UNTOUCHED (mcts.py:139-148: 300 repeats, depth 3, use_means -> calculate_G_mean expansions,
+    threshold 0.5; oracle/make_golden_defaults.py): episode 4 stops before iteration 177, episode 1 before 21; with the stop out of reach
+    (mcts_defaults_full) every episode grows the full 1 + 4 * 301 = 1 205-node tree.  The GPU suite runs every episode."""
+    from oracle import mcts_oracle as MO
+    g = golden(name)
+    m = _oracle(g, weights_cache)
+    p = _params_of(g, MO)
+    d = MO.Params()
+    if name == 'mcts_defaults':          # the fixture's parameters ARE the defaults
+        assert all(getattr(p, k) == getattr(d, k) for k in ('C', 'threshold', 'repeats', 'simulation_repeats', 'simulation_depth', 'use_means', 'samples'))
+        assert sorted(int(x) for x in g['repeats_done']) == [21, 65, 145, 177, 233, 300]
+        r = int(g['repeats_done'][e])
+        ts = g['thr_stat'][e][:r + 1]
+        assert ts[-1] > 0.5 and (ts[:-1] <= 0.5).all()
+    else:
+        assert (g['repeats_done'] == 300).all() and (g['n_nodes'] == 1 + 4 * 301).all()
+    got = MO.plan(m, torch.from_numpy(g['frames'][e]), p, int(g['stage']), episode=e)
+    _check_planner_fixture(g, e, (got[0], got[1], got[2], got[3], got[4], got[5].numpy()))
+
+
+@pytest.mark.parametrize('e', [0, 3])
+def test_oracle_planner_two_simulations_per_iteration(golden, weights_cache, e):
+    """simulation_repeats = 2 (mcts.py:185-189: the mean of the simulations is back-propagated, the leaf keeps the LAST simulation's Qpi) at
+    the benchmark's depth; episode 3 stops before iteration 45"""
+    from oracle import mcts_oracle as MO
+    g = golden('mcts_simrep2_s10')
+    m = _oracle(g, weights_cache)
+    p = _params_of(g, MO)
+    assert p.simulation_repeats == 2 and [int(x) for x in g['repeats_done']] == [50, 50, 50, 45]
+    assert (g['states_explored'] == g['n_paths'] * p.simulation_depth * 2).all()
+    got = MO.plan(m, torch.from_numpy(g['frames'][e]), p, int(g['stage']), episode=e)
+    _check_planner_fixture(g, e, (got[0], got[1], got[2], got[3], got[4], got[5].numpy()))
+
+
 @pytest.mark.parametrize('e', [0, 1])
 def test_oracle_planner_prior_with_ten_samples_vs_reference(golden, weights_cache, e):
     """using_prior_for_exploration (mcts.py:44-45) together with Node.expand(samples=10) and use_habit (shortcut evaluated, not taken)"""

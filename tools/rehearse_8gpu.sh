@@ -14,7 +14,7 @@ import json
 for f in ('gpus8_share', 'force_dist'):
     try:
         d = json.loads(open('gpurun_out/rehearse/%s.json' % f).read().strip().splitlines()[-1])
-        print(f, {k: d.get(k) for k in ('value', 'n_gpus', 'rccl_ranks', 'backend', 'per_rank_ms_per_step', 'all_gather_ms')},
+        print(f, {k: d.get(k) for k in ('value', 'n_gpus', 'rccl_ranks', 'ranks', 'backend', 'per_rank_ms_per_step', 'all_gather_ms')},
               'roofline' in d, 'cpu_baseline' in d, sorted(d.get('extras', {})))
     except Exception as e:
         print(f, 'ERR', e)
