@@ -95,8 +95,11 @@ struct efe_ctx {
     int64_t mfma_bf16x3 = 0;       // OPT-IN EXPERIMENT (bf16x3.hip): Linear(256, 16384) of the decoder on the bf16 pipe, operands split in three bf16 planes
     uint16_t* fc4_b3 = nullptr;    // its packed planes (part of wbufs)
     uint16_t* ct_b3[2] = {nullptr, nullptr};      // po_net.13 / .15 (k_dec_a's layers) as bf16 planes
+    uint16_t* ct3_b3 = nullptr;                   // po_net.17 (ConvT3, k_dec_b_b3) as bf16 planes
+    int64_t b3_convt3 = 1;                        // mfma_bf16x3: ConvT3 on the bf16 pipe too (0 = the fp32 k_dec_b4 behind the two bf16 kernels, round 5's form)
     bool arch_gfx950 = false;      // hipDeviceProp_t.gcnArchName starts with gfx950 (checked at creation)
     int64_t sim_split = 1;         // simulations of <= 16 episodes: the chain kernel on eight workgroups per 8 episodes (k_sim_chain<8>); 0 = one workgroup (A/B, bit-identical)
+    bool sim_sync_dirty = false;   // the last split launch's call did not complete on the host: zero sim_sync before the next one
     float* sim_xch = nullptr; int* sim_sync = nullptr;      // its exchange buffer and arrival counters / sticky timeout flag (owned; zeroed on the stream before every split launch)
     int64_t check_rows = 0;        // development: range-check efe_rows.ids on the host before every _rows call
     int64_t last_macs = 0;
@@ -496,7 +499,8 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         db.rows = c; db.live = live_of(nc, m0); db.m0 = m0; db.rows_per_group = nc.rows_per_group; db.gm = nc.gm; db.reward0 = reward0; db.store0 = store0;
         db.val = val; db.parts = split ? 4 : 1; db.valq = split ? val : nullptr; db.po = po_store; db.reward_intent = (int)ctx->reward_intent;
         e0 = ctx->prof_begin(st);
-        launch_dec_b(db, st);
+        if (ctx->mfma_bf16x3 && ctx->b3_convt3 && ctx->ct3_b3 && !split) { db.w3b3 = ctx->ct3_b3; launch_dec_b_b3(db, st); }      // opt-in experiment
+        else launch_dec_b(db, st);
         ctx->prof_end(e0, st);
     }
     ctx->cls = PROF_OTHER;
@@ -851,11 +855,12 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
         // with everything else; the option is on only after every plane exists: a failure part-way leaves the experiment off, not half-enabled)
         if (value && ctx->committed && !ctx->fc4_b3) {
             HIPCHK(hipSetDevice(ctx->device));
-            if (pack_fc4_b3(ctx)) { ctx->fc4_b3 = nullptr; ctx->ct_b3[0] = ctx->ct_b3[1] = nullptr; ctx->mfma_bf16x3 = 0; return 1; }
+            if (pack_fc4_b3(ctx)) { ctx->fc4_b3 = nullptr; ctx->ct_b3[0] = ctx->ct_b3[1] = nullptr; ctx->ct3_b3 = nullptr; ctx->mfma_bf16x3 = 0; return 1; }
         }
         ctx->mfma_bf16x3 = value ? 1 : 0;
         return 0;
     }
+    if (!strcmp(name, "b3_convt3")) { ctx->b3_convt3 = value ? 1 : 0; return 0; }
     if (!strcmp(name, "arena_align")) { if (value < 256 || (value & (value - 1))) return ctx->fail("arena_align must be a power of two >= 256"); ctx->arena_align = value; return 0; }
     if (!strcmp(name, "mid_unfused")) { ctx->mid_unfused = value; return 0; }
     if (!strcmp(name, "head_unfused")) { ctx->head_unfused = value; return 0; }
@@ -882,6 +887,14 @@ static int pack_fc4_b3(efe_ctx* ctx) {
         HIPCHK(hipMalloc((void**)&ctx->ct_b3[i], cp.size() * 2)); ctx->wbufs.push_back(ctx->ct_b3[i]);
         HIPCHK(hipMemcpy(ctx->ct_b3[i], cp.data(), cp.size() * 2, hipMemcpyHostToDevice));
     }
+    {
+        const HostTensor* cw = need(ctx, "down.po_net.17.weight", {64, 32, 3, 3});
+        if (!cw) return 1;
+        std::vector<uint16_t> cp((size_t)4 * 9 * 3 * 64 * 8);
+        pack_convt3_bf16x3(cw->data.data(), cp.data());
+        HIPCHK(hipMalloc((void**)&ctx->ct3_b3, cp.size() * 2)); ctx->wbufs.push_back(ctx->ct3_b3);
+        HIPCHK(hipMemcpy(ctx->ct3_b3, cp.data(), cp.size() * 2, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -893,7 +906,7 @@ int efe_commit_weights(efe_ctx* ctx) {
         HIPCHK(hipDeviceSynchronize());
         for (void* p : ctx->wbufs) (void)hipFree(p);
         ctx->wbufs.clear();
-        ctx->fc4_b3 = nullptr; ctx->ct_b3[0] = ctx->ct_b3[1] = nullptr;
+        ctx->fc4_b3 = nullptr; ctx->ct_b3[0] = ctx->ct_b3[1] = nullptr; ctx->ct3_b3 = nullptr;
     }
     ctx->committed = false;
     const int A = ctx->pi_dim;
@@ -1429,15 +1442,21 @@ int efe_simulate_rows(efe_ctx* ctx, const float* starting_s, int E, int depth, i
     float* trp = ctx->allocT<float>((size_t)2 * E * T * 32);
     float* pre_tr = ctx->mid_unfused ? nullptr : trp;
     if (!s0t || !ps1t || !mt || !lvt || !Gt || !trp) return 1;
+    bool split_launch = false;
     {   // the whole habit-policy rollout (depth x (encode_s, sample, transition, reparameterise)) is one launch (fused.hip)
         SimChainArgs sa{};
         sa.W = ctx->mid16; sa.H = ctx->top16; sa.s0 = starting_s; sa.E = E; sa.T = T; sa.use_means = use_means;
         sa.k0 = k0; sa.k1 = k1; sa.stage = nz->stage; sa.row_offset = nz->row_offset;
         sa.eps_inj = eps; sa.u_inj = u; sa.ids = rs.ids;
         if (ctx->sim_split && (E + SIM_FE - 1) / SIM_FE <= SIM_MAX_SPLIT_GROUPS) {
-            // the split form's arrival counters and sticky timeout flag start every launch at zero, whatever the previous launch did
+            // The split form's arrival counters and sticky timeout flag re-arm themselves at the end of a launch.  Whenever the previous
+            // split call did not reach its end on the host (an error behind the kernel's enqueue) they are zeroed on the stream first --
+            // not before every launch: a 32-byte hipMemsetAsync costs ~25 us of the 400 us a one-episode planner iteration takes.
             sa.xch = ctx->sim_xch; sa.sync = ctx->sim_sync;
-            if (hipMemsetAsync(ctx->sim_sync, 0, (size_t)SIM_MAX_SPLIT_GROUPS * 4 * sizeof(int), st) != hipSuccess) return ctx->fail("efe_simulate: sim_sync memset failed");
+            if (ctx->sim_sync_dirty && hipMemsetAsync(ctx->sim_sync, 0, (size_t)SIM_MAX_SPLIT_GROUPS * 4 * sizeof(int), st) != hipSuccess)
+                return ctx->fail("efe_simulate: sim_sync memset failed");
+            ctx->sim_sync_dirty = true;             // cleared where this call has enqueued everything and found no launch error
+            split_launch = true;
         }
         sa.s0_traj = s0t; sa.ps1_traj = ps1t; sa.mean_traj = mt; sa.lv_traj = lvt; sa.pi0 = pi0; sa.Qpi0 = Qpi0; sa.pi_dim = ctx->pi_dim; sa.tr = pre_tr;
         ctx->cls = PROF_MID;
@@ -1450,7 +1469,9 @@ int efe_simulate_rows(efe_ctx* ctx, const float* starting_s, int E, int depth, i
     if (trajectory_impl(ctx, s0t, ps1t, mt, lvt, pi0, E * T, k0, k1, nz->stage, nz->row_offset * (uint32_t)T,
                         eps ? eps + (size_t)T * E * 10 : nullptr, Gt, rs.mask, rs.ids, T, pre_tr, st)) return 1;     // trajectory row e * T + t belongs to episode slot e
     launch_mean_rows(Gt, G_mean, E, T, st);
-    return finish(ctx, st);
+    const int rc = finish(ctx, st);
+    if (rc == 0 && split_launch) ctx->sim_sync_dirty = false;
+    return rc;
 }
 
 int efe_action_posterior(efe_ctx* ctx, const float* sum_G, int n_groups, int n, float temperature, float* P, float* logP, void* stream) {

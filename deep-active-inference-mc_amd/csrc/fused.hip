@@ -185,9 +185,10 @@ __device__ __forceinline__ float4 hidden16_slice(const float4* __restrict__ Wp, 
 // all NWG workgroups of the group have stored their slice of xbuf -> the full [16][512] activation in LDS (act_out).
 // A peer that does not arrive within the spin bound (~0.3 s) must never produce a silently wrong rollout: the workgroup that timed out
 // raises the group's STICKY flag (sync[2], agent scope) before it goes on -- i.e. before it publishes any further slice or arrival -- and
-// every workgroup re-reads the flag behind each gather: *bad is set in all of them, whichever one saw the timeout, and the writer poisons
-// every output of the launch (k_sim_chain's epilogue).  The counters are zeroed on the stream in front of every split launch
-// (engine.hip), so a launch that was cut short cannot leave the next one's barriers open.
+// the writer reads the flag behind its last gather (k_sim_chain's epilogue): whichever workgroup saw the timeout, at whichever exchange,
+// the writer poisons every output of the launch.  The words re-arm themselves at the end of a launch; after a call that failed the
+// engine zeroes them on the stream before the next split launch (engine.hip, sim_sync_dirty), so a launch that was cut short cannot
+// leave the next one's barriers open.
 template <int NWG>
 __device__ __forceinline__ void xchg_gather(const float* xbuf, int* sync, int target, float4* act_out, int tid, int* bad) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's slice stores are acknowledged (write-through)
@@ -196,10 +197,9 @@ __device__ __forceinline__ void xchg_gather(const float* xbuf, int* sync, int ta
         __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
         while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(1);
-        int sticky = 0;
-        if (spins >= (1 << 18)) sticky = 1 | __hip_atomic_fetch_or(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (returning form: complete before the next arrival)
-        else sticky = __hip_atomic_load(sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (sticky) *bad = 1;
+        // (returning form: the flag is set before this workgroup's next arrival, and every arrival of the LAST exchange precedes the
+        // writer's read of the flag in the epilogue -- one read per launch, not one per gather: an agent-scope round trip costs ~1 us)
+        if (spins >= (1 << 18)) *bad = 1 | __hip_atomic_fetch_or(sync + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t xr = rsrc16(xbuf);
@@ -425,6 +425,14 @@ __global__ void __launch_bounds__(256, 1) k_sim_chain(const SimChainArgs a) {
                     if (e < E) a.tr[(size_t)pass * E * T * 32 + (size_t)e0 * T * 32 + r] = qnan;
                 }
             if (a.Qpi0 && tid < SIM_FE * A && e0 + tid / A < E) a.Qpi0[(size_t)e0 * A + tid] = qnan;
+        }
+        // the last workgroup of the group to get here re-arms the arrival counter, the exit counter and the sticky flag for the next launch
+        // (all NWG have passed every exchange and read the flag by then).  A launch that never gets here -- the call failed behind the
+        // kernel's enqueue -- is covered by the engine: it zeroes the words on the stream before the next split launch (sim_sync_dirty).
+        if (tid == 0 && __hip_atomic_fetch_add(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NWG - 1) {
+            __hip_atomic_store(sync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

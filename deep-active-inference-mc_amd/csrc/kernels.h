@@ -128,6 +128,7 @@ struct DecBArgs {
     float* valq;
     float* po;            // [slots][rows_per_group][4096] stored images
     int reward_intent;    // 0 = the shipped port's NCHW-broadcast reward target, 1 = the upstream-intent variant (reward_term below)
+    const void* w3b3 = nullptr;      // option mfma_bf16x3: ConvT3's weights as bf16 planes [4 ks][9 taps][3][64 lanes][8] (bf16x3.hip, k_dec_b_b3)
 };
 // fused encoder trunk: o [rows][64][64] -> conv1..conv4 (+ReLU) -> out [rows][576] in NHWC (p*64 + c) order
 struct EncArgs {
@@ -145,6 +146,8 @@ void launch_fc4_b3(const GemmArgs& a, hipStream_t st);   // the same on the bf16
 void pack_bf16x3(const float* W, const int* row_perm, int out, int in, uint16_t* dst);
 void launch_dec_a_b3(const DecAArgs& a, hipStream_t st);  // k_dec_a's two layers on the bf16 pipe, every operand through LDS (opt-in experiment)
 void pack_conv_bf16x3(const float* W_cicokk, int Cin, int Cout, uint16_t* dst);
+void launch_dec_b_b3(const DecBArgs& a, hipStream_t st);  // k_dec_b4's layers with ConvT3 on the bf16 pipe (opt-in experiment)
+void pack_convt3_bf16x3(const float* W_cicokk, uint16_t* dst);
 int init_bf16x3_kernels();
 void launch_dec_a(const DecAArgs& a, hipStream_t st);
 void launch_dec_b(const DecBArgs& a, hipStream_t st);

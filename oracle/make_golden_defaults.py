@@ -13,7 +13,9 @@ The reference planner at ITS OWN DEFAULTS and with several simulations per itera
                        Qpi is the LAST simulation's) at the benchmark's depth: 10-sample expansions, depth-5 simulations, 50 iterations,
                        threshold 0.5 (early stops included)
 
-Episode e draws its noise at global rows 4e+a (expansions), e (root encode, simulate steps) and e*depth+t (trajectory); one noise stage
+Fixture episode k is planned as GLOBAL episode e = episode_ids[k] (the default-parameter cases keep the index a frame had in the probe
+batch, so that the probed margins hold): it draws its noise at global rows 4e+a (expansions), e (root encode, simulate steps) and
+e*depth+t (trajectory) -- what the lock-step planner uses for episode e of a batch (or a one-episode batch at episode_offset e); one noise stage
 per engine-level call in the reference's call order (root encode, root expansion, then per iteration the expansion and each simulation).
 Fixtures hold tensors only.
 
@@ -42,8 +44,9 @@ DEFAULTS = dict(C=1.0, threshold=0.5, repeats=300, simulation_repeats=1, simulat
                 using_prior_for_exploration=False)
 
 
-def run_case(model, inj, ref_mcts, state, *, frames, samples, stage0, configure, record_stat=None):
-    """`configure(params)` edits a fresh MCTS_Params() (None: untouched).  -> dict of arrays, report"""
+def run_case(model, inj, ref_mcts, state, *, frames, samples, stage0, configure, record_stat=None, ids=None):
+    """`configure(params)` edits a fresh MCTS_Params() (None: untouched); `ids[k]` = the GLOBAL episode index fixture episode k is planned as
+    (its noise rows: 4 id + a, id, id * depth + t; default k).  -> dict of arrays, report"""
     orig_expand, orig_init, orig_ct = ref_mcts.Node.expand, ref_mcts.Node.__init__, ref_mcts.calc_threshold
     created = []
 
@@ -59,8 +62,18 @@ def run_case(model, inj, ref_mcts, state, *, frames, samples, stage0, configure,
         if record_stat is not None:
             record_stat.append(float(v))
         return v
+    orig_pfs = ref_mcts.Node.probs_for_selection
+    margins = []                                                 # (top score - runner-up) of every tree-policy decision of the current episode
+
+    def probs_rec(self):                                         # a recording wrapper: returns the reference's value
+        v = orig_pfs(self)
+        t2 = torch.topk(torch.nan_to_num(v.detach().float(), nan=-1e30), 2).values
+        margins.append(float(t2[0] - t2[1]))
+        return v
     ref_mcts.Node.expand, ref_mcts.Node.__init__, ref_mcts.calc_threshold = expand_s, init_capture, calc_threshold_rec
+    ref_mcts.Node.probs_for_selection = probs_rec
     E = frames.shape[0]
+    ids = list(range(E)) if ids is None else [int(i) for i in ids]
     p0 = ref_mcts.MCTS_Params()
     if configure is not None:
         configure(p0)
@@ -70,6 +83,7 @@ def run_case(model, inj, ref_mcts, state, *, frames, samples, stage0, configure,
     ag = np.zeros((E, R), dtype=np.float64); npaths = np.zeros(E, dtype=np.int64)
     repd = np.zeros(E, dtype=np.int64); expl = np.zeros(E, dtype=np.int64); rootN = np.zeros((E, 4), dtype=np.float32)
     nodes = np.zeros(E, dtype=np.int64); maxlen = np.zeros(E, dtype=np.int64)
+    sel_margin = np.full((E, R), np.inf, dtype=np.float32)       # per iteration: the smallest decision margin along its selection path
     try:
         for e in range(E):
             params = ref_mcts.MCTS_Params()
@@ -77,41 +91,56 @@ def run_case(model, inj, ref_mcts, state, *, frames, samples, stage0, configure,
                 assert all(getattr(params, k) == v for k, v in DEFAULTS.items()), vars(params)
             else:
                 configure(params)
-            state['ro'], state['episode'] = 4 * e, e
+            gid = ids[e]
+            state['ro'], state['episode'] = 4 * gid, gid
             inj.stage = stage0
-            inj.p_enc(PX.PASS_ROOT, 0, inj.stage, e, with_eps=False); inj.stage += 1
+            inj.p_enc(PX.PASS_ROOT, 0, inj.stage, gid, with_eps=False); inj.stage += 1
             del created[:]
+            del margins[:]
             frame = torch.from_numpy(frames[e, 0][:, :, None].copy())
             t = time.time()
             path, reps, explored, all_paths, all_G = ref_mcts.active_inference_mcts(model, frame, params, o_shape=(1, 64, 64))
             assert not inj.q
             fp[e, :len(path)] = [int(x) for x in path]
+            k = 0
             for i, p_ in enumerate(all_paths):
                 assert len(p_) <= ap.shape[2]
                 ap[e, i, :len(p_)] = [int(x) for x in p_]
+                sel_margin[e, i] = min(margins[k:k + len(p_)])       # select() evaluates one decision per action of the path (mcts.py:49-62)
+                k += len(p_)
+            assert k == len(margins)
             ag[e, :len(all_G)] = all_G
             npaths[e], repd[e], expl[e] = len(all_paths), reps, explored
             rootN[e] = created[0].N.numpy()
             nodes[e] = len(created); maxlen[e] = max(len(p_) for p_ in all_paths)
-            print(f'episode {e}: {time.time() - t:.1f} s, reps {reps}, nodes {len(created)}, longest path {maxlen[e]}, final {path}', flush=True)
+            print(f'episode {e} (global {gid}): {time.time() - t:.1f} s, reps {reps}, nodes {len(created)}, longest path {maxlen[e]}, final {path}', flush=True)
     finally:
         ref_mcts.Node.expand, ref_mcts.Node.__init__, ref_mcts.calc_threshold = orig_expand, orig_init, orig_ct
+        ref_mcts.Node.probs_for_selection = orig_pfs
         state['ro'], state['episode'] = 0, 0
-    arrs = dict(frames=frames, episodes=E, samples=samples, repeats=R, simulation_depth=depth, simulation_repeats=int(p0.simulation_repeats),
+    arrs = dict(frames=frames, episode_ids=np.asarray(ids, dtype=np.int64), episodes=E, samples=samples, repeats=R, simulation_depth=depth, simulation_repeats=int(p0.simulation_repeats),
                 use_means=int(bool(p0.use_means)), threshold=float(p0.threshold), C=float(p0.C), stage=stage0,
                 using_prior_for_exploration=int(bool(p0.using_prior_for_exploration)), use_habit=int(bool(p0.use_habit)),
                 final_path=fp, all_paths=ap, all_paths_G=ag, n_paths=npaths, repeats_done=repd, states_explored=expl, root_N=rootN,
-                n_nodes=nodes, wseed=WSEED, gain=GAIN, nseed=NSEED)
-    return arrs, dict(reps=[int(x) for x in repd], nodes=[int(x) for x in nodes], longest_path=[int(x) for x in maxlen])
+                n_nodes=nodes, sel_margin=sel_margin, wseed=WSEED, gain=GAIN, nseed=NSEED)
+    return arrs, dict(reps=[int(x) for x in repd], nodes=[int(x) for x in nodes], longest_path=[int(x) for x in maxlen],
+                      min_margin=[float(sel_margin[e, :npaths[e]].min()) for e in range(E)])
 
 
-# frames of the default-parameter cases: the first six of synth.make_frames(FRAME_SEED, PROBE_N).  `--probe` (all 16 frames, stop
-# disabled, statistic recorded) says where each threshold would stop them:
-#   threshold 0.5  stops at [300, 21, 145, 65, 177, 233, 21, 21, 300, 141, 21, 21, 161, 29, 45, 300]
-#   threshold 0.4  stops at [251, 14, 28, 42, 105, 48, 14, 14, 300, 31, 14, 14, 99, 19, 25, 300]
-# -> at the reference's default 0.5, frames 0 - 5 give one episode that never stops, three that run >= 145 iterations, two early stops
-FRAME_SEED, PROBE_N = 31, 16
-PICKED = [0, 1, 2, 3, 4, 5]
+# Frames of the default-parameter cases, picked from `--probe` (synth.make_frames(FRAME_SEED, PROBE_N), stop disabled, the stop statistic
+# and every tree-policy decision's margin -- best score minus runner-up -- recorded).  A 300-iteration episode takes ~2 000 argmax
+# decisions over scores in [0, 1 + C/N]; the engine's G differs from the CPU reference's by up to ~1e-3 in fp32 (tests/test_gpu_parity.py
+# tolerances), which moves a score by up to ~1e-5: an episode whose smallest margin is below that is a coin flip for ANY other fp32
+# implementation (it would not even reproduce across two BLAS builds), so the fixtures use episodes whose smallest margin is >= 5e-5 and
+# store the margins (`sel_margin`, per iteration) so that the tests can state it.  Probe table (40 frames):
+#   stop at threshold 0.5:     [300, 21, 145, 65, 177, 233, 21, 21, 300, 141, 21, 21, 161, 29, 45, 300, 181, 33, 25, 89, 109, 121, 69, 21, 157,
+#                               65, 21, 145, 57, 69, 21, 65, 21, 33, 101, 125, 141, 21, 217, 33]
+#   smallest margin up to it:  frames 15: 7.4e-5 (never stops), 38: 1.4e-4 (217), 4: 1.3e-4 (177), 35: 3.3e-4 (125), 3: 6.0e-5 (65), 1: 2.8e-3 (21)
+#   smallest margin, 300 its:  frames 15: 7.4e-5, 18: 6.2e-5, 17: 5.7e-5      (28 of the 40 frames are below 3e-5 somewhere in 300 iterations)
+FRAME_SEED, PROBE_N = 31, 40
+PICKED = [15, 38, 4, 35, 3, 1]            # mcts_defaults: stops at [300 (never), 217, 177, 125, 65, 21]
+PICKED_FULL = [15, 18, 17]                # mcts_defaults_full: 300 iterations each
+MIN_MARGIN = 5e-5
 
 
 def no_stop(p):
@@ -137,15 +166,22 @@ def main():
         s = np.array(stat).reshape(PROBE_N, 300)
         for t in (0.3, 0.4, 0.45, 0.5, 0.55, 0.6):
             print('threshold', t, 'stops at', [int(np.argmax(r > t)) if (r > t).any() else 300 for r in s])
+        stop05 = [int(np.argmax(r > 0.5)) if (r > 0.5).any() else 300 for r in s]
+        mg = arrs['sel_margin']
+        print('smallest decision margin over 300 iterations   ', ['%.1e' % mg[e].min() for e in range(PROBE_N)])
+        print('... up to the stop of the default threshold 0.5', ['%.1e' % mg[e, :max(1, stop05[e])].min() for e in range(PROBE_N)])
         return
     mpath = os.path.join(GOLD, 'MANIFEST.json')
     manifest = json.load(open(mpath))
     report = {}
     frames = all_frames[PICKED]
     stat = []
-    arrs, report['mcts_defaults'] = run_case(model, inj, ref_mcts, state, frames=frames, samples=1, stage0=1000, configure=None, record_stat=stat)
+    arrs, report['mcts_defaults'] = run_case(model, inj, ref_mcts, state, frames=frames, samples=1, stage0=1000, configure=None, record_stat=stat,
+                                              ids=PICKED)
+    arrs.update(frame_seed=FRAME_SEED, n_frames=PROBE_N)
     reps = report['mcts_defaults']['reps']
-    assert any(r >= 150 for r in reps) and any(r < 150 for r in reps), reps
+    assert reps == [300, 217, 177, 125, 65, 21], reps
+    assert min(report['mcts_defaults']['min_margin']) >= MIN_MARGIN, report
     ts = np.full((len(PICKED), 300), np.nan, dtype=np.float32)          # one check per started iteration (+ the one that stops the episode)
     k = 0
     for e, r in enumerate(reps):
@@ -155,10 +191,13 @@ def main():
     assert k == len(stat)
     arrs['thr_stat'] = ts
     save('mcts_defaults', arrs, manifest)
-    arrs, report['mcts_defaults_full'] = run_case(model, inj, ref_mcts, state, frames=frames[:3], samples=1, stage0=1000, configure=no_stop)
-    assert all(r == 300 for r in report['mcts_defaults_full']['reps'])
+    arrs, report['mcts_defaults_full'] = run_case(model, inj, ref_mcts, state, frames=all_frames[PICKED_FULL], samples=1, stage0=1000, configure=no_stop,
+                                                   ids=PICKED_FULL)
+    arrs.update(frame_seed=FRAME_SEED, n_frames=PROBE_N)
+    assert all(r == 300 for r in report['mcts_defaults_full']['reps']) and min(report['mcts_defaults_full']['min_margin']) >= MIN_MARGIN, report
     save('mcts_defaults_full', arrs, manifest)
     arrs, report['mcts_simrep2_s10'] = run_case(model, inj, ref_mcts, state, frames=synth.make_frames(32, 4), samples=10, stage0=2000, configure=simrep2)
+    arrs.update(frame_seed=32, n_frames=4)
     save('mcts_simrep2_s10', arrs, manifest)
     manifest['default_planner_cases'] = ('mcts_defaults, mcts_defaults_full, mcts_simrep2_s10: oracle/make_golden_defaults.py '
                                          '(same shim and injection as make_golden.py)')

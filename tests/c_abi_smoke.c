@@ -104,7 +104,7 @@ static int fixture_check(efe_ctx* ctx, const char* wpath, const char* bpath) {
 
 int main(int argc, char** argv) {
     efe_ctx* ctx = NULL;
-    if (efe_abi_version() != 5) { fprintf(stderr, "abi version\n"); return 1; }
+    if (efe_abi_version() != 6) { fprintf(stderr, "abi version\n"); return 1; }
     if (efe_create(&ctx, 0)) { fprintf(stderr, "efe_create failed (no HIP device?)\n"); return 2; }
     CHECK(lin(ctx, "top.qpi_net.0", 128, 10)); CHECK(lin(ctx, "top.qpi_net.2", 128, 128)); CHECK(lin(ctx, "top.qpi_net.4", 4, 128));
     CHECK(lin(ctx, "mid.ps_net.0", 512, 14)); CHECK(lin(ctx, "mid.ps_net.3", 512, 512)); CHECK(lin(ctx, "mid.ps_net.6", 512, 512));

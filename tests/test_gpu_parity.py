@@ -573,11 +573,14 @@ def _fixture_params(g):
 def test_planner_at_the_reference_defaults_and_with_two_simulations(golden, models, name):
     """The reference planner's OWN default call (mcts.py:139-148: 300 repeats, simulation depth 3, use_means -> calculate_G_mean expansions,
     threshold 0.5; `MCTS_Params()` untouched on both sides) and simulation_repeats = 2 (mcts.py:185-189), captured from the reference
-    (oracle/make_golden_defaults.py).  mcts_defaults: six episodes that stop before iterations 300 (never), 21, 145, 65, 177, 233;
+    (oracle/make_golden_defaults.py).  mcts_defaults: six episodes that stop before iterations 300 (never), 217, 177, 125, 65, 21;
     mcts_defaults_full: the stop out of reach, 1 205-node trees = the lock-step planner's node capacity, 300-entry path history;
     mcts_simrep2_s10: 10-sample expansions, depth-5 simulations, two simulations per iteration, one early stop.
-    Compared: repeats_done, states_explored, every path, the G history, the final path, the root visit counts -- through the lock-step
-    planner on all episodes, the single-episode API (host Node tree) and each episode alone on the device planner."""
+    Fixture episode k is GLOBAL episode episode_ids[k] of the batch synth.make_frames(frame_seed, n_frames) (the episodes were picked from
+    a 40-frame probe for decision margins >= 5e-5: a 300-iteration episode takes ~2 000 argmax decisions, and an fp32-level difference in
+    G -- 1e-3 -- moves a score by ~1e-5).  Compared: repeats_done, states_explored, every path, the G history, the final path, the root
+    visit counts -- through the lock-step planner on the WHOLE batch (the other episodes plan alongside) and each fixture episode alone
+    on the device planner at its global episode offset."""
     import daimc_amd
     g = golden(name)
     m = inject(_model(g, models))
@@ -586,24 +589,28 @@ def test_planner_at_the_reference_defaults_and_with_two_simulations(golden, mode
         d = daimc_amd.MCTS_Params()
         assert all(getattr(p, k) == getattr(d, k) for k in vars(d)), 'the fixture is the reference default call'
         p = d                                                     # literally the untouched default object
-    E = int(g['episodes'])
-    frames = torch.from_numpy(g['frames'])
+    ids = [int(i) for i in g['episode_ids']]
+    batch = synth.make_frames(int(g['frame_seed']), int(g['n_frames']))
+    assert np.array_equal(batch[ids], g['frames'])
+    E = batch.shape[0]
     m._stage = int(g['stage'])
-    out, visits = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
+    out, visits = daimc_amd.active_inference_mcts_batch(m, torch.from_numpy(batch), p, o_shape=(1, 64, 64))
     planner = next(pl for pl in m._planners.values() if pl.E == E and pl.p.repeats == p.repeats and pl.p.simulation_repeats == p.simulation_repeats)
-    assert planner.cap == 1 + 4 * (p.repeats + 2) and int(planner.n_nodes.max()) == int(g['n_nodes'].max()) <= planner.cap
-    for e in range(E):
-        _check_deep(g, e, out[e], visits[e])
-    # episode 0 through the reference-shaped single-episode API on the host Node tree (all its noise rows start at 0) ...
-    m._stage = int(g['stage'])
-    p.host_tree = True
-    _check_deep(g, 0, daimc_amd.active_inference_mcts(m, frames[0], p, o_shape=(1, 64, 64)))
-    p.host_tree = False
-    # ... and the longest-running and the earliest-stopping episode alone on the device planner at their global episode offsets
-    for e in sorted({int(np.argmax(g['repeats_done'])), int(np.argmin(g['repeats_done']))}):
+    assert planner.cap == 1 + 4 * (p.repeats + 2) and int(planner.n_nodes.max()) <= planner.cap
+    for k, e in enumerate(ids):
+        _check_deep(g, k, out[e], visits[e])
+    assert int(planner.n_nodes[ids].max()) == int(g['n_nodes'].max())
+    # the longest-running and the earliest-stopping fixture episode alone on the device planner (the reference's one-episode call shape)
+    for k in sorted({int(np.argmax(g['repeats_done'])), int(np.argmin(g['repeats_done']))}):
         m._stage = int(g['stage'])
-        out1, v1 = daimc_amd.active_inference_mcts_batch(m, frames[e:e + 1], p, o_shape=(1, 64, 64), episode_offset=e)
-        _check_deep(g, e, out1[0], v1[0])
+        out1, v1 = daimc_amd.active_inference_mcts_batch(m, torch.from_numpy(g['frames'][k:k + 1]), p, o_shape=(1, 64, 64), episode_offset=ids[k])
+        _check_deep(g, k, out1[0], v1[0])
+    if ids[0] == 0:
+        # episode 0 through the reference-shaped single-episode API on the host Node tree (all its noise rows start at 0)
+        m._stage = int(g['stage'])
+        p.host_tree = True
+        _check_deep(g, 0, daimc_amd.active_inference_mcts(m, torch.from_numpy(g['frames'][0]), p, o_shape=(1, 64, 64)))
+        p.host_tree = False
 
 
 @pytest.mark.parametrize('name', ['mcts_defaults', 'mcts_simrep2_s10'])
@@ -614,14 +621,16 @@ def test_lockstep_batch_of_64_at_the_reference_defaults_contains_the_reference_e
     g = golden(name)
     m = inject(_model(g, models))
     p = _fixture_params(g)
-    E, E0 = 64, int(g['episodes'])
-    frames = torch.cat([torch.from_numpy(g['frames']), torch.from_numpy(synth.make_frames(79, E - E0))], 0)
+    ids = [int(i) for i in g['episode_ids']]
+    batch = synth.make_frames(int(g['frame_seed']), int(g['n_frames']))
+    E = 64
+    frames = torch.cat([torch.from_numpy(batch), torch.from_numpy(synth.make_frames(79, E - batch.shape[0]))], 0)
     m._stage = int(g['stage'])
     out, visits = daimc_amd.active_inference_mcts_batch(m, frames, p, o_shape=(1, 64, 64))
     planner = next(pl for pl in m._planners.values() if pl.E == E and pl.p.repeats == p.repeats and pl.p.simulation_repeats == p.simulation_repeats)
     assert planner.overlap and planner._ids is not None and len(planner._ids[1]) < E          # stopped episodes were compacted out
-    for e in range(E0):
-        _check_deep(g, e, out[e], visits[e])
+    for k, e in enumerate(ids):
+        _check_deep(g, k, out[e], visits[e])
     np.testing.assert_allclose(visits.sum(1).numpy(), 1.0, rtol=1e-6)
     assert all(o_[2] == len(o_[3]) * p.simulation_depth * p.simulation_repeats for o_ in out)
 
