@@ -433,31 +433,40 @@ constexpr size_t DBB_LDS = DBB_H + (size_t)DBB_YROWS * 2 * 3 * 64 * sizeof(float
 
 #define DBB_MFMA(ACC, AF, BF) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AF), __builtin_bit_cast(bf16x8, BF), ACC, 0, 0, 0)
 
-// One 16-channel step of wave (r, PH).  slab: this step's weights + lane * 16; bv[v]: the wave's four views (pixel byte address + g * 16
-// + ks * 32).  Products in the order (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi): small terms first.
-template <int PH>
-__device__ __forceinline__ void dbb_step(f32x16 (&acc)[3], const unsigned char* slab, const unsigned char* const (&bv)[4]) {
+// The four 16-channel steps of a strip for wave (r, PH).  abase: weight buffer 0 + lane * 16 (step ks in buffer ks & 1); bv[v]: the wave's
+// four views (pixel byte address + g * 16).  sync(ks) = "slab ks has landed for everybody" (drain + barrier + the next slab's DMA request).
+// Per step the taps go as PAIRS on different accumulators (a third accumulator takes the odd tap: no two consecutive MFMAs share a chain):
+//   PH = 1: (7 -> 0 | 8 -> 1) on view 0, (1 -> 0 | 2 -> 1) on view 2, (6 -> 1 on view 1 | 0 -> 2 on view 3)
+//   PH = 0: (4 -> 0 | 5 -> 1) on view 0, (3 on view 1, its products alternating between accumulators 1 and 2)
+// (packed tap index kh * 3 + kw; views 0 = (r, j)  1 = (r, j + 1)  2 = (r + 1, j)  3 = (r + 1, j + 1)).  The fragments of a pair are read
+// between the MFMAs of the pair before it -- ACROSS the step boundary too: sync(ks + 1) sits in front of the LAST pair of step ks, whose
+// fragments are in registers by then, so the first pair of a step never starts with a burst of twelve exposed reads (that cost 12 % of the
+// kernel: profiles/r6_dec_b_b3_ablation.txt).  Products in the order (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi): small terms first.
+template <int PH, class Sync>
+__device__ __forceinline__ void dbb_strip(f32x16 (&acc)[3], const unsigned char* abase, const unsigned char* const (&bv)[4], Sync sync) {
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-    // pairs (tap X -> accumulator aX, tap Y -> aY); packed tap index kh * 3 + kw, views 0 = (r, j)  1 = (r, j + 1)  2 = (r + 1, j)  3 = (r + 1, j + 1)
-    //   PH = 1: (7 -> 0 | 8 -> 1) on view 0, (1 -> 0 | 2 -> 1) on view 2, (6 -> 1 on view 1 | 0 -> 2 on view 3)
-    //   PH = 0: (4 -> 0 | 5 -> 1) on view 0, (3 on view 1, its products alternating between accumulators 1 and 2)
     constexpr int NP = PH ? 3 : 2;
     constexpr int TX[3] = {PH ? 7 : 4, PH ? 1 : 3, 6}, TY[3] = {PH ? 8 : 5, PH ? 2 : 3, 0};
     constexpr int VX[3] = {0, PH ? 2 : 1, 1}, VY[3] = {0, PH ? 2 : 1, 3};
     constexpr int AX[3] = {0, PH ? 0 : 1, 1}, AY[3] = {1, PH ? 1 : 2, 2};
     float4 ax[2][3], ay[2][3], bx[2][3], by[2][3];
-    auto ld = [&](int i, int l, float4 (&axn)[3], float4 (&ayn)[3], float4 (&bxn)[3], float4 (&byn)[3]) {       // fragment read l of pair i
+    auto ld = [&](int ks, int i, int l, float4 (&axn)[3], float4 (&ayn)[3], float4 (&bxn)[3], float4 (&byn)[3]) {       // fragment read l of pair i of step ks
+        const unsigned char* slab = abase + (ks & 1) * DBB_SLAB;
         const int k = l / 3, p = l % 3;
         if (k == 0) axn[p] = *reinterpret_cast<const float4*>(slab + (TX[i] * 3 + p) * 1024);
-        else if (k == 1) bxn[p] = *reinterpret_cast<const float4*>(bv[VX[i]] + p * 128);
+        else if (k == 1) bxn[p] = *reinterpret_cast<const float4*>(bv[VX[i]] + p * 128 + ks * 32);
         else if (k == 2) { if (TY[i] != TX[i]) ayn[p] = *reinterpret_cast<const float4*>(slab + (TY[i] * 3 + p) * 1024); }
-        else { if (VY[i] != VX[i]) byn[p] = *reinterpret_cast<const float4*>(bv[VY[i]] + p * 128); }
+        else { if (VY[i] != VX[i]) byn[p] = *reinterpret_cast<const float4*>(bv[VY[i]] + p * 128 + ks * 32); }
     };
+    sync(0);
 #pragma unroll
-    for (int l = 0; l < 12; ++l) ld(0, l, ax[0], ay[0], bx[0], by[0]);
+    for (int l = 0; l < 12; ++l) ld(0, 0, l, ax[0], ay[0], bx[0], by[0]);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int c = i & 1, n = c ^ 1;
+    for (int q = 0; q < 4 * NP; ++q) {
+        const int i = q % NP, c = q & 1, n = c ^ 1;
+        const int qn = q + 1, ksn = qn / NP, in_ = qn % NP;
+        const bool more = qn < 4 * NP;
+        if (more && in_ == 0) sync(ksn);
         const bool sameT = TY[i] == TX[i], sameV = VY[i] == VX[i];
 #pragma unroll
         for (int m = 0; m < 12; ++m) {
@@ -469,7 +478,7 @@ __device__ __forceinline__ void dbb_step(f32x16 (&acc)[3], const unsigned char* 
                 if (pr & 1) DBB_MFMA(acc[AY[i]], ax[c][PA[pr]], bx[c][PB[pr]]);
                 else DBB_MFMA(acc[AX[i]], ax[c][PA[pr]], bx[c][PB[pr]]);
             }
-            if (i + 1 < NP) ld(i + 1, m, ax[n], ay[n], bx[n], by[n]);
+            if (more) ld(ksn, in_, m, ax[n], ay[n], bx[n], by[n]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -481,22 +490,15 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
     float* sH = reinterpret_cast<float*>(smb + DBB_H);          // [ring row][channel half][kh][64 output columns]
     __shared__ float4 sb3[8];
     __shared__ float4 sW4[8 * 12];
-    __shared__ float sred[NW];
+    __shared__ float sred[2][NW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int r = w & 3, ph = w >> 2;
-    const int img = (int)blockIdx.x;
-    if (!row_live(a.live, img)) return;
-
-    const int mg = a.m0 + img;
-    const int g = mg / a.rows_per_group;
-    const int rr = mg - g * a.rows_per_group;
-    int gt, gp, gs;
-    group_decode(a.gm, g, gt, gp, gs);
-    const int mode = (gp == 0 && a.reward0) ? 1 : 0;
-    const int slot = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
-    float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + rr) * 4096 : nullptr;
+    // persistent over images (one workgroup per CU: nothing else hides a workgroup's start-up): static stride, dead rows of the call skipped
+    auto next_live = [&](int i) { while (i < a.rows && !row_live(a.live, i)) i += (int)gridDim.x; return i; };
+    int img = next_live((int)blockIdx.x);
+    if (img >= a.rows) return;
 
     if (tid < 8) sb3[tid] = reinterpret_cast<const float4*>(a.b3)[tid];
     if (tid < 96) {                                              // the 4x4x1 tap table of k_dec_b4: pattern = h * 4 + kw, float4 i4 = (kh, g4)
@@ -507,11 +509,11 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
     const float4* w4p = sW4 + (h * 4 + (lane & 3)) * 12;
     if (tid < DBB_PXB / 4) reinterpret_cast<uint32_t*>(smb + DBB_ZPX * DBB_PXB)[tid] = 0u;
 
-    const f32x4* Xv = reinterpret_cast<const f32x4*>(a.y2) + (size_t)img * (32 * 32 * 16);
+    const f32x4* Y2 = reinterpret_cast<const f32x4*>(a.y2);
     auto y2_at = [&](int iy, int idx) -> size_t { return (size_t)(((iy & 1) * 16 + ((idx & 511) >> 5)) * 512 + (iy >> 1) * 32 + (idx & 31)); };
     f32x4 pf[NPF];
 #pragma unroll
-    for (int it = 0; it < NPF; ++it) pf[it] = Xv[y2_at(min(it, 31), tid)];
+    for (int it = 0; it < NPF; ++it) pf[it] = Y2[(size_t)img * (32 * 32 * 16) + y2_at(it, tid)];
     // weight slabs by LDS-DMA: piece i (1 KiB) of a slab is copied by wave i & 7
     const char* Wg = reinterpret_cast<const char*>(a.w3b3) + lane * 16;
     const unsigned lds_w0 = (unsigned)(size_t)(smb + DBB_W0);
@@ -535,151 +537,171 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
     const unsigned char* abase = smb + DBB_W0 + lane * 16;
 
     const float D1 = 1.00001f, D0 = 0.00001f;
-    float part = 0.f;
-    float gh[6], gpr = 0.f;
-    // ---- gather of output row oh (lane = column), k_dec_b4's: out = b4 + H[0][oh + 1] + H[1][oh] + H[2][oh - 1], channel halves added here
-    auto g_load = [&](int oh, int r0y, int hb0) {
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int tr = oh + 1 - kh;
-            const bool rv = tr >= 0 && tr <= 63;
-            int hs = hb0 + (tr - r0y);
-            hs = hs < 0 ? hs + DBB_YROWS : hs;
-            hs = hs >= DBB_YROWS ? hs - DBB_YROWS : hs;
-            hs = rv ? hs : 0;
-            const float* hq = sH + ((hs * 2) * 3 + kh) * 64 + lane;
-            gh[2 * kh] = hq[0]; gh[2 * kh + 1] = hq[3 * 64];
-        }
-    };
-    auto g_sig = [&](int oh) {
-        float v = a.b4;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int tr = oh + 1 - kh;
-            v += (tr >= 0 && tr <= 63) ? gh[2 * kh] + gh[2 * kh + 1] : 0.f;
-        }
-        gpr = hw_sigmoid(v);
-    };
-    auto g_term = [&](int oh) {
-#pragma clang fp contract(off)
-        const float pr = gpr;
-        const float l1 = hw_log(D1 - pr), l0 = hw_log(D0 + pr);
-        const float te = __builtin_fmaf(pr - 1.0f, l1, -(pr * l0));
-        const float tw = reward_term(pr, oh, lane, 64, 64, a.reward_intent);
-        const float t = mode == 0 ? te : tw;
-        part += oh >= 0 ? t : 0.0f;
-    };
-    auto g_store = [&](int oh) {
-        if (po && oh >= 0) {
-            int owl = lane; asm volatile("" : "+v"(owl));
-            (po + oh * 64)[owl] = gpr;
-        }
-    };
-
-    int hb = 0, hbp = 0;
+    int hb = 0, hbp = 0, nimgs = 0;
 #pragma unroll 1
-    for (int s = 0; s < NS; ++s) {
-        const int oh0 = 2 * SR * (s - 1) - 1 + w;             // this wave's output row of the previous strip (deferred gather)
-        // ---- stage the strip: thread -> (row it, pixel ix, channel quad c4) of k_dec_b4's y2 addressing, split into planes
-#pragma unroll
-        for (int it = 0; it < NPF; ++it) {
-            const int seg = tid >> 5, wi = tid & 31;
-            const int ix = 2 * (wi >> 1) + (seg >> 3), c4 = 2 * (seg & 7) + (wi & 1);
-            const bool in = SR * s + it < 32;
-            put_planes(smb + (size_t)(it * 32 + ix) * DBB_PXB, 4 * c4, in ? pf[it][0] : 0.f, in ? pf[it][1] : 0.f, in ? pf[it][2] : 0.f, in ? pf[it][3] : 0.f);
-        }
-        f32x16 acc[3];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            glds_drain();                                     // this wave's pieces of slab ks have landed ...
-            __syncthreads();                                  // ... and everybody's (ks = 0: the staged strip too); nobody reads the other buffer any more
-            if (ks == 0) {
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {              // accumulators start at the bias (register e holds channel (e & 3) + 8 (e >> 2) + 4 h)
-                    const float4 bb = sb3[2 * g4 + h];
-                    acc[0][4 * g4] = bb.x; acc[0][4 * g4 + 1] = bb.y; acc[0][4 * g4 + 2] = bb.z; acc[0][4 * g4 + 3] = bb.w;
-                }
-                acc[1] = acc[0];
-                acc[2] = (f32x16)(0.f);
-            }
-            if (ks < 3 || s + 1 < NS) slab_dma((ks + 1) & 3, (ks + 1) & 1);
-            if (ks == 3) {                                    // the next strip's rows, behind the slab request
-#pragma unroll
-                for (int it = 0; it < NPF; ++it) pf[it] = Xv[y2_at(min(SR * (s + 1 < NS ? s + 1 : s) + it, 31), tid)];
-            }
-            const unsigned char* slab = abase + (ks & 1) * DBB_SLAB;
-            const unsigned char* bv[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) bv[v] = smb + (size_t)spx[v] * DBB_PXB + h * 16 + ks * 32;
-            if (ph) dbb_step<1>(acc, slab, bv); else dbb_step<0>(acc, slab, bv);
-            if (s > 0) {                                      // the previous strip's gather, a piece per step
-                if (ks == 0) g_load(oh0, 2 * SR * (s - 1), hbp);
-                if (ks == 1) g_sig(oh0);
-                if (ks == 2) g_term(oh0);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[1][e] += acc[2][e];
-        // ---- ReLU, then the 32 -> 1 conv as tap planes on the accumulators (k_dec_b4's tail for this wave's row parity ph)
-        float w4g[3][16];
-#pragma unroll
-        for (int i4 = 0; i4 < 12; ++i4) {
-            const float4 q = w4p[i4];
-            w4g[i4 >> 2][4 * (i4 & 3)] = q.x; w4g[i4 >> 2][4 * (i4 & 3) + 1] = q.y; w4g[i4 >> 2][4 * (i4 & 3) + 2] = q.z; w4g[i4 >> 2][4 * (i4 & 3) + 3] = q.w;
-        }
-        {
-            f32x4 Tq[2][3];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[0][e] = relu_bits(acc[0][e]); acc[1][e] = relu_bits(acc[1][e]); }
-#pragma unroll
-            for (int pw = 0; pw < 2; ++pw)
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) Tq[pw][kh] = (f32x4)(0.f);
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    Tq[0][kh] = __builtin_amdgcn_mfma_f32_4x4x1f32(w4g[kh][e], acc[0][e], Tq[0][kh], 0, 0, 0);
-                    Tq[1][kh] = __builtin_amdgcn_mfma_f32_4x4x1f32(w4g[kh][e], acc[1][e], Tq[1][kh], 0, 0, 0);
-                }
-            int hsw = hb + 2 * r + ph;                        // ring slot of this wave's y3 row 2 (SR s + r) + ph
-            hsw = hsw >= DBB_YROWS ? hsw - DBB_YROWS : hsw;
-            float* hp = sH + ((hsw * 2 + h) * 3) * 64 + 2 * j;
+    for (; img < a.rows; ++nimgs) {
+        const int nimg = next_live(img + (int)gridDim.x);
+        const int mg = a.m0 + img;
+        const int g = mg / a.rows_per_group;
+        const int rr = mg - g * a.rows_per_group;
+        int gt, gp, gs;
+        group_decode(a.gm, g, gt, gp, gs);
+        const int mode = (gp == 0 && a.reward0) ? 1 : 0;
+        const int slot = (gp == 0 && a.store0) ? gt * a.gm.S + gs : -1;
+        float* po = (slot >= 0) ? a.po + ((size_t)slot * a.rows_per_group + rr) * 4096 : nullptr;
+        float part = 0.f;
+        float gh[2][6], gpr[2] = {0.f, 0.f};
+        // ---- gather of output row oh (lane = column), k_dec_b4's: out = b4 + H[0][oh + 1] + H[1][oh] + H[2][oh - 1], channel halves added here
+        auto g_load = [&](int oh, int q, int r0y, int hb0) {
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                float l = wave_shr1(Tq[1][kh][2]), rgt = wave_shl1(Tq[0][kh][0]);
-                l = (j == 0) ? 0.f : l;
-                rgt = (j == 31) ? 0.f : rgt;
-                float2 eo;
-                eo.x = (Tq[1][kh][0] + Tq[0][kh][1]) + l;
-                eo.y = (rgt + Tq[1][kh][1]) + Tq[0][kh][2];
-                *reinterpret_cast<float2*>(hp + kh * 64) = eo;
+                const int tr = oh + 1 - kh;
+                const bool rv = tr >= 0 && tr <= 63;
+                int hs = hb0 + (tr - r0y);
+                hs = hs < 0 ? hs + DBB_YROWS : hs;
+                hs = hs >= DBB_YROWS ? hs - DBB_YROWS : hs;
+                hs = rv ? hs : 0;
+                const float* hq = sH + ((hs * 2) * 3 + kh) * 64 + lane;
+                gh[q][2 * kh] = hq[0]; gh[q][2 * kh + 1] = hq[3 * 64];
             }
+        };
+        auto g_sig = [&](int oh, int q) {
+            float v = a.b4;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int tr = oh + 1 - kh;
+                v += (tr >= 0 && tr <= 63) ? gh[q][2 * kh] + gh[q][2 * kh + 1] : 0.f;
+            }
+            gpr[q] = hw_sigmoid(v);
+        };
+        auto g_term = [&](int oh, int q) {
+#pragma clang fp contract(off)
+            const float pr = gpr[q];
+            const float l1 = hw_log(D1 - pr), l0 = hw_log(D0 + pr);
+            const float te = __builtin_fmaf(pr - 1.0f, l1, -(pr * l0));
+            const float tw = reward_term(pr, oh, lane, 64, 64, a.reward_intent);
+            const float t = mode == 0 ? te : tw;
+            part += oh >= 0 ? t : 0.0f;
+        };
+        auto g_store = [&](int oh, int q) {
+            if (po && oh >= 0) {
+                int owl = lane; asm volatile("" : "+v"(owl));
+                (po + oh * 64)[owl] = gpr[q];
+            }
+        };
+#pragma unroll 1
+        for (int s = 0; s < NS; ++s) {
+            const int oh0 = 2 * SR * (s - 1) - 1 + r, oh1 = oh0 + 4;      // the light waves' two output rows of the previous strip (deferred gather)
+            // ---- stage the strip: thread -> (row it, pixel ix, channel quad c4) of k_dec_b4's y2 addressing, split into planes
+#pragma unroll
+            for (int it = 0; it < NPF; ++it) {
+                const int seg = tid >> 5, wi = tid & 31;
+                const int ix = 2 * (wi >> 1) + (seg >> 3), c4 = 2 * (seg & 7) + (wi & 1);
+                const bool in = SR * s + it < 32;
+                put_planes(smb + (size_t)(it * 32 + ix) * DBB_PXB, 4 * c4, in ? pf[it][0] : 0.f, in ? pf[it][1] : 0.f, in ? pf[it][2] : 0.f, in ? pf[it][3] : 0.f);
+            }
+            f32x16 acc[3];
+            const bool last = s + 1 == NS;
+            auto sync = [&](int ks) {
+                glds_drain();                                     // this wave's pieces of slab ks have landed ...
+                __syncthreads();                                  // ... and everybody's (ks = 0: the staged strip too); nobody reads the other buffer any more
+                if (ks == 0) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {              // accumulators start at the bias (register e holds channel (e & 3) + 8 (e >> 2) + 4 h)
+                        const float4 bb = sb3[2 * g4 + h];
+                        acc[0][4 * g4] = bb.x; acc[0][4 * g4 + 1] = bb.y; acc[0][4 * g4 + 2] = bb.z; acc[0][4 * g4 + 3] = bb.w;
+                    }
+                    acc[1] = acc[0];
+                    acc[2] = (f32x16)(0.f);
+                }
+                if (ks < 3 || !last || nimg < a.rows) slab_dma((ks + 1) & 3, (ks + 1) & 1);
+                if (ks == 3) {                                    // the next strip's rows (the next image's first strip behind the last one), behind the slab request
+                    const size_t ib = (size_t)(last ? (nimg < a.rows ? nimg : img) : img) * (32 * 32 * 16);
+                    const int r0 = last ? 0 : SR * (s + 1);
+#pragma unroll
+                    for (int it = 0; it < NPF; ++it) pf[it] = Y2[ib + y2_at(min(r0 + it, 31), tid)];
+                }
+                // the previous strip's gather, a piece per step, on the LIGHT waves (ph = 0: half the matrix work of their SIMD partners)
+                if (s > 0 && ph == 0) {
+                    if (ks == 1) { g_load(oh0, 0, 2 * SR * (s - 1), hbp); g_load(oh1, 1, 2 * SR * (s - 1), hbp); }
+                    if (ks == 2) { g_sig(oh0, 0); g_term(oh0, 0); }
+                    if (ks == 3) { g_sig(oh1, 1); g_term(oh1, 1); }
+                }
+            };
+            const unsigned char* bv[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bv[v] = smb + (size_t)spx[v] * DBB_PXB + h * 16;
+            if (ph) dbb_strip<1>(acc, abase, bv, sync); else dbb_strip<0>(acc, abase, bv, sync);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[1][e] += acc[2][e];
+            // ---- ReLU, then the 32 -> 1 conv as tap planes on the accumulators (k_dec_b4's tail for this wave's row parity ph)
+            float w4g[3][16];
+#pragma unroll
+            for (int i4 = 0; i4 < 12; ++i4) {
+                const float4 q = w4p[i4];
+                w4g[i4 >> 2][4 * (i4 & 3)] = q.x; w4g[i4 >> 2][4 * (i4 & 3) + 1] = q.y; w4g[i4 >> 2][4 * (i4 & 3) + 2] = q.z; w4g[i4 >> 2][4 * (i4 & 3) + 3] = q.w;
+            }
+            {
+                f32x4 Tq[2][3];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc[0][e] = relu_bits(acc[0][e]); acc[1][e] = relu_bits(acc[1][e]); }
+#pragma unroll
+                for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) Tq[pw][kh] = (f32x4)(0.f);
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        Tq[0][kh] = __builtin_amdgcn_mfma_f32_4x4x1f32(w4g[kh][e], acc[0][e], Tq[0][kh], 0, 0, 0);
+                        Tq[1][kh] = __builtin_amdgcn_mfma_f32_4x4x1f32(w4g[kh][e], acc[1][e], Tq[1][kh], 0, 0, 0);
+                    }
+                int hsw = hb + 2 * r + ph;                        // ring slot of this wave's y3 row 2 (SR s + r) + ph
+                hsw = hsw >= DBB_YROWS ? hsw - DBB_YROWS : hsw;
+                float* hp = sH + ((hsw * 2 + h) * 3) * 64 + 2 * j;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    float l = wave_shr1(Tq[1][kh][2]), rgt = wave_shl1(Tq[0][kh][0]);
+                    l = (j == 0) ? 0.f : l;
+                    rgt = (j == 31) ? 0.f : rgt;
+                    float2 eo;
+                    eo.x = (Tq[1][kh][0] + Tq[0][kh][1]) + l;
+                    eo.y = (rgt + Tq[1][kh][1]) + Tq[0][kh][2];
+                    *reinterpret_cast<float2*>(hp + kh * 64) = eo;
+                }
+            }
+            __syncthreads();
+            if (s > 0 && ph == 0) { g_store(oh0, 0); g_store(oh1, 1); }
+            if (s == NS - 1) {                                    // the last strip's own rows (and row 63 behind it)
+#pragma unroll
+                for (int q = 0; q <= 1; ++q) {
+                    if (q == 1 && w != 0) break;
+                    const int oh = 2 * SR * s - 1 + q * NW + w;
+                    g_load(oh, 0, 2 * SR * s, hb); g_sig(oh, 0); g_term(oh, 0); g_store(oh, 0);
+                }
+            }
+            hbp = hb;
+            hb += 2 * SR;
+            hb = hb >= DBB_YROWS ? hb - DBB_YROWS : hb;
         }
+        // the image's sum: wave-wise, then (((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7))); the partials alternate between two LDS rows, so
+        // the only barrier is the one behind the NEXT image's first staging (the last image: an own barrier)
+        float v = part;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) sred[nimgs & 1][w] = v;
         __syncthreads();
-        if (s > 0) g_store(oh0);
-        if (s == NS - 1) {                                    // the last strip's own rows (and row 63 behind it)
-#pragma unroll
-            for (int q = 0; q <= 1; ++q) {
-                if (q == 1 && w != 0) break;
-                const int oh = 2 * SR * s - 1 + q * NW + w;
-                g_load(oh, 2 * SR * s, hb); g_sig(oh); g_term(oh); g_store(oh);
-            }
+        if (tid == 0) {
+            const float* q = sred[nimgs & 1];
+            a.val[mg] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
         }
-        hbp = hb;
-        hb += 2 * SR;
-        hb = hb >= DBB_YROWS ? hb - DBB_YROWS : hb;
+        img = nimg;
     }
-    float v = part;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) sred[w] = v;
-    __syncthreads();
-    if (tid == 0) a.val[mg] = ((sred[0] + sred[1]) + (sred[2] + sred[3])) + ((sred[4] + sred[5]) + (sred[6] + sred[7]));
 }
 
 void launch_dec_b_b3(const DecBArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_dec_b_b3, dim3(a.rows), dim3(512), DBB_LDS, st, a);
+    const int grid = a.rows < 256 ? a.rows : 256;        // persistent: one workgroup per CU
+    hipLaunchKernelGGL(k_dec_b_b3, dim3(grid), dim3(512), DBB_LDS, st, a);
 }
 
 // ConvT3 weights for k_dec_b_b3: [Cin = 64][Cout = 32][3][3] -> [ks = Cin / 16][tap][3 planes][64 lanes][8 bf16]
