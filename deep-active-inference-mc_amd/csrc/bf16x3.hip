@@ -16,6 +16,7 @@
 // ds_read_b128).  A wave owns 64 features x 64 rows per step (2 x 2 tiles of 32 x 32), the weights come as pre-split, fragment-major
 // planes [32-feature tile][16-channel step][plane][64 lanes][8 bf16] straight from L2 (1 KiB per wave-level load).  Fragment k order:
 // lane (x, g) holds channels 16 ks + 8 g .. + 7 of row / column x in BOTH operands (any common bijection contracts the same 16 channels).
+#include <cmath>
 #include "mfma_pipe.h"
 
 namespace efe {
@@ -32,8 +33,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 }
 __device__ __forceinline__ void glds_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-constexpr int B3_ROWB = 3 * 512 + 16;                 // bytes per staged row: three planes of 256 bf16 + padding
-constexpr size_t B3_LDS = (size_t)64 * B3_ROWB;       // 99 328 B: one workgroup per CU
+template <int NPL> struct Fc4L {
+    static constexpr int ROWB = NPL * 512 + 16;                   // bytes per staged row: NPL planes of 256 x 16 bit + padding
+    static constexpr size_t LDS = (size_t)64 * ROWB;              // 99 328 B (three planes): one workgroup per CU
+};
 
 // round-to-nearest-even fp32 -> bf16 (finite inputs), as the upper 16 bits
 __host__ __device__ inline uint32_t bf16_rne(float x) {
@@ -64,9 +67,67 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, uint32_t& hi, uint
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2_t));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The two operand splits the kernels below are instantiated for (engine options "mfma_bf16x3" / "mfma_f16x2"):
+//   SchB3: x = hi + mid + lo as three bf16 (3 x 8 mantissa bits), six products; error of an fp32 GEMM, every fixture at unchanged tolerances.
+//   SchH2: x = hi + lo as two fp16 (2 x 11 bits), three products  w_lo x_hi + w_hi x_lo + w_hi x_hi  on v_mfma_f32_32x32x16_f16 -- half
+//          the matrix work, two thirds of the operand bytes.  fp16 has 5 exponent bits: the WEIGHTS are scaled by a power of two at pack
+//          time (largest |w| just below 2^14; the kernels multiply the accumulators back, exactly) so that their low planes are normal
+//          numbers; activations stay unscaled -- the matrix pipe and v_cvt_pk_f16_f32 keep fp16 denormals (tools/ubench/f16_probe.hip), so
+//          an activation below 2^-3 loses at most 2^-25 absolutely -- and must stay below 65 504 (a larger one becomes inf -> NaN
+//          sums: loud, never silently wrong).  Operand representation error 2^-22 relative: tools/f16_split_check.py.
+// Plane 0 = hi.  PA / PB: the weight / activation plane of product pr, small terms first.
+// ---------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+struct SchB3 {
+    static constexpr int NPL = 3, NPR = 6, MODE = 1;
+    static constexpr bool SCALED = false;
+    static constexpr int PA(int pr) { constexpr int t[6] = {2, 0, 1, 1, 0, 0}; return t[pr]; }
+    static constexpr int PB(int pr) { constexpr int t[6] = {0, 2, 1, 0, 1, 0}; return t[pr]; }
+    static __device__ __forceinline__ f32x16 mfma(const float4& a, const float4& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void split_pk(float x0, float x1, uint32_t (&pl)[3]) { split3_pk(x0, x1, pl[0], pl[1], pl[2]); }
+};
+struct SchH2 {
+    static constexpr int NPL = 2, NPR = 3, MODE = 2;
+    static constexpr bool SCALED = true;
+    static constexpr int PA(int pr) { constexpr int t[3] = {1, 0, 0}; return t[pr]; }
+    static constexpr int PB(int pr) { constexpr int t[3] = {0, 1, 0}; return t[pr]; }
+    static __device__ __forceinline__ f32x16 mfma(const float4& a, const float4& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void split_pk(float x0, float x1, uint32_t (&pl)[2]) {
+        f32x2 v; v.x = x0; v.y = x1;
+        const f16x2_t hh = __builtin_convertvector(v, f16x2_t);           // v_cvt_pk_f16_f32: round to nearest even, denormals kept
+        pl[0] = __builtin_bit_cast(uint32_t, hh);
+        const f32x2 r = v - __builtin_convertvector(hh, f32x2);          // exact
+        pl[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
+    }
+};
+// host side: x (already scaled) -> NPL 16-bit planes
+inline void split_host(int mode, float x, uint32_t (&p)[3]) {
+    if (mode == 1) { split3(x, p[0], p[1], p[2]); return; }
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    p[0] = __builtin_bit_cast(uint16_t, hi); p[1] = __builtin_bit_cast(uint16_t, lo); p[2] = 0;
+}
+// the power of two the weights of a layer are multiplied by before the fp16 split: the largest magnitude lands in [2^13, 2^14)
+float split_weight_scale(int mode, const float* w, size_t n) {
+    if (mode != 2) return 1.0f;
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = fmaxf(mx, fabsf(w[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
+    int e; frexpf(mx, &e);                        // mx = f * 2^e, f in [0.5, 1)
+    return ldexpf(1.0f, 14 - e);
+}
+
 __host__ __device__ inline int fc4b3_spg(int mtiles) { return ((mtiles + 15) / 16 + 7) / 8; }     // steps of 16 feature tiles, dealt to 8 groups
 
+template <class SC>
 __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
+    constexpr int NPL = SC::NPL, B3_ROWB = Fc4L<SC::NPL>::ROWB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -100,12 +161,11 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
                 const int r = idx >> 6, c4 = idx & 63;
                 const int gr = row0 + r;
                 const f32x4 v = (gr < a.n_pix) ? X[(size_t)gr * 64 + c4] : (f32x4)(0.f);
-                uint32_t hi[2], mid[2], lo[2];
-                split3_pk(v[0], v[1], hi[0], mid[0], lo[0]); split3_pk(v[2], v[3], hi[1], mid[1], lo[1]);
+                uint32_t pa_[NPL], pb_[NPL];
+                SC::split_pk(v[0], v[1], pa_); SC::split_pk(v[2], v[3], pb_);
                 unsigned char* d = smb + (size_t)r * B3_ROWB + c4 * 8;
-                *reinterpret_cast<uint2*>(d) = make_uint2(hi[0], hi[1]);
-                *reinterpret_cast<uint2*>(d + 512) = make_uint2(mid[0], mid[1]);
-                *reinterpret_cast<uint2*>(d + 1024) = make_uint2(lo[0], lo[1]);
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(d + p * 512) = make_uint2(pa_[p], pb_[p]);
             }
             __syncthreads();
 #pragma unroll
@@ -133,16 +193,17 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) bq[mt][g4] = *reinterpret_cast<const float4*>(a.bias + (mt0 + mt) * 32 + 8 * g4 + 4 * g);
+        const float ws_inv = SC::SCALED ? a.wb3_scale_inv : 1.0f;        // fp16 split: the accumulators hold (weight scale) x W x
         // fragment of (tile mt, step ks, plane p): float4 index ((mt * 16 + ks) * 3 + p) * 64 + lane
-        auto afrag = [&](int mt, int ks, int p) -> float4 { return wfrag(wr, ln, (size_t)(((mt0 + mt) * 16 + ks) * 3 + p) * 64); };
+        auto afrag = [&](int mt, int ks, int p) -> float4 { return wfrag(wr, ln, (size_t)(((mt0 + mt) * 16 + ks) * NPL + p) * 64); };
         auto bfrag = [&](int nt, int ks, int p) -> float4 { return *reinterpret_cast<const float4*>(brow[nt] + p * 512 + ks * 32); };
         // fragments of step ks live in buffer set ks & 1; the loop is fully unrolled so that every index is static (hipcc copies a
         // software-pipeline buffer it cannot rename: 48 v_mov per step and an s_waitcnt vmcnt(0) on the loads that were meant to stay in flight)
-        float4 af[2][2][3], bf[2][2][3];
+        float4 af[2][2][NPL], bf[2][2][NPL];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) { af[0][t][p] = afrag(t, 0, p); bf[0][t][p] = bfrag(t, 0, p); }
+            for (int p = 0; p < NPL; ++p) { af[0][t][p] = afrag(t, 0, p); bf[0][t][p] = bfrag(t, 0, p); }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const int cb = ks & 1, nb = cb ^ 1;
@@ -150,19 +211,17 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) { af[nb][t][p] = afrag(t, ks + 1, p); bf[nb][t][p] = bfrag(t, ks + 1, p); }
+                    for (int p = 0; p < NPL; ++p) { af[nb][t][p] = afrag(t, ks + 1, p); bf[nb][t][p] = bfrag(t, ks + 1, p); }
             }
             __builtin_amdgcn_sched_barrier(0);
-            // the six products, smallest first: (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi); planes 0 = hi, 1 = mid, 2 = lo
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            // the products, smallest first (SchB3: (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi); SchH2: (lo, hi) (hi, lo) (hi, hi))
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
+            for (int pr = 0; pr < SC::NPR; ++pr)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[cb][mt][PA[pr]]), __builtin_bit_cast(bf16x8, bf[cb][nt][PB[pr]]),
-                                                                              acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = SC::mfma(af[cb][mt][SC::PA(pr)], bf[cb][nt][SC::PB(pr)], acc[mt][nt]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // epilogue: the same as k_fc4 (bias, ReLU, dropout mask from Philox, NHWC store)
@@ -178,8 +237,14 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
                     const int co = (mt0 + mt) * 32 + 8 * g4 + 4 * g;
                     const float4 bb = bq[mt][g4];
                     const uint32_t word = ((co >> 5) & 3) == 0 ? rnd.x : ((co >> 5) & 3) == 1 ? rnd.y : ((co >> 5) & 3) == 2 ? rnd.z : rnd.w;
-                    float v[4] = {acc[mt][nt][4 * g4 + 0] + bb.x, acc[mt][nt][4 * g4 + 1] + bb.y,
-                                  acc[mt][nt][4 * g4 + 2] + bb.z, acc[mt][nt][4 * g4 + 3] + bb.w};
+                    float v[4];
+                    if (SC::SCALED) {
+                        v[0] = __builtin_fmaf(acc[mt][nt][4 * g4 + 0], ws_inv, bb.x); v[1] = __builtin_fmaf(acc[mt][nt][4 * g4 + 1], ws_inv, bb.y);
+                        v[2] = __builtin_fmaf(acc[mt][nt][4 * g4 + 2], ws_inv, bb.z); v[3] = __builtin_fmaf(acc[mt][nt][4 * g4 + 3], ws_inv, bb.w);
+                    } else {
+                        v[0] = acc[mt][nt][4 * g4 + 0] + bb.x; v[1] = acc[mt][nt][4 * g4 + 1] + bb.y;
+                        v[2] = acc[mt][nt][4 * g4 + 2] + bb.z; v[3] = acc[mt][nt][4 * g4 + 3] + bb.w;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = ((word >> ((co + e) & 31)) & 1u) ? fmaxf(v[e], 0.f) * 2.0f : 0.0f;
                     *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
@@ -202,12 +267,14 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
 // the 4-wave 2 x 2 form (12 reads per 24 MFMAs, one wave per SIMD) is 2.5 % slower (tools/ubench/patches/da3_4waves.py).  y2 leaves in
 // k_dec_a's fp32 layout: k_dec_b4 is unchanged.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int DA3_PXB = 3 * 128 + 16;                   // bytes per staged pixel
-constexpr int DA3_IMG = 257 * DA3_PXB;                  // image + zero pixel
-constexpr int DA3_SLAB = 2 * 4 * 3 * 1024;              // one tap's weights: [2 mt][4 ks][3 planes][64 lanes][16 B]
-constexpr int DA3_W0 = (DA3_IMG + 255) & ~255;          // byte offset of weight buffer 0
-constexpr int DA3_BIAS = DA3_W0 + 2 * DA3_SLAB;         // two bias vectors (fp32)
-constexpr size_t DA3_LDS = DA3_BIAS + 2 * 64 * sizeof(float);
+template <int NPL_> struct Da3L {
+    static constexpr int PXB = NPL_ * 128 + 16;                 // bytes per staged pixel
+    static constexpr int IMG = 257 * PXB;                       // image + zero pixel
+    static constexpr int SLAB = 2 * 4 * NPL_ * 1024;            // one tap's weights: [2 mt][4 ks][NPL planes][64 lanes][16 B]
+    static constexpr int W0 = (IMG + 255) & ~255;               // byte offset of weight buffer 0
+    static constexpr int BIAS = W0 + 2 * SLAB;                  // two bias vectors (fp32)
+    static constexpr size_t LDS = BIAS + 2 * 64 * sizeof(float);
+};
 
 // NTW = 32-pixel tiles per wave: 2 -> four waves (one per SIMD, 2 x 2 register tiles), 1 -> eight waves (two per SIMD, 2 x 1 tiles: nine
 // fragment reads per 12 MFMAs instead of 12 per 24, but a second wave on every SIMD fills the pipe while the first one stages, splits,
@@ -215,10 +282,12 @@ constexpr size_t DA3_LDS = DA3_BIAS + 2 * 64 * sizeof(float);
 #ifndef EFE_DA3_NTW
 #define EFE_DA3_NTW 1
 #endif
-template <int NTW>
+template <class SC, int NTW>
 __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
-    constexpr int NW = 8 / NTW, NTHR = 64 * NW, NPF = 4096 / NTHR, PP = 24 / NW;      // waves, threads, float4 of an image per thread, DMA pieces per wave and tap
-    constexpr int MF = 12 * NTW, NL = 6 + 3 * NTW;                                     // MFMAs and fragment reads of one 16-channel step
+    constexpr int NPL = SC::NPL, NPR = SC::NPR;
+    constexpr int DA3_PXB = Da3L<NPL>::PXB, DA3_SLAB = Da3L<NPL>::SLAB, DA3_W0 = Da3L<NPL>::W0, DA3_BIAS = Da3L<NPL>::BIAS;
+    constexpr int NW = 8 / NTW, NTHR = 64 * NW, NPF = 4096 / NTHR, PP = 8 * NPL / NW;  // waves, threads, float4 of an image per thread, DMA pieces per wave and tap
+    constexpr int MF = 2 * NPR * NTW, NA = 2 * NPL, NL = NA + NPL * NTW;               // MFMAs and fragment reads (NA of them weights) of one 16-channel step
     extern __shared__ __attribute__((aligned(16))) unsigned char sm3[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -247,11 +316,10 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
     };
     // fp32 quad (4 consecutive channels c .. c + 3 of one pixel) -> the three planes of that pixel
     auto put_planes = [&](unsigned char* px, int c, const float v0, const float v1, const float v2, const float v3) {
-        uint32_t hi[2], mid[2], lo[2];
-        split3_pk(v0, v1, hi[0], mid[0], lo[0]); split3_pk(v2, v3, hi[1], mid[1], lo[1]);
-        *reinterpret_cast<uint2*>(px + c * 2) = make_uint2(hi[0], hi[1]);
-        *reinterpret_cast<uint2*>(px + 128 + c * 2) = make_uint2(mid[0], mid[1]);
-        *reinterpret_cast<uint2*>(px + 256 + c * 2) = make_uint2(lo[0], lo[1]);
+        uint32_t pa_[NPL], pb_[NPL];
+        SC::split_pk(v0, v1, pa_); SC::split_pk(v2, v3, pb_);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(px + p * 128 + c * 2) = make_uint2(pa_[p], pb_[p]);
     };
     f32x4 pf[NPF];                                       // the next image: 64 KiB / NTHR threads
     {
@@ -276,12 +344,13 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
         }
         slab_dma(W1, 0);
         f32x16 acc[2][NTW];
-        auto acc_init = [&](int boff) {                   // the accumulators start at the bias: register e of tile mt holds channel 32 mt + (e & 3) + 8 (e >> 2) + 4 g
+        auto acc_init = [&](int boff, float wsc) {        // the accumulators start at the bias (x the fp16 split's weight scale): register e of tile mt holds channel 32 mt + (e & 3) + 8 (e >> 2) + 4 g
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 bb = bias4[boff + mt * 8 + 2 * g4 + g];
+                    float4 bb = bias4[boff + mt * 8 + 2 * g4 + g];
+                    if (SC::SCALED) { bb.x *= wsc; bb.y *= wsc; bb.z *= wsc; bb.w *= wsc; }
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt) { acc[mt][nt][4 * g4] = bb.x; acc[mt][nt][4 * g4 + 1] = bb.y; acc[mt][nt][4 * g4 + 2] = bb.z; acc[mt][nt][4 * g4 + 3] = bb.w; }
                 }
@@ -301,34 +370,32 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
 #pragma unroll
                 for (int it = 0; it < NPF; ++it) pf[it] = X[it * NTHR + tid];
             }
-            float4 af[2][2][3], bf[2][NTW][3];
+            float4 af[2][2][NPL], bf[2][NTW][NPL];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) af[0][t][p] = *reinterpret_cast<const float4*>(ab + ((t * 4 + 0) * 3 + p) * 1024);
+                for (int t = 0; t < 2; ++t) af[0][t][p] = *reinterpret_cast<const float4*>(ab + ((t * 4 + 0) * NPL + p) * 1024);
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) bf[0][t][p] = *reinterpret_cast<const float4*>(sm3 + pb[t] + p * 128);
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int cb = ks & 1, nb = cb ^ 1;
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
                 for (int m = 0; m < MF; ++m) {
                     const int pr = m / (2 * NTW), mt = (m / NTW) & 1, nt = m % NTW;
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[cb][mt][PA[pr]]), __builtin_bit_cast(bf16x8, bf[cb][nt][PB[pr]]),
-                                                                          acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = SC::mfma(af[cb][mt][SC::PA(pr)], bf[cb][nt][SC::PB(pr)], acc[mt][nt]);
                     if (ks < 3) {
 #pragma unroll
                         for (int l = 0; l < NL; ++l) {
                             if (l * MF / NL != m) continue;
-                            if (l < 6) af[nb][l / 3][l % 3] = *reinterpret_cast<const float4*>(ab + (((l / 3) * 4 + ks + 1) * 3 + l % 3) * 1024);
-                            else bf[nb][(l - 6) / 3][(l - 6) % 3] = *reinterpret_cast<const float4*>(sm3 + pb[(l - 6) / 3] + ((l - 6) % 3) * 128 + (ks + 1) * 32);
+                            if (l < NA) af[nb][l / NPL][l % NPL] = *reinterpret_cast<const float4*>(ab + (((l / NPL) * 4 + ks + 1) * NPL + l % NPL) * 1024);
+                            else bf[nb][(l - NA) / NPL][(l - NA) % NPL] = *reinterpret_cast<const float4*>(sm3 + pb[(l - NA) / NPL] + ((l - NA) % NPL) * 128 + (ks + 1) * 32);
                         }
-                        if (next != nullptr) {
+                        if (next != nullptr) {                  // DMA piece p of the next slab: behind MFMA MF / 2 + p / 3 of step p % 3
 #pragma unroll
-                            for (int i = 0; i < PP / 3; ++i)
-                                if (m == MF / 2 + 3 * i) glds16(dsp + ((PP / 3) * ks + i) * 1024, ddp + (unsigned)(((PP / 3) * ks + i) * 1024));
+                            for (int pp = 0; pp < PP; ++pp)
+                                if (pp % 3 == ks && m == MF / 2 + pp / 3) glds16(dsp + pp * 1024, ddp + (unsigned)(pp * 1024));
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -336,7 +403,7 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
             }
         };
         // ---------------- layer 1: out[oh, ow] = sum_{kh, kw} in[oh + 1 - kh, ow + 1 - kw] . W[:, :, kh, kw] -------------------------------
-        acc_init(0);
+        acc_init(0, a.w1s);
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
             const int kh = t / 3, kw = t - kh * 3;
@@ -358,8 +425,11 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4)
-                        put_planes(px, mt * 32 + 8 * g4 + 4 * g, relu_bits(acc[mt][nt][4 * g4 + 0]), relu_bits(acc[mt][nt][4 * g4 + 1]),
-                                   relu_bits(acc[mt][nt][4 * g4 + 2]), relu_bits(acc[mt][nt][4 * g4 + 3]));
+                    {
+                        const float u = SC::SCALED ? a.w1s_inv : 1.0f;      // (fp16 split: the weight scale is undone before the activation is split again)
+                        put_planes(px, mt * 32 + 8 * g4 + 4 * g, SC::SCALED ? relu_bits(acc[mt][nt][4 * g4 + 0]) * u : relu_bits(acc[mt][nt][4 * g4 + 0]), SC::SCALED ? relu_bits(acc[mt][nt][4 * g4 + 1]) * u : relu_bits(acc[mt][nt][4 * g4 + 1]),
+                                   SC::SCALED ? relu_bits(acc[mt][nt][4 * g4 + 2]) * u : relu_bits(acc[mt][nt][4 * g4 + 2]), SC::SCALED ? relu_bits(acc[mt][nt][4 * g4 + 3]) * u : relu_bits(acc[mt][nt][4 * g4 + 3]));
+                    }
             }
         }
         // ---------------- layer 2 (stride 2): 4 output parities, oh = 2 ih - 1 + kh (the tap order of ConvT2Addr, mfma_pipe.h) ---------------
@@ -368,7 +438,7 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
 #pragma unroll 1
         for (int par = 0; par < 4; ++par) {
             const int ph = par >> 1, pw = par & 1;
-            acc_init(16);
+            acc_init(16, a.w2s);
             const int ntaps = (1 + ph) * (1 + pw);
 #pragma unroll 1
             for (int t = 0; t < ntaps; ++t, ++T) {
@@ -394,6 +464,7 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
                             float4 v;
                             v.x = relu_bits(acc[mt][nt][4 * g4 + 0]); v.y = relu_bits(acc[mt][nt][4 * g4 + 1]);
                             v.z = relu_bits(acc[mt][nt][4 * g4 + 2]); v.w = relu_bits(acc[mt][nt][4 * g4 + 3]);
+                            if (SC::SCALED) { v.x *= a.w2s_inv; v.y *= a.w2s_inv; v.z *= a.w2s_inv; v.w *= a.w2s_inv; }
                             yp[(mt * 4 + g4) * 512] = v;
                         }
                 }
@@ -423,15 +494,15 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
 // LDS: strip 64.5 KB + two slabs 55.3 KB + H ring 27.6 KB = 147 KB.  Only launches of > 128 images take this kernel (the small, split
 // launches stay on k_dec_b4<4>); per-image sums are reduced wave-wise, (((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7))).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int DBB_PXB = 3 * 128 + 16;
 constexpr int DBB_ZPX = 5 * 32;                          // the zero pixel behind the five rows
-constexpr int DBB_W0 = ((DBB_ZPX + 1) * DBB_PXB + 255) & ~255;
-constexpr int DBB_SLAB = 27 * 1024;                      // one 16-channel step: [9 taps][3 planes][64 lanes][16 B]
-constexpr int DBB_H = DBB_W0 + 2 * DBB_SLAB;
 constexpr int DBB_YROWS = 4 * 4 + 2;
-constexpr size_t DBB_LDS = DBB_H + (size_t)DBB_YROWS * 2 * 3 * 64 * sizeof(float);
-
-#define DBB_MFMA(ACC, AF, BF) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AF), __builtin_bit_cast(bf16x8, BF), ACC, 0, 0, 0)
+template <class SC> struct DbbL {                        // LDS layout for NPL planes
+    static constexpr int PXB = SC::NPL * 128 + 16;                       // bytes per staged pixel
+    static constexpr int W0 = ((DBB_ZPX + 1) * PXB + 255) & ~255;
+    static constexpr int SLAB = 9 * SC::NPL * 1024;                      // one 16-channel step: [9 taps][NPL planes][64 lanes][16 B]
+    static constexpr int H = W0 + 2 * SLAB;
+    static constexpr size_t LDS = H + (size_t)DBB_YROWS * 2 * 3 * 64 * sizeof(float);
+};
 
 // The four 16-channel steps of a strip for wave (r, PH).  abase: weight buffer 0 + lane * 16 (step ks in buffer ks & 1); bv[v]: the wave's
 // four views (pixel byte address + g * 16).  sync(ks) = "slab ks has landed for everybody" (drain + barrier + the next slab's DMA request).
@@ -442,25 +513,25 @@ constexpr size_t DBB_LDS = DBB_H + (size_t)DBB_YROWS * 2 * 3 * 64 * sizeof(float
 // between the MFMAs of the pair before it -- ACROSS the step boundary too: sync(ks + 1) sits in front of the LAST pair of step ks, whose
 // fragments are in registers by then, so the first pair of a step never starts with a burst of twelve exposed reads (that cost 12 % of the
 // kernel: profiles/r6_dec_b_b3_ablation.txt).  Products in the order (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi): small terms first.
-template <int PH, class Sync>
+template <class SC, int PH, class Sync>
 __device__ __forceinline__ void dbb_strip(f32x16 (&acc)[3], const unsigned char* abase, const unsigned char* const (&bv)[4], Sync sync) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int NPL = SC::NPL, NMF = 2 * SC::NPR, NRD = 4 * NPL, SLAB = DbbL<SC>::SLAB;
     constexpr int NP = PH ? 3 : 2;
     constexpr int TX[3] = {PH ? 7 : 4, PH ? 1 : 3, 6}, TY[3] = {PH ? 8 : 5, PH ? 2 : 3, 0};
     constexpr int VX[3] = {0, PH ? 2 : 1, 1}, VY[3] = {0, PH ? 2 : 1, 3};
     constexpr int AX[3] = {0, PH ? 0 : 1, 1}, AY[3] = {1, PH ? 1 : 2, 2};
-    float4 ax[2][3], ay[2][3], bx[2][3], by[2][3];
-    auto ld = [&](int ks, int i, int l, float4 (&axn)[3], float4 (&ayn)[3], float4 (&bxn)[3], float4 (&byn)[3]) {       // fragment read l of pair i of step ks
-        const unsigned char* slab = abase + (ks & 1) * DBB_SLAB;
-        const int k = l / 3, p = l % 3;
-        if (k == 0) axn[p] = *reinterpret_cast<const float4*>(slab + (TX[i] * 3 + p) * 1024);
+    float4 ax[2][NPL], ay[2][NPL], bx[2][NPL], by[2][NPL];
+    auto ld = [&](int ks, int i, int l, float4 (&axn)[NPL], float4 (&ayn)[NPL], float4 (&bxn)[NPL], float4 (&byn)[NPL]) {       // fragment read l of pair i of step ks
+        const unsigned char* slab = abase + (ks & 1) * SLAB;
+        const int k = l / NPL, p = l % NPL;
+        if (k == 0) axn[p] = *reinterpret_cast<const float4*>(slab + (TX[i] * NPL + p) * 1024);
         else if (k == 1) bxn[p] = *reinterpret_cast<const float4*>(bv[VX[i]] + p * 128 + ks * 32);
-        else if (k == 2) { if (TY[i] != TX[i]) ayn[p] = *reinterpret_cast<const float4*>(slab + (TY[i] * 3 + p) * 1024); }
+        else if (k == 2) { if (TY[i] != TX[i]) ayn[p] = *reinterpret_cast<const float4*>(slab + (TY[i] * NPL + p) * 1024); }
         else { if (VY[i] != VX[i]) byn[p] = *reinterpret_cast<const float4*>(bv[VY[i]] + p * 128 + ks * 32); }
     };
     sync(0);
 #pragma unroll
-    for (int l = 0; l < 12; ++l) ld(0, 0, l, ax[0], ay[0], bx[0], by[0]);
+    for (int l = 0; l < NRD; ++l) ld(0, 0, l, ax[0], ay[0], bx[0], by[0]);
 #pragma unroll
     for (int q = 0; q < 4 * NP; ++q) {
         const int i = q % NP, c = q & 1, n = c ^ 1;
@@ -469,23 +540,28 @@ __device__ __forceinline__ void dbb_strip(f32x16 (&acc)[3], const unsigned char*
         if (more && in_ == 0) sync(ksn);
         const bool sameT = TY[i] == TX[i], sameV = VY[i] == VX[i];
 #pragma unroll
-        for (int m = 0; m < 12; ++m) {
+        for (int m = 0; m < NMF; ++m) {
             const int pr = m >> 1;
             if (!sameT) {
-                if ((m & 1) == 0) DBB_MFMA(acc[AX[i]], ax[c][PA[pr]], bx[c][PB[pr]]);
-                else DBB_MFMA(acc[AY[i]], ay[c][PA[pr]], (sameV ? bx[c][PB[pr]] : by[c][PB[pr]]));
-            } else if ((m & 1) == 0) {                        // one tap, six products, alternating accumulators
-                if (pr & 1) DBB_MFMA(acc[AY[i]], ax[c][PA[pr]], bx[c][PB[pr]]);
-                else DBB_MFMA(acc[AX[i]], ax[c][PA[pr]], bx[c][PB[pr]]);
+                if ((m & 1) == 0) acc[AX[i]] = SC::mfma(ax[c][SC::PA(pr)], bx[c][SC::PB(pr)], acc[AX[i]]);
+                else acc[AY[i]] = SC::mfma(ay[c][SC::PA(pr)], (sameV ? bx[c][SC::PB(pr)] : by[c][SC::PB(pr)]), acc[AY[i]]);
+            } else if ((m & 1) == 0) {                        // one tap, its products alternating between two accumulators
+                if (pr & 1) acc[AY[i]] = SC::mfma(ax[c][SC::PA(pr)], bx[c][SC::PB(pr)], acc[AY[i]]);
+                else acc[AX[i]] = SC::mfma(ax[c][SC::PA(pr)], bx[c][SC::PB(pr)], acc[AX[i]]);
             }
-            if (more) ld(ksn, in_, m, ax[n], ay[n], bx[n], by[n]);
+            if (more) {
+#pragma unroll
+                for (int l = m * NRD / NMF; l < (m + 1) * NRD / NMF; ++l) ld(ksn, in_, l, ax[n], ay[n], bx[n], by[n]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
+template <class SC>
 __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
-    constexpr int SR = 4, NW = 8, NTHR = 512, NS = 32 / SR, NPF = (SR + 1) * 512 / NTHR;
+    constexpr int SR = 4, NW = 8, NTHR = 512, NS = 32 / SR, NPF = (SR + 1) * 512 / NTHR, NPL = SC::NPL;
+    constexpr int DBB_PXB = DbbL<SC>::PXB, DBB_W0 = DbbL<SC>::W0, DBB_SLAB = DbbL<SC>::SLAB, DBB_H = DbbL<SC>::H;
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
     float* sH = reinterpret_cast<float*>(smb + DBB_H);          // [ring row][channel half][kh][64 output columns]
     __shared__ float4 sb3[8];
@@ -504,7 +580,9 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
     if (tid < 96) {                                              // the 4x4x1 tap table of k_dec_b4: pattern = h * 4 + kw, float4 i4 = (kh, g4)
         const int pat = tid / 12, i4 = tid - pat * 12;
         const int kw = pat & 3, hh = pat >> 2, kh = i4 >> 2, g4 = i4 & 3;
-        sW4[tid] = kw < 3 ? reinterpret_cast<const float4*>(a.w4 + (3 * kh + kw) * 32)[2 * g4 + hh] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 q4 = kw < 3 ? reinterpret_cast<const float4*>(a.w4 + (3 * kh + kw) * 32)[2 * g4 + hh] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (SC::SCALED) { q4.x *= a.w3s_inv; q4.y *= a.w3s_inv; q4.z *= a.w3s_inv; q4.w *= a.w3s_inv; }      // ReLU commutes with the (positive, power-of-two) weight scale: undone in the taps
+        sW4[tid] = q4;
     }
     const float4* w4p = sW4 + (h * 4 + (lane & 3)) * 12;
     if (tid < DBB_PXB / 4) reinterpret_cast<uint32_t*>(smb + DBB_ZPX * DBB_PXB)[tid] = 0u;
@@ -521,16 +599,15 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int piece = w + 8 * i;
-            if (piece < 27) glds16(Wg + (size_t)ks * DBB_SLAB + piece * 1024, lds_w0 + (unsigned)(buf * DBB_SLAB + piece * 1024));
+            if (piece < 9 * NPL) glds16(Wg + (size_t)ks * DBB_SLAB + piece * 1024, lds_w0 + (unsigned)(buf * DBB_SLAB + piece * 1024));
         }
     };
     slab_dma(0, 0);
     auto put_planes = [&](unsigned char* px, int c, const float v0, const float v1, const float v2, const float v3) {
-        uint32_t hi[2], mid[2], lo[2];
-        split3_pk(v0, v1, hi[0], mid[0], lo[0]); split3_pk(v2, v3, hi[1], mid[1], lo[1]);
-        *reinterpret_cast<uint2*>(px + c * 2) = make_uint2(hi[0], hi[1]);
-        *reinterpret_cast<uint2*>(px + 128 + c * 2) = make_uint2(mid[0], mid[1]);
-        *reinterpret_cast<uint2*>(px + 256 + c * 2) = make_uint2(lo[0], lo[1]);
+        uint32_t pa_[NPL], pb_[NPL];
+        SC::split_pk(v0, v1, pa_); SC::split_pk(v2, v3, pb_);
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(px + p * 128 + c * 2) = make_uint2(pa_[p], pb_[p]);
     };
     // the four shifted views of this wave's input row (column 32 does not exist: the zero pixel)
     const int spx[4] = {r * 32 + j, (j < 31) ? r * 32 + j + 1 : DBB_ZPX, (r + 1) * 32 + j, (j < 31) ? (r + 1) * 32 + j + 1 : DBB_ZPX};
@@ -608,7 +685,8 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
                 if (ks == 0) {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {              // accumulators start at the bias (register e holds channel (e & 3) + 8 (e >> 2) + 4 h)
-                        const float4 bb = sb3[2 * g4 + h];
+                        float4 bb = sb3[2 * g4 + h];
+                        if (SC::SCALED) { bb.x *= a.w3s; bb.y *= a.w3s; bb.z *= a.w3s; bb.w *= a.w3s; }       // the accumulators hold (weight scale) x y3
                         acc[0][4 * g4] = bb.x; acc[0][4 * g4 + 1] = bb.y; acc[0][4 * g4 + 2] = bb.z; acc[0][4 * g4 + 3] = bb.w;
                     }
                     acc[1] = acc[0];
@@ -631,7 +709,7 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
             const unsigned char* bv[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) bv[v] = smb + (size_t)spx[v] * DBB_PXB + h * 16;
-            if (ph) dbb_strip<1>(acc, abase, bv, sync); else dbb_strip<0>(acc, abase, bv, sync);
+            if (ph) dbb_strip<SC, 1>(acc, abase, bv, sync); else dbb_strip<SC, 0>(acc, abase, bv, sync);
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[1][e] += acc[2][e];
             // ---- ReLU, then the 32 -> 1 conv as tap planes on the accumulators (k_dec_b4's tail for this wave's row parity ph)
@@ -701,29 +779,36 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
 
 void launch_dec_b_b3(const DecBArgs& a, hipStream_t st) {
     const int grid = a.rows < 256 ? a.rows : 256;        // persistent: one workgroup per CU
-    hipLaunchKernelGGL(k_dec_b_b3, dim3(grid), dim3(512), DBB_LDS, st, a);
+    if (a.split == 2) hipLaunchKernelGGL(k_dec_b_b3<SchH2>, dim3(grid), dim3(512), DbbL<SchH2>::LDS, st, a);
+    else hipLaunchKernelGGL(k_dec_b_b3<SchB3>, dim3(grid), dim3(512), DbbL<SchB3>::LDS, st, a);
 }
 
-// ConvT3 weights for k_dec_b_b3: [Cin = 64][Cout = 32][3][3] -> [ks = Cin / 16][tap][3 planes][64 lanes][8 bf16]
-void pack_convt3_bf16x3(const float* W_cicokk, uint16_t* dst) {
+// ConvT3 weights for k_dec_b_b3: [Cin = 64][Cout = 32][3][3] -> [ks = Cin / 16][tap][NPL planes][64 lanes][8 x 16 bit]; returns the weight scale
+float pack_convt3_split(int mode, const float* W_cicokk, uint16_t* dst) {
+    const int npl = mode == 2 ? 2 : 3;
+    const float sc = split_weight_scale(mode, W_cicokk, (size_t)64 * 32 * 9);
     for (int ks = 0; ks < 4; ++ks)
         for (int t = 0; t < 9; ++t)
             for (int lane = 0; lane < 64; ++lane)
                 for (int s = 0; s < 8; ++s) {
                     const int co = lane & 31, ci = ks * 16 + 8 * (lane >> 5) + s;
                     uint32_t p[3];
-                    split3(W_cicokk[((size_t)ci * 32 + co) * 9 + t], p[0], p[1], p[2]);
-                    for (int pl = 0; pl < 3; ++pl) dst[((((size_t)ks * 9 + t) * 3 + pl) * 64 + lane) * 8 + s] = (uint16_t)p[pl];
+                    split_host(mode, W_cicokk[((size_t)ci * 32 + co) * 9 + t] * sc, p);
+                    for (int pl = 0; pl < npl; ++pl) dst[((((size_t)ks * 9 + t) * npl + pl) * 64 + lane) * 8 + s] = (uint16_t)p[pl];
                 }
+    return sc;
 }
 
 void launch_dec_a_b3(const DecAArgs& a, hipStream_t st) {
     const int grid = a.rows < 256 ? a.rows : 256;        // persistent: one workgroup per CU
-    hipLaunchKernelGGL(k_dec_a_b3<EFE_DA3_NTW>, dim3(grid), dim3(512 / EFE_DA3_NTW), DA3_LDS, st, a);
+    if (a.split == 2) hipLaunchKernelGGL((k_dec_a_b3<SchH2, EFE_DA3_NTW>), dim3(grid), dim3(512 / EFE_DA3_NTW), Da3L<2>::LDS, st, a);
+    else hipLaunchKernelGGL((k_dec_a_b3<SchB3, EFE_DA3_NTW>), dim3(grid), dim3(512 / EFE_DA3_NTW), Da3L<3>::LDS, st, a);
 }
 
-// conv weights for k_dec_a_b3: get(tap, co, ci) -> [tap][2 mt][4 ks][3 planes][64 lanes][8 bf16]
-void pack_conv_bf16x3(const float* W_cicokk, int Cin, int Cout, uint16_t* dst) {
+// conv weights for k_dec_a_b3: get(tap, co, ci) -> [tap][2 mt][4 ks][NPL planes][64 lanes][8 x 16 bit]; returns the weight scale
+float pack_conv_split(int mode, const float* W_cicokk, int Cin, int Cout, uint16_t* dst) {
+    const int npl = mode == 2 ? 2 : 3;
+    const float sc = split_weight_scale(mode, W_cicokk, (size_t)Cin * Cout * 9);
     for (int t = 0; t < 9; ++t)
         for (int mt = 0; mt < Cout / 32; ++mt)
             for (int ks = 0; ks < Cin / 16; ++ks)
@@ -731,38 +816,45 @@ void pack_conv_bf16x3(const float* W_cicokk, int Cin, int Cout, uint16_t* dst) {
                     for (int s = 0; s < 8; ++s) {
                         const int co = mt * 32 + (lane & 31), ci = ks * 16 + 8 * (lane >> 5) + s;
                         uint32_t p[3];
-                        split3(W_cicokk[((size_t)ci * Cout + co) * 9 + t], p[0], p[1], p[2]);       // ConvTranspose2d weights are [Cin][Cout][kh][kw]
-                        for (int pl = 0; pl < 3; ++pl)
-                            dst[(((((size_t)t * (Cout / 32) + mt) * (Cin / 16) + ks) * 3 + pl) * 64 + lane) * 8 + s] = (uint16_t)p[pl];
+                        split_host(mode, W_cicokk[((size_t)ci * Cout + co) * 9 + t] * sc, p);       // ConvTranspose2d weights are [Cin][Cout][kh][kw]
+                        for (int pl = 0; pl < npl; ++pl)
+                            dst[(((((size_t)t * (Cout / 32) + mt) * (Cin / 16) + ks) * npl + pl) * 64 + lane) * 8 + s] = (uint16_t)p[pl];
                     }
+    return sc;
 }
 
 int init_bf16x3_kernels() {
-    if (hipFuncSetAttribute((const void*)k_dec_a_b3<EFE_DA3_NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DA3_LDS) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)k_dec_b_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DBB_LDS) != hipSuccess) return 1;
-    return hipFuncSetAttribute((const void*)k_fc4_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3_LDS) != hipSuccess;
+    if (hipFuncSetAttribute((const void*)k_dec_a_b3<SchB3, EFE_DA3_NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Da3L<3>::LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_dec_a_b3<SchH2, EFE_DA3_NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Da3L<2>::LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_dec_b_b3<SchB3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DbbL<SchB3>::LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_dec_b_b3<SchH2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DbbL<SchH2>::LDS) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_fc4_b3<SchH2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Fc4L<2>::LDS) != hipSuccess) return 1;
+    return hipFuncSetAttribute((const void*)k_fc4_b3<SchB3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Fc4L<3>::LDS) != hipSuccess;
 }
 
 void launch_fc4_b3(const GemmArgs& a, hipStream_t st) {
     // persistent: one 8-wave workgroup per CU, 8 feature groups x 32 workgroups, each with >= 1 (row tile, step) pair
     const int nsteps = ((a.n_pix + 63) / 64) * fc4b3_spg(a.mtiles);
     const int nper = nsteps < 32 ? nsteps : 32;
-    hipLaunchKernelGGL(k_fc4_b3, dim3(8 * nper), dim3(512), B3_LDS, st, a);
+    if (a.split == 2) hipLaunchKernelGGL(k_fc4_b3<SchH2>, dim3(8 * nper), dim3(512), Fc4L<2>::LDS, st, a);
+    else hipLaunchKernelGGL(k_fc4_b3<SchB3>, dim3(8 * nper), dim3(512), Fc4L<3>::LDS, st, a);
 }
 
-// host side of efe_commit_weights: W [out][in = 256] (rows already in the engine's NHWC feature order through row_perm) -> three bf16
-// planes, fragment-major [out / 32][16][3][64 lanes][8]
-void pack_bf16x3(const float* W, const int* row_perm, int out, int in, uint16_t* dst) {
-    const int mtiles = out / 32;
+// host side of efe_commit_weights: W [out][in = 256] (rows already in the engine's NHWC feature order through row_perm) -> NPL 16-bit
+// planes, fragment-major [out / 32][16][NPL][64 lanes][8]; returns the weight scale (1 for the bf16 split)
+float pack_dense_split(int mode, const float* W, const int* row_perm, int out, int in, uint16_t* dst) {
+    const int mtiles = out / 32, npl = mode == 2 ? 2 : 3;
+    const float sc = split_weight_scale(mode, W, (size_t)out * in);
     for (int mt = 0; mt < mtiles; ++mt)
         for (int ks = 0; ks < in / 16; ++ks)
             for (int lane = 0; lane < 64; ++lane)
                 for (int s = 0; s < 8; ++s) {
                     const int co = mt * 32 + (lane & 31), ci = ks * 16 + 8 * (lane >> 5) + s;
                     uint32_t p[3];
-                    split3(W[(size_t)(row_perm ? row_perm[co] : co) * in + ci], p[0], p[1], p[2]);
-                    for (int pl = 0; pl < 3; ++pl) dst[((((size_t)mt * (in / 16) + ks) * 3 + pl) * 64 + lane) * 8 + s] = (uint16_t)p[pl];
+                    split_host(mode, W[(size_t)(row_perm ? row_perm[co] : co) * in + ci] * sc, p);
+                    for (int pl = 0; pl < npl; ++pl) dst[((((size_t)mt * (in / 16) + ks) * npl + pl) * 64 + lane) * 8 + s] = (uint16_t)p[pl];
                 }
+    return sc;
 }
 
 }  // namespace efe

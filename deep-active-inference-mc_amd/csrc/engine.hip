@@ -92,10 +92,15 @@ struct efe_ctx {
                                    // (k_conv_e); 0 = k_conv_g for every layer (A/B, parity of the fallbacks)
     int64_t dec_split = 1;         // dSprites path: decoder launches of <= 128 images run k_dec_b4 with four workgroups per image (0 = never: A/B)
     int64_t fuse_final_g = 1;      // generic path: last two decoder layers in one kernel (k_dec_bg); 0 = separate launches (A/B, parity tests of k_final_g)
-    int64_t mfma_bf16x3 = 0;       // OPT-IN EXPERIMENT (bf16x3.hip): Linear(256, 16384) of the decoder on the bf16 pipe, operands split in three bf16 planes
-    uint16_t* fc4_b3 = nullptr;    // its packed planes (part of wbufs)
-    uint16_t* ct_b3[2] = {nullptr, nullptr};      // po_net.13 / .15 (k_dec_a's layers) as bf16 planes
-    uint16_t* ct3_b3 = nullptr;                   // po_net.17 (ConvT3, k_dec_b_b3) as bf16 planes
+    // OPT-IN EXPERIMENTS (bf16x3.hip): the decoder's Linear(256, 16384) and three large ConvTranspose2d layers on the 16-bit matrix pipe with
+    // split operands.  mfma_bf16x3 holds the MODE: 0 = off (exact fp32, the default), 1 = three bf16 planes / six products (option
+    // "mfma_bf16x3"), 2 = two fp16 planes / three products (option "mfma_f16x2").  The planes below are packed for `split_packed`.
+    int64_t mfma_bf16x3 = 0;
+    int split_packed = 0;
+    uint16_t* fc4_b3 = nullptr;    // po_net.9's packed planes (part of wbufs)
+    uint16_t* ct_b3[2] = {nullptr, nullptr};      // po_net.13 / .15 (k_dec_a's layers) as planes
+    uint16_t* ct3_b3 = nullptr;                   // po_net.17 (ConvT3, k_dec_b_b3) as planes
+    float s_fc4 = 1.f, s_ct[2] = {1.f, 1.f}, s_ct3 = 1.f;      // fp16 split: the power of two each layer's weights were scaled by
     int64_t b3_convt3 = 1;                        // mfma_bf16x3: ConvT3 on the bf16 pipe too (0 = the fp32 k_dec_b4 behind the two bf16 kernels, round 5's form)
     bool arch_gfx950 = false;      // hipDeviceProp_t.gcnArchName starts with gfx950 (checked at creation)
     int64_t sim_split = 1;         // simulations of <= 16 episodes: the chain kernel on eight workgroups per 8 episodes (k_sim_chain<8>); 0 = one workgroup (A/B, bit-identical)
@@ -240,7 +245,10 @@ void fc(efe_ctx* ctx, const Layer& L, const float* X, int ldx, int x_mod, float*
     a.rows_per_group = nc.rows_per_group; a.row_offset = nc.row_offset; a.m0 = m0;
     hipEvent_t e0 = ctx->prof_begin(st);
     if (L.mtiles >= 64 && !(L.mtiles & 1) && L.cin == 256 && ldx == 256 && x_mod == 0 && relu && drop) {
-        if (ctx->mfma_bf16x3 && ctx->fc4_b3 && &L == &ctx->dec_fc[3]) { a.Wb3 = ctx->fc4_b3; launch_fc4_b3(a, st); }     // opt-in experiment
+        if (ctx->mfma_bf16x3 && ctx->fc4_b3 && &L == &ctx->dec_fc[3]) {      // opt-in experiment
+            a.Wb3 = ctx->fc4_b3; a.split = (int)ctx->mfma_bf16x3; a.wb3_scale_inv = 1.0f / ctx->s_fc4;
+            launch_fc4_b3(a, st);
+        }
         else launch_fc4(a, st);     // Linear(256, 64 * base^2): batch tile staged in LDS
     } else {
         // tile shape by problem size: small launches (transition / habit / heads) use 32x32 wave tiles so that the
@@ -490,7 +498,11 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         da.x4 = x4; da.y2 = y2; da.w1 = ctx->dec_ct[0].Wp; da.b1 = ctx->dec_ct[0].bias; da.w2 = ctx->dec_ct[1].Wp;
         da.b2 = ctx->dec_ct[1].bias; da.rows = c; da.live = live_of(nc, m0); da.queue = queues + m0 / C; da.parts = split ? 8 : 1;
         hipEvent_t e0 = ctx->prof_begin(st);
-        if (ctx->mfma_bf16x3 && ctx->ct_b3[0] && !split) { da.w1b3 = ctx->ct_b3[0]; da.w2b3 = ctx->ct_b3[1]; launch_dec_a_b3(da, st); }      // opt-in experiment
+        if (ctx->mfma_bf16x3 && ctx->ct_b3[0] && !split) {      // opt-in experiment
+            da.w1b3 = ctx->ct_b3[0]; da.w2b3 = ctx->ct_b3[1]; da.split = (int)ctx->mfma_bf16x3;
+            da.w1s = ctx->s_ct[0]; da.w1s_inv = 1.0f / ctx->s_ct[0]; da.w2s = ctx->s_ct[1]; da.w2s_inv = 1.0f / ctx->s_ct[1];
+            launch_dec_a_b3(da, st);
+        }
         else launch_dec_a(da, st);
         ctx->prof_end(e0, st);
         ctx->cls = PROF_CT3;
@@ -499,7 +511,10 @@ int run_decoder(efe_ctx* ctx, const float* dec_in /*[N][16]*/, int N, const Nois
         db.rows = c; db.live = live_of(nc, m0); db.m0 = m0; db.rows_per_group = nc.rows_per_group; db.gm = nc.gm; db.reward0 = reward0; db.store0 = store0;
         db.val = val; db.parts = split ? 4 : 1; db.valq = split ? val : nullptr; db.po = po_store; db.reward_intent = (int)ctx->reward_intent;
         e0 = ctx->prof_begin(st);
-        if (ctx->mfma_bf16x3 && ctx->b3_convt3 && ctx->ct3_b3 && !split) { db.w3b3 = ctx->ct3_b3; launch_dec_b_b3(db, st); }      // opt-in experiment
+        if (ctx->mfma_bf16x3 && ctx->b3_convt3 && ctx->ct3_b3 && !split) {      // opt-in experiment
+            db.w3b3 = ctx->ct3_b3; db.split = (int)ctx->mfma_bf16x3; db.w3s = ctx->s_ct3; db.w3s_inv = 1.0f / ctx->s_ct3;
+            launch_dec_b_b3(db, st);
+        }
         else launch_dec_b(db, st);
         ctx->prof_end(e0, st);
     }
@@ -828,7 +843,7 @@ int efe_set_weight(efe_ctx* ctx, const char* key, const float* data_host, const 
     return 0;
 }
 
-static int pack_fc4_b3(efe_ctx* ctx);
+static int pack_fc4_b3(efe_ctx* ctx, int mode);
 
 int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     if (!name) return 1;
@@ -849,15 +864,17 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
         if (value && !ctx->arch_gfx950) return ctx->fail("sim_split: validated on gfx950 only (this device is another architecture)");
         ctx->sim_split = value ? 1 : 0; return 0;
     }
-    if (!strcmp(name, "mfma_bf16x3")) {       // opt-in experiment; the planes are packed now if the weights are already committed
-        if (value && ctx->generic) return ctx->fail("mfma_bf16x3: the experiment covers the Dynamic-dSprites geometry only");
+    if (!strcmp(name, "mfma_bf16x3") || !strcmp(name, "mfma_f16x2")) {       // opt-in experiments; the planes are packed now if the weights are already committed
+        const int mode = !value ? 0 : name[5] == 'b' ? 1 : 2;
+        if (mode && ctx->generic) return ctx->fail(std::string(name) + ": the experiment covers the Dynamic-dSprites geometry only");
         // (packed from ctx->raw only while raw IS the committed set -- efe_set_weight clears `committed`, the next commit packs the planes
         // with everything else; the option is on only after every plane exists: a failure part-way leaves the experiment off, not half-enabled)
-        if (value && ctx->committed && !ctx->fc4_b3) {
+        if (mode && ctx->committed && ctx->split_packed != mode) {
             HIPCHK(hipSetDevice(ctx->device));
-            if (pack_fc4_b3(ctx)) { ctx->fc4_b3 = nullptr; ctx->ct_b3[0] = ctx->ct_b3[1] = nullptr; ctx->ct3_b3 = nullptr; ctx->mfma_bf16x3 = 0; return 1; }
+            HIPCHK(hipDeviceSynchronize());             // work that still reads the other mode's planes
+            if (pack_fc4_b3(ctx, mode)) { ctx->mfma_bf16x3 = 0; return 1; }
         }
-        ctx->mfma_bf16x3 = value ? 1 : 0;
+        ctx->mfma_bf16x3 = mode;
         return 0;
     }
     if (!strcmp(name, "b3_convt3")) { ctx->b3_convt3 = value ? 1 : 0; return 0; }
@@ -868,33 +885,49 @@ int efe_set_option(efe_ctx* ctx, const char* name, int64_t value) {
     return ctx->fail(std::string("unknown option ") + name);
 }
 
-// option mfma_bf16x3: down.po_net.9 (rows in NHWC order) as three bf16 planes for k_fc4_b3
-static int pack_fc4_b3(efe_ctx* ctx) {
+// options mfma_bf16x3 (mode 1) / mfma_f16x2 (mode 2): po_net.9 (rows in NHWC order), po_net.13 / .15 / .17 as 16-bit planes for the kernels of
+// bf16x3.hip.  Planes of the other mode are released first; a failure leaves no planes at all.
+static void drop_split_planes(efe_ctx* ctx) {
+    void* old[4] = {ctx->fc4_b3, ctx->ct_b3[0], ctx->ct_b3[1], ctx->ct3_b3};
+    for (void* q : old) {
+        if (!q) continue;
+        ctx->wbufs.erase(std::remove(ctx->wbufs.begin(), ctx->wbufs.end(), q), ctx->wbufs.end());
+        (void)hipFree(q);
+    }
+    ctx->fc4_b3 = nullptr; ctx->ct_b3[0] = ctx->ct_b3[1] = nullptr; ctx->ct3_b3 = nullptr; ctx->split_packed = 0;
+}
+static int pack_fc4_b3(efe_ctx* ctx, int mode) {
+    drop_split_planes(ctx);
+    const int npl = mode == 2 ? 2 : 3;
+    auto upload = [&](uint16_t*& dst, const std::vector<uint16_t>& v) -> int {
+        if (hipMalloc((void**)&dst, v.size() * 2) != hipSuccess) { dst = nullptr; return 1; }
+        ctx->wbufs.push_back(dst);
+        return hipMemcpy(dst, v.data(), v.size() * 2, hipMemcpyHostToDevice) != hipSuccess;
+    };
+    auto fail = [&](const char* what) { drop_split_planes(ctx); return ctx->fail(std::string("split-operand planes: ") + what); };
     const HostTensor* w = need(ctx, "down.po_net.9.weight", {16384, 256});
-    if (!w) return 1;
+    if (!w) { drop_split_planes(ctx); return 1; }
     std::vector<int> rowp(16384);
     for (int p = 0; p < 256; ++p) for (int c = 0; c < 64; ++c) rowp[p * 64 + c] = c * 256 + p;
-    std::vector<uint16_t> planes((size_t)16384 * 256 * 3);
-    pack_bf16x3(w->data.data(), rowp.data(), 16384, 256, planes.data());
-    HIPCHK(hipMalloc((void**)&ctx->fc4_b3, planes.size() * 2)); ctx->wbufs.push_back(ctx->fc4_b3);
-    HIPCHK(hipMemcpy(ctx->fc4_b3, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+    std::vector<uint16_t> planes((size_t)16384 * 256 * npl);
+    ctx->s_fc4 = pack_dense_split(mode, w->data.data(), rowp.data(), 16384, 256, planes.data());
+    if (upload(ctx->fc4_b3, planes)) return fail("po_net.9");
     const char* ck[2] = {"down.po_net.13", "down.po_net.15"};
     for (int i = 0; i < 2; ++i) {
         const HostTensor* cw = need(ctx, std::string(ck[i]) + ".weight", {64, 64, 3, 3});
-        if (!cw) return 1;
-        std::vector<uint16_t> cp((size_t)9 * 64 * 64 * 3);
-        pack_conv_bf16x3(cw->data.data(), 64, 64, cp.data());
-        HIPCHK(hipMalloc((void**)&ctx->ct_b3[i], cp.size() * 2)); ctx->wbufs.push_back(ctx->ct_b3[i]);
-        HIPCHK(hipMemcpy(ctx->ct_b3[i], cp.data(), cp.size() * 2, hipMemcpyHostToDevice));
+        if (!cw) { drop_split_planes(ctx); return 1; }
+        std::vector<uint16_t> cp((size_t)9 * 64 * 64 * npl);
+        ctx->s_ct[i] = pack_conv_split(mode, cw->data.data(), 64, 64, cp.data());
+        if (upload(ctx->ct_b3[i], cp)) return fail(ck[i]);
     }
     {
         const HostTensor* cw = need(ctx, "down.po_net.17.weight", {64, 32, 3, 3});
-        if (!cw) return 1;
-        std::vector<uint16_t> cp((size_t)4 * 9 * 3 * 64 * 8);
-        pack_convt3_bf16x3(cw->data.data(), cp.data());
-        HIPCHK(hipMalloc((void**)&ctx->ct3_b3, cp.size() * 2)); ctx->wbufs.push_back(ctx->ct3_b3);
-        HIPCHK(hipMemcpy(ctx->ct3_b3, cp.data(), cp.size() * 2, hipMemcpyHostToDevice));
+        if (!cw) { drop_split_planes(ctx); return 1; }
+        std::vector<uint16_t> cp((size_t)4 * 9 * npl * 64 * 8);
+        ctx->s_ct3 = pack_convt3_split(mode, cw->data.data(), cp.data());
+        if (upload(ctx->ct3_b3, cp)) return fail("po_net.17");
     }
+    ctx->split_packed = mode;
     return 0;
 }
 
@@ -906,7 +939,7 @@ int efe_commit_weights(efe_ctx* ctx) {
         HIPCHK(hipDeviceSynchronize());
         for (void* p : ctx->wbufs) (void)hipFree(p);
         ctx->wbufs.clear();
-        ctx->fc4_b3 = nullptr; ctx->ct_b3[0] = ctx->ct_b3[1] = nullptr; ctx->ct3_b3 = nullptr;
+        ctx->fc4_b3 = nullptr; ctx->ct_b3[0] = ctx->ct_b3[1] = nullptr; ctx->ct3_b3 = nullptr; ctx->split_packed = 0;
     }
     ctx->committed = false;
     const int A = ctx->pi_dim;
@@ -1043,7 +1076,7 @@ int efe_commit_weights(efe_ctx* ctx) {
         std::vector<int> rowp(16384);
         for (int p = 0; p < 256; ++p) for (int c = 0; c < 64; ++c) rowp[p * 64 + c] = c * 256 + p;
         if (pack_linear(ctx, ctx->dec_fc[3], "down.po_net.9", 16384, 256, rowp.data(), nullptr)) return 1;
-        if (ctx->mfma_bf16x3 && pack_fc4_b3(ctx)) return 1;
+        if (ctx->mfma_bf16x3 && pack_fc4_b3(ctx, (int)ctx->mfma_bf16x3)) return 1;
     }
     for (int i = 0; i < 3; ++i) {   // ConvTranspose2d weights are [Cin][Cout][kh][kw]
         const HostTensor* w = need(ctx, std::string(tk[i]) + ".weight", {tci[i], tco[i], 3, 3});

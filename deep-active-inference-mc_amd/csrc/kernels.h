@@ -97,7 +97,9 @@ struct GemmArgs {
     int rows_per_group;
     uint32_t row_offset;  // global index of row 0 of a group on this rank
     int m0;               // index of column 0 of this launch inside the [group][row] batch
-    const void* Wb3 = nullptr;   // option mfma_bf16x3 (bf16x3.hip): the same weights as three bf16 planes [mtile][16][3][64 lanes][8]
+    const void* Wb3 = nullptr;   // options mfma_bf16x3 / mfma_f16x2 (bf16x3.hip): the same weights as 16-bit planes [mtile][16][planes][64 lanes][8]
+    int split = 0;               // 1 = three bf16 planes, 2 = two fp16 planes
+    float wb3_scale_inv = 1.0f;  // fp16 split: 1 / (the power of two the packed weights were scaled by)
 };
 
 // fused decoder, stage A: x4 [rows][16][16][64] -> ConvT(64,64,s1)+ReLU -> ConvT(64,64,s2)+ReLU -> y2 [rows][4 parities][8 channel groups][16x16 positions][8] (see k_dec_a)
@@ -109,7 +111,9 @@ struct DecAArgs {
     RowMask live;
     int parts;            // 1 = persistent, one image per workgroup pass; 8 = small launches, an image over eight workgroups (k_dec_a_s)
     int* queue;           // zero-initialised ticket counter of this launch: images beyond the first two per workgroup are claimed dynamically
-    const void* w1b3 = nullptr; const void* w2b3 = nullptr;      // option mfma_bf16x3: the two layers' weights as bf16 planes [tap][2][4][3][64 lanes][8] (bf16x3.hip)
+    const void* w1b3 = nullptr; const void* w2b3 = nullptr;      // options mfma_bf16x3 / mfma_f16x2: the two layers' weights as 16-bit planes [tap][2][4][planes][64 lanes][8] (bf16x3.hip)
+    int split = 0;                                               // 1 = three bf16 planes, 2 = two fp16 planes
+    float w1s = 1.0f, w1s_inv = 1.0f, w2s = 1.0f, w2s_inv = 1.0f;  // fp16 split: the layers' weight scales (powers of two) and their inverses
 };
 // fused decoder, stage B: y2 -> ConvT(64,32,s2)+ReLU -> ConvT(32,1,s1)+Sigmoid -> per-image reduction (+ image store)
 struct DecBArgs {
@@ -128,7 +132,9 @@ struct DecBArgs {
     float* valq;
     float* po;            // [slots][rows_per_group][4096] stored images
     int reward_intent;    // 0 = the shipped port's NCHW-broadcast reward target, 1 = the upstream-intent variant (reward_term below)
-    const void* w3b3 = nullptr;      // option mfma_bf16x3: ConvT3's weights as bf16 planes [4 ks][9 taps][3][64 lanes][8] (bf16x3.hip, k_dec_b_b3)
+    const void* w3b3 = nullptr;      // options mfma_bf16x3 / mfma_f16x2: ConvT3's weights as 16-bit planes [4 ks][9 taps][planes][64 lanes][8] (bf16x3.hip, k_dec_b_b3)
+    int split = 0;                   // 1 = three bf16 planes, 2 = two fp16 planes
+    float w3s = 1.0f, w3s_inv = 1.0f;      // fp16 split: the power of two the packed weights were scaled by, and its inverse
 };
 // fused encoder trunk: o [rows][64][64] -> conv1..conv4 (+ReLU) -> out [rows][576] in NHWC (p*64 + c) order
 struct EncArgs {
@@ -143,11 +149,11 @@ struct EncArgs {
 void launch_enc_trunk(const EncArgs& a, hipStream_t st);
 void launch_fc4(const GemmArgs& a, hipStream_t st);      // Linear(256,16384)+ReLU+Dropout with the batch tile staged in LDS
 void launch_fc4_b3(const GemmArgs& a, hipStream_t st);   // the same on the bf16 pipe, operands split in three (opt-in experiment, bf16x3.hip)
-void pack_bf16x3(const float* W, const int* row_perm, int out, int in, uint16_t* dst);
+float pack_dense_split(int mode, const float* W, const int* row_perm, int out, int in, uint16_t* dst);      // mode 1 = bf16 x 3, 2 = fp16 x 2; -> weight scale
 void launch_dec_a_b3(const DecAArgs& a, hipStream_t st);  // k_dec_a's two layers on the bf16 pipe, every operand through LDS (opt-in experiment)
-void pack_conv_bf16x3(const float* W_cicokk, int Cin, int Cout, uint16_t* dst);
+float pack_conv_split(int mode, const float* W_cicokk, int Cin, int Cout, uint16_t* dst);
 void launch_dec_b_b3(const DecBArgs& a, hipStream_t st);  // k_dec_b4's layers with ConvT3 on the bf16 pipe (opt-in experiment)
-void pack_convt3_bf16x3(const float* W_cicokk, uint16_t* dst);
+float pack_convt3_split(int mode, const float* W_cicokk, uint16_t* dst);      // -> the weight scale (1 for the bf16 split)
 int init_bf16x3_kernels();
 void launch_dec_a(const DecAArgs& a, hipStream_t st);
 void launch_dec_b(const DecBArgs& a, hipStream_t st);

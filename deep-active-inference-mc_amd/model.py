@@ -393,11 +393,16 @@ class ActiveInferenceModel:
     def set_option(self, name, value):
         """efe_set_option: launch-group sizes (dec_chunk, enc_chunk, dec_chunk_g, dec_budget_g), reward_upstream_intent (0 / 1: the reward
         target the upstream NHWC code means instead of the shipped port's NCHW broadcast), A/B switches that leave the
-        results unchanged (generic path: fuse_final_g, ct_fuse12, enc_tiled; sim_split, mid_unfused, head_unfused), the mfma_bf16x3
-        experiment, poison / trace / arena_align / check_rows (development) -- the list with defaults: include/efe_engine.h"""
+        results unchanged (generic path: fuse_final_g, ct_fuse12, enc_tiled; sim_split, mid_unfused, head_unfused), the mfma_bf16x3 /
+        mfma_f16x2 experiments (one split mode at a time: setting one replaces the other), poison / trace / arena_align / check_rows (development) -- the list with defaults: include/efe_engine.h"""
         e = self._engine
         e.check(e.lib.efe_set_option(e.ctx, name.encode(), int(value)))
         self._opts = dict(getattr(self, '_opts', {}), **{name: int(value)})
+        if name in ('mfma_bf16x3', 'mfma_f16x2'):          # ONE split mode in the engine: setting either option replaces (or, with 0, clears) the other
+            other = 'mfma_f16x2' if name == 'mfma_bf16x3' else 'mfma_bf16x3'
+            self._opts.pop(other, None)
+            self._opts.pop(name, None)
+            self._opts[name] = int(value)                  # (re-inserted last: a replica replays the options in this order)
         r = getattr(self, '_replica', None)
         if r is not None:                   # the planner's simulation context follows (one tree must not mix two reward definitions)
             r.set_option(name, value)

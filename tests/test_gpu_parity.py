@@ -1413,25 +1413,29 @@ def test_contexts_release_their_device_memory(weights_cache):
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# OPT-IN EXPERIMENT (engine option mfma_bf16x3, csrc/bf16x3.hip): Linear(256, 16384) of the decoder on the bf16 matrix pipe with both
-# operands split into three bf16 planes (6 products, fp32 accumulation).  Narrower inputs than the reference's fp32 -- never the default,
-# never the headline -- so every decoder-bearing fixture is run through it at the UNCHANGED tolerances
+# OPT-IN EXPERIMENTS (engine options mfma_bf16x3 / mfma_f16x2, csrc/bf16x3.hip): the decoder's Linear(256, 16384) and its three large
+# transposed convolutions on the 16-bit matrix pipe with BOTH operands split -- into three bf16 planes (6 products) or two fp16 planes
+# (3 products, weights scaled by a power of two), fp32 accumulation.  Narrower inputs than the reference's fp32 -- never the default,
+# never the headline -- so every decoder-bearing fixture is run through both at the UNCHANGED tolerances
 # ---------------------------------------------------------------------------------------------------------------------------
-@pytest.fixture()
-def models_b3(models):
+SPLITS = ['mfma_bf16x3', 'mfma_f16x2']
+
+
+@pytest.fixture(params=SPLITS)
+def models_b3(request, models):
     used = []
 
     def get(wseed, gain, seed):
         m = models(wseed, gain, seed)
-        m.set_option('mfma_bf16x3', 1)
+        m.set_option(request.param, 1)
         used.append(m)
         return m
     yield get
     for m in used:
-        m.set_option('mfma_bf16x3', 0)
+        m.set_option(request.param, 0)
 
 
-def test_bf16x3_every_decoder_fixture_at_unchanged_tolerances(golden, models_b3):
+def test_split_operands_every_decoder_fixture_at_unchanged_tolerances(golden, models_b3):
     """the reference-captured fixtures that go through the decoder, with the experiment on: same assertions, same tolerances"""
     for gain in GAINS:
         test_networks_vs_golden(golden, models_b3, gain)
@@ -1448,38 +1452,67 @@ def test_bf16x3_every_decoder_fixture_at_unchanged_tolerances(golden, models_b3)
         test_planners_at_benchmark_depth_vs_reference(golden, models_b3, name)
 
 
-def test_bf16x3_large_launches_vs_oracle(models_b3, weights_cache):
-    """the launch sizes at which k_dec_a_b3 runs (the persistent kernel: more than 128 images per launch), against the oracle at the unchanged
-    tolerances: 1100 decoder rows, calculate_G over 150 rows x 4 samples, and the benchmarked configuration itself (128 rows x depth 5 x 10 samples)"""
+def test_split_operands_large_launches_vs_oracle(models_b3, weights_cache):
+    """the launch sizes at which k_dec_a_b3 / k_dec_b_b3 run (the persistent kernels: more than 128 images per launch), against the oracle at
+    the unchanged tolerances: 1100 decoder rows, calculate_G over 150 rows x 4 samples, and the benchmarked configuration itself (128 rows x
+    depth 5 x 10 samples)"""
     test_decoder_many_rows_vs_oracle(models_b3, weights_cache)
     test_calculate_G_many_rows_vs_oracle(models_b3, weights_cache)
     test_full_size_cfg2_vs_oracle(models_b3, weights_cache)
 
 
-def test_bf16x3_vs_fp32_path_and_oracle_on_many_rows(models, weights_cache):
-    """1100 decoder rows (several 64-row tiles + a ragged tail, every feature group): the experiment against the fp32 kernel (same masks,
-    images within the sigmoid tolerance) and against the oracle; and it really is another kernel (not bit-identical)"""
+@pytest.mark.parametrize('opt', SPLITS)
+def test_split_operands_vs_fp32_path_and_oracle_on_many_rows(models, weights_cache, opt):
+    """1100 decoder rows (several 64-row tiles + a ragged tail, every feature group): the experiment against the fp32 kernels (same masks,
+    images within the sigmoid tolerance) and against the oracle; and it really is another kernel (not bit-identical); switching from one
+    split to the other re-packs the planes"""
     seed, M, st = 31, 1100, 5
     m = models(1234, 1.15, seed)
     s = PX.uniform_fill(12, (M, 10), 400, -1.5, 1.5)
     ref = c(m.model_down.decoder(s, stage=st, pass_=PX.PASS_D2A))
+    other = SPLITS[1 - SPLITS.index(opt)]
     try:
-        m.set_option('mfma_bf16x3', 1)
+        m.set_option(other, 1)
+        got_other = c(m.model_down.decoder(s, stage=st, pass_=PX.PASS_D2A))
+        m.set_option(opt, 1)                       # the planes of the other mode are released, these packed
         got = c(m.model_down.decoder(s, stage=st, pass_=PX.PASS_D2A))
     finally:
-        m.set_option('mfma_bf16x3', 0)
+        m.set_option(opt, 0)
+    assert np.array_equal(c(m.model_down.decoder(s, stage=st, pass_=PX.PASS_D2A)), ref)        # off again: the exact fp32 kernels, bit for bit
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=4e-6)
-    assert not np.array_equal(got, ref)
+    assert not np.array_equal(got, ref) and not np.array_equal(got, got_other)
     orc = EO.OracleModel(weights_cache(1234, 1.15), EO.PhiloxNoise(seed))
     with torch.no_grad():
         o = orc.decoder(torch.from_numpy(s[:200]), PX.PASS_D2A, 0, st).numpy()
     np.testing.assert_allclose(got[:200], o, rtol=1e-5, atol=4e-6)
 
 
-def test_bf16x3_is_off_by_default_and_refused_on_other_geometries(models):
+def test_fp16_split_weight_scale_follows_the_weights(models, weights_cache):
+    """mfma_f16x2 scales every layer's weights by a power of two before the fp16 split (largest magnitude just below 2^14) and multiplies the
+    accumulators back: results must not depend on the overall magnitude of a layer beyond fp32 rounding -- the decoder with ConvT3's weights
+    x 2^-9 and the final layer's x 2^9 (y3 a factor 512 smaller: every low plane would be a denormal without the scale) stays within the
+    sigmoid tolerance of the exact fp32 kernels on the same weights"""
+    import daimc_amd
+    w = dict(weights_cache(1234, 1.15))
+    w['down.po_net.17.weight'] = w['down.po_net.17.weight'] * np.float32(2.0 ** -9)
+    w['down.po_net.17.bias'] = w['down.po_net.17.bias'] * np.float32(2.0 ** -9)
+    w['down.po_net.19.weight'] = w['down.po_net.19.weight'] * np.float32(2.0 ** 9)
+    m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=5, init_weights=False)
+    m.load_flat_weights(w)
+    s = PX.uniform_fill(13, (300, 10), 401, -1.5, 1.5)
+    ref = c(m.model_down.decoder(s, stage=2, pass_=PX.PASS_D1))
+    m.set_option('mfma_f16x2', 1)
+    got = c(m.model_down.decoder(s, stage=2, pass_=PX.PASS_D1))
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=4e-6)
+    base = models(1234, 1.15, 5)
+    np.testing.assert_allclose(ref, c(base.model_down.decoder(s, stage=2, pass_=PX.PASS_D1)), rtol=1e-5, atol=4e-6)     # (the rescaled network IS the same function)
+
+
+def test_split_operands_are_off_by_default_and_refused_on_other_geometries(models):
     import daimc_amd
     m = models(1234, 1.15, 3)
-    assert getattr(m, '_opts', {}).get('mfma_bf16x3', 0) == 0
+    assert all(getattr(m, '_opts', {}).get(o, 0) == 0 for o in SPLITS)
     g = daimc_amd.ActiveInferenceModel(10, 3, 0.0, 1.0, 1.0, colour_channels=3, resolution=32, device='cuda:0', seed=1)
-    with pytest.raises(RuntimeError):
-        g.set_option('mfma_bf16x3', 1)
+    for o in SPLITS:
+        with pytest.raises(RuntimeError):
+            g.set_option(o, 1)
