@@ -844,49 +844,58 @@ def main():
                      'what': 'the headline steps alternated over two engine contexts on two HIP streams (same kernels, same results; '
                              'the transition stages of one step overlap the decoder of the other)'}
         del m2
-    b3 = None
+    # OPT-IN EXPERIMENTS, never the headline (narrower operands than the reference's fp32 arithmetic): the same steps with the decoder's
+    # Linear(256, 16384) and its three large transposed convolutions on the 16-bit matrix pipe, both operands split (csrc/bf16x3.hip):
+    #   mfma_bf16x3: three bf16 planes, 6 products per fp32-equivalent MAC;   mfma_f16x2: two fp16 planes, 3 products, weights scaled by 2^k
+    # fp32 accumulation; every decoder-bearing fixture passes at the UNCHANGED tolerances in both modes (tests/test_gpu_parity.py::test_split_operands_*)
+    PEAK_16BIT_TF = 2516.6                                         # dense bf16 / fp16 MFMA, MI355X_MICROARCH.md
+    SPLIT_MODES = {'mfma_bf16x3': ('rollout_bf16x3', 6, 'bf16 x 3 planes per operand, 6 products'),
+                   'mfma_f16x2': ('rollout_f16x2', 3, 'fp16 x 2 planes per operand, 3 products, weights x 2^k')}
+    splits = {}
     if not a.no_extras and solo:
-        # OPT-IN EXPERIMENT, never the headline (narrower inputs than the reference's fp32 arithmetic): the same steps with the decoder's
-        # Linear(256, 16384) on the bf16 matrix pipe, both operands split into three bf16 planes (engine option mfma_bf16x3, csrc/bf16x3.hip:
-        # 6 products, fp32 accumulation; every fixture passes at the unchanged tolerances with it, profiles/r5_observed_errors.txt)
-        PEAK_BF16_TF = 2516.6                                      # dense bf16 MFMA, MI355X_MICROARCH.md; 6 products per fp32-equivalent MAC
-        model.set_option('mfma_bf16x3', 1)
-        try:
-            for k in range(4):
-                step(kk); kk += 1
-            regs3, _, kk = timed_regions(step, a.steps, kk, rk, min_total_s=2.0, max_regions=12)
-            dt3 = statistics.median(regs3)
-            cls3 = {}
-            for c_ in ('dec_dense_16384', 'dec_a_convT1_convT2', 'dec_b_convT3_final_reduce'):       # one class per pass (event pairs around every launch inflate a step)
-                model.prof_enable(True, classes=[c_])
-                for _ in range(5):
+        n_img = 3 * S * D * R                                      # decoder rows of one step (19 200 at the default size)
+        fp32k = locals().get('kern') or {}
+        for opt, (xkey, nprod, dtxt) in SPLIT_MODES.items():
+            peak = PEAK_16BIT_TF / nprod                            # fp32-equivalent TFLOP/s: every MAC costs `nprod` 16-bit products
+            model.set_option(opt, 1)
+            try:
+                for k in range(4):
                     step(kk); kk += 1
-                ms_, n_ = model.prof_read()[c_]
-                cls3[c_] = ms_ / max(n_, 1)
-            model.prof_enable(False)
-            n_img = 3 * S * D * R                                   # decoder rows of one step (19 200 at the default size)
-            fp32k = locals().get('kern') or {}
-            def kline(name, cls, macs_row):
-                ms_ = cls3[cls]
-                tf = 2.0 * macs_row * n_img / (ms_ * 1e-3) / 1e12 if ms_ > 0 else None
-                return {'name': name, 'avg_launch_ms': ms_, 'fp32_kernel_ms': (fp32k.get(cls) or {}).get('ms'), 'fp32_equivalent_tflops': tf,
-                        'frac_of_bf16_peak_over_6': tf / (PEAK_BF16_TF / 6.0) if tf else None}
-            kfc4 = kline('k_fc4_b3', 'dec_dense_16384', 256 * 16384)
-            kda = kline('k_dec_a_b3', 'dec_a_convT1_convT2', 2 * 256 * 9 * 64 * 64)
-            b3 = {'value': R * a.steps / dt3, 'unit': 'rollouts/s', 'ms_per_step': 1e3 * dt3 / a.steps, 'timed_regions': len(regs3),
-                  'dtype': 'bf16 x 3 planes per operand, 6 products, fp32 accumulate (Linear(256, 16384), ConvT(64,64,s1), ConvT(64,64,s2); every other kernel f32)',
-                  'what': 'EXPERIMENT, not the headline: engine option mfma_bf16x3 = 1 on the headline workload',
-                  'kernels': [kfc4, kda,
-                              {'name': 'k_dec_b4 (UNCHANGED fp32 kernel, behind the two bf16 kernels)', 'avg_launch_ms': cls3['dec_b_convT3_final_reduce'],
-                               'fp32_kernel_ms': (fp32k.get('dec_b_convT3_final_reduce') or {}).get('ms'),
-                               'note': 'the same binary runs slower here than in the headline: the board lowers its clock under the bf16 kernels (power)'}],
-                  'roofline': {'bound': 'mfma', 'kernel': 'k_dec_a_b3', 'peak': PEAK_BF16_TF / 6.0, 'unit': 'TFLOP/s (fp32-equivalent: bf16 dense peak / 6 products)',
-                               'achieved': kda['fp32_equivalent_tflops'], 'frac': kda['frac_of_bf16_peak_over_6']},
-                  'speedup_vs_headline': (R * a.steps / dt3) / value if rank == 0 else None}
-        except Exception as ex:          # an experiment must never cost the line its headline
-            b3 = {'error': repr(ex)[:300]}
-        finally:
-            model.set_option('mfma_bf16x3', 0)
+                with ClockSampler(device) as clk3:
+                    regs3, _, kk = timed_regions(step, a.steps, kk, rk, min_total_s=2.0, max_regions=12)
+                dt3 = statistics.median(regs3)
+                cls3 = {}
+                for c_ in ('dec_dense_16384', 'dec_a_convT1_convT2', 'dec_b_convT3_final_reduce'):       # one class per pass (event pairs around every launch inflate a step)
+                    model.prof_enable(True, classes=[c_])
+                    for _ in range(5):
+                        step(kk); kk += 1
+                    ms_, n_ = model.prof_read()[c_]
+                    cls3[c_] = ms_ / max(n_, 1)
+                model.prof_enable(False)
+
+                def kline(name, cls, macs_row):
+                    ms_ = cls3[cls]
+                    tf = 2.0 * macs_row * n_img / (ms_ * 1e-3) / 1e12 if ms_ > 0 else None
+                    return {'name': name, 'avg_launch_ms': ms_, 'fp32_kernel_ms': (fp32k.get(cls) or {}).get('ms'), 'fp32_equivalent_tflops': tf,
+                            'frac_of_16bit_peak_over_products': tf / peak if tf else None}
+                ks_ = [kline('k_fc4_b3', 'dec_dense_16384', 256 * 16384), kline('k_dec_a_b3', 'dec_a_convT1_convT2', 2 * 256 * 9 * 64 * 64),
+                       kline('k_dec_b_b3 (ConvT3 on the 16-bit pipe; the 32 -> 1 layer, sigmoid and sums stay fp32)', 'dec_b_convT3_final_reduce', MAC_DECB_ROW)]
+                dom3 = max(ks_, key=lambda e: e['avg_launch_ms'])   # the roofline entry is the experiment's own dominant kernel
+                x = {'value': R * a.steps / dt3, 'unit': 'rollouts/s', 'ms_per_step': 1e3 * dt3 / a.steps, 'timed_regions': len(regs3),
+                     'dtype': dtxt + ', fp32 accumulate (Linear(256, 16384), ConvT(64,64,s1), ConvT(64,64,s2), ConvT(64,32,s2); every other kernel f32)',
+                     'what': f'EXPERIMENT, not the headline: engine option {opt} = 1 on the headline workload',
+                     'kernels': ks_,
+                     'roofline': {'bound': 'mfma', 'kernel': dom3['name'], 'peak': peak,
+                                  'unit': f'TFLOP/s (fp32-equivalent: 16-bit dense peak {PEAK_16BIT_TF} / {nprod} products)',
+                                  'achieved': dom3['fp32_equivalent_tflops'], 'frac': dom3['frac_of_16bit_peak_over_products'],
+                                  'avg_launch_ms': dom3['avg_launch_ms'], 'traffic': None},
+                     'speedup_vs_headline': (R * a.steps / dt3) / value if rank == 0 else None}
+                x['roofline'].update(clk3.report(dom3['frac_of_16bit_peak_over_products']))
+                splits[opt] = x
+            except Exception as ex:          # an experiment must never cost the line its headline
+                splits[opt] = {'error': repr(ex)[:300]}
+            finally:
+                model.set_option(opt, 0)
     if not a.no_extras:
         # every rank runs the extras (they are collective at N > 1); rank 0 attaches them
         key = 'mcts_cfg3' if world == 1 else 'mcts_cfg4_sharded'
@@ -898,20 +907,22 @@ def main():
         mcadj = bench_mcts(a_np, model, device, rk, 3, 1, False, threshold=2.0, min_total_s=2.0)
         mc05['full_work_adjacent'] = {'value': mcadj['value'], 'ms_per_step': mcadj['ms_per_step'], 'timed_regions': mcadj['timed_regions']}
         mc05['speedup_vs_adjacent_full_work'] = mc05['value'] / mcadj['value']
-        if b3 is not None and 'error' not in b3:
-            # the planner with the experiment on (its expansions are 7 680-image launches: the bf16 kernels serve them; the 960-image simulations too)
-            model.set_option('mfma_bf16x3', 1)
-            mcb3 = None
+        for opt, x in splits.items():
+            if 'error' in x:
+                continue
+            # the planner with the experiment on (its expansions are 7 680-image launches: the split kernels serve them; the 960-image simulations too)
+            model.set_option(opt, 1)
+            mcx = None
             try:
-                mcb3 = bench_mcts(a_np, model, device, rk, 3, 1, False, threshold=2.0, min_total_s=2.0)
+                mcx = bench_mcts(a_np, model, device, rk, 3, 1, False, threshold=2.0, min_total_s=2.0)
             except Exception as ex:
-                b3['mcts_cfg3'] = {'error': repr(ex)[:300]}
+                x['mcts_cfg3'] = {'error': repr(ex)[:300]}
             finally:
-                model.set_option('mfma_bf16x3', 0)
-            if mcb3 is not None:
-                b3['mcts_cfg3'] = {'value': mcb3['value'], 'unit': mcb3['unit'], 'ms_per_step': mcb3['ms_per_step'], 'timed_regions': mcb3['timed_regions'],
-                                   'speedup_vs_fp32_adjacent': mcb3['value'] / mcadj['value'],
-                                   'what': 'EXPERIMENT: configs[2] (64 episodes in lock-step) with mfma_bf16x3 = 1, against the full-work fp32 measurement taken right before it'}
+                model.set_option(opt, 0)
+            if mcx is not None:
+                x['mcts_cfg3'] = {'value': mcx['value'], 'unit': mcx['unit'], 'ms_per_step': mcx['ms_per_step'], 'timed_regions': mcx['timed_regions'],
+                                  'speedup_vs_fp32_adjacent': mcx['value'] / mcadj['value'],
+                                  'what': f'EXPERIMENT: configs[2] (64 episodes in lock-step) with {opt} = 1, against the full-work fp32 measurement taken right before the experiments'}
         single = bench_single_episode(model, device, a.samples) if world == 1 else None
         del model
         torch.cuda.empty_cache()
@@ -920,8 +931,8 @@ def main():
             out['extras'] = {key: mc, key + '_threshold_0.5': mc05, 'animalai_cfg5': ai}
             if pipelined:
                 out['extras']['rollout_two_streams'] = pipelined
-            if b3:
-                out['extras']['rollout_bf16x3'] = b3
+            for opt, x in splits.items():
+                out['extras'][SPLIT_MODES[opt][0]] = x
             if single:
                 out['extras']['single_episode'] = single
     emit(out)

@@ -500,7 +500,8 @@ template <class SC> struct DbbL {                        // LDS layout for NPL p
     static constexpr int PXB = SC::NPL * 128 + 16;                       // bytes per staged pixel
     static constexpr int W0 = ((DBB_ZPX + 1) * PXB + 255) & ~255;
     static constexpr int SLAB = 9 * SC::NPL * 1024;                      // one 16-channel step: [9 taps][NPL planes][64 lanes][16 B]
-    static constexpr int H = W0 + 2 * SLAB;
+    static constexpr bool RES = SC::NPL == 2;                            // two planes: all four steps' weights stay in LDS (72 KiB), copied once per workgroup
+    static constexpr int H = W0 + (RES ? 4 : 2) * SLAB;
     static constexpr size_t LDS = H + (size_t)DBB_YROWS * 2 * 3 * 64 * sizeof(float);
 };
 
@@ -522,7 +523,7 @@ __device__ __forceinline__ void dbb_strip(f32x16 (&acc)[3], const unsigned char*
     constexpr int AX[3] = {0, PH ? 0 : 1, 1}, AY[3] = {1, PH ? 1 : 2, 2};
     float4 ax[2][NPL], ay[2][NPL], bx[2][NPL], by[2][NPL];
     auto ld = [&](int ks, int i, int l, float4 (&axn)[NPL], float4 (&ayn)[NPL], float4 (&bxn)[NPL], float4 (&byn)[NPL]) {       // fragment read l of pair i of step ks
-        const unsigned char* slab = abase + (ks & 1) * SLAB;
+        const unsigned char* slab = abase + (DbbL<SC>::RES ? ks : (ks & 1)) * SLAB;
         const int k = l / NPL, p = l % NPL;
         if (k == 0) axn[p] = *reinterpret_cast<const float4*>(slab + (TX[i] * NPL + p) * 1024);
         else if (k == 1) bxn[p] = *reinterpret_cast<const float4*>(bv[VX[i]] + p * 128 + ks * 32);
@@ -602,7 +603,9 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
             if (piece < 9 * NPL) glds16(Wg + (size_t)ks * DBB_SLAB + piece * 1024, lds_w0 + (unsigned)(buf * DBB_SLAB + piece * 1024));
         }
     };
-    slab_dma(0, 0);
+    constexpr bool RES = DbbL<SC>::RES;
+    if (RES) { slab_dma(0, 0); slab_dma(1, 1); slab_dma(2, 2); slab_dma(3, 3); }      // resident weights: no per-step copies, no per-step barriers
+    else slab_dma(0, 0);
     auto put_planes = [&](unsigned char* px, int c, const float v0, const float v1, const float v2, const float v3) {
         uint32_t pa_[NPL], pb_[NPL];
         SC::split_pk(v0, v1, pa_); SC::split_pk(v2, v3, pb_);
@@ -680,8 +683,10 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
             f32x16 acc[3];
             const bool last = s + 1 == NS;
             auto sync = [&](int ks) {
-                glds_drain();                                     // this wave's pieces of slab ks have landed ...
-                __syncthreads();                                  // ... and everybody's (ks = 0: the staged strip too); nobody reads the other buffer any more
+                if (!RES || ks == 0) {
+                    glds_drain();                                 // this wave's pieces of slab ks have landed ...
+                    __syncthreads();                              // ... and everybody's (ks = 0: the staged strip too); nobody reads the other buffer any more
+                }
                 if (ks == 0) {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {              // accumulators start at the bias (register e holds channel (e & 3) + 8 (e >> 2) + 4 h)
@@ -692,7 +697,7 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
                     acc[1] = acc[0];
                     acc[2] = (f32x16)(0.f);
                 }
-                if (ks < 3 || !last || nimg < a.rows) slab_dma((ks + 1) & 3, (ks + 1) & 1);
+                if (!RES && (ks < 3 || !last || nimg < a.rows)) slab_dma((ks + 1) & 3, (ks + 1) & 1);
                 if (ks == 3) {                                    // the next strip's rows (the next image's first strip behind the last one), behind the slab request
                     const size_t ib = (size_t)(last ? (nimg < a.rows ? nimg : img) : img) * (32 * 32 * 16);
                     const int r0 = last ? 0 : SR * (s + 1);

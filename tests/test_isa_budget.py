@@ -36,7 +36,8 @@ BUDGET = {
     'k_convt_p<1, 4>': 168, 'k_convt_p<1, 8>': 168, 'k_convt_p<2, 4>': 168, 'k_convt_p<2, 8>': 168, 'k_convt_12<4>': 256,
     'k_conv_e<1, 4>': 168, 'k_conv_e<2, 16>': 168, 'k_conv_e12': 256,
     'k_trans_fused': 256, 'k_head<16>': 256, 'k_head<32>': 256,
-    'k_fc4_b3': 256, 'k_dec_a_b3<1>': 256,                                      # the opt-in bf16 x 3 experiment: one 8-wave workgroup per CU = 2 waves per SIMD
+    # the opt-in split-operand experiments (bf16 x 3 / fp16 x 2 planes): one 8-wave workgroup per CU = 2 waves per SIMD
+    'k_fc4_b3<SchB3>': 256, 'k_fc4_b3<SchH2>': 256, 'k_dec_a_b3<SchB3, 1>': 256, 'k_dec_a_b3<SchH2, 1>': 256, 'k_dec_b_b3<SchB3>': 256, 'k_dec_b_b3<SchH2>': 256,
 }
 
 
@@ -56,6 +57,7 @@ SSPILL = {
     'k_conv_e<1, 4>': 0, 'k_conv_e<2, 16>': 0, 'k_conv_e12': 0,
     'k_enc_trunk': 26, 'k_head<16>': 25, 'k_head<32>': 22,      # (+4 / +10 with the row-identity pointer of ABI 4 among the kernel arguments)
     'k_final_g': 47,            # fallback of the generic decoder tail (option fuse_final_g = 0 / the resolution-32 variant)
+    'k_dec_b_b3<SchB3>': 35, 'k_dec_b_b3<SchH2>': 28,      # (persistent image loop + per-strip gather state: spilled scalars are re-read outside the MFMA stream)
     'k_sim_chain<1>': 131, 'k_sim_chain<8>': 180,      # latency-bound one-launch simulation chain (one workgroup per 8 episodes / split over eight)
 }
 SSPILL_DEFAULT = 0
