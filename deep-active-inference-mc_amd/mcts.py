@@ -240,6 +240,11 @@ class BatchedMCTS:
         # (a private copy: planners are cached by the VALUE of the parameters, a caller that later mutates its object must not change a
         # cached planner whose buffers were sized for the old values)
         self.E, self.p = int(n_episodes), copy.copy(params)
+        if getattr(params, 'use_graph', False):
+            # (removed with ABI 5: the hipGraph replay of an iteration.  Said once, loudly, instead of silently ignoring the attribute)
+            import warnings
+            warnings.warn('MCTS_Params.use_graph is no longer supported (removed with engine ABI 5) and is ignored: the planner launches its '
+                          'iterations directly (INTEGRATION.md section 4)', RuntimeWarning, stacklevel=3)
         self.pi_dim = A = model.pi_dim
         self.ep0 = int(episode_offset)
         self.cap = cap = 1 + A * (params.repeats + 2)

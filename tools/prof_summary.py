@@ -26,6 +26,23 @@ MACS_G84 = {'k_dec_bg<3>': 21 * 21 * 4 * 9 * 64 * 32 + 84 * 84 * 9 * 32 * 3, 'k_
             'k_fc4<2>': 256 * 64 * 21 * 21}
 
 
+# the opt-in split-operand kernels (csrc/bf16x3.hip): fp32-equivalent work against the dense 16-bit MFMA peak / products per MAC
+PEAK_16 = 2516.6
+SPLIT = {'SchB3': 6, 'SchH2': 3}
+MACS_SPLIT = {'k_fc4_b3': 4194304, 'k_dec_a_b3': 18874368, 'k_dec_b_b3': 20054016}
+
+
+def split_peak(k):
+    """(macs per image, peak TFLOP/s) of a split-operand kernel instance, or None"""
+    base = k.split('<')[0]
+    if base not in MACS_SPLIT:
+        return None
+    for sc, nprod in SPLIT.items():
+        if sc in k:
+            return MACS_SPLIT[base], PEAK_16 / nprod
+    return None
+
+
 def steady_table(d, rows_arg):
     """-> lines; per kernel the MEDIAN duration of its calls in the kernel trace and the roofline fraction it implies"""
     tr = glob.glob(os.path.join(d, 'kt', '**', '*kernel_trace.csv'), recursive=True)
@@ -39,7 +56,7 @@ def steady_table(d, rows_arg):
     generic = any(k.startswith('k_dec_bg') for k in calls)
     macs = dict(MACS, **MACS_G84) if generic else MACS
     per_img = [k for k in calls if k.startswith('k_dec_b4<1>') or k.startswith('k_dec_bg')]
-    rows = rows_arg or max((max(c[2] for c in calls[k]) for k in per_img), default=0)
+    rows = rows_arg or max((max(c[2] for c in calls[k]) for k in per_img), default=0) or 19200       # (a split-mode profile has no one-workgroup-per-image kernel: the headline's 19 200)
     out = ['\n== steady state (kernel trace, median over each kernel\'s calls) and the roofline fraction it implies ==',
            f'(persistent kernels: {rows} images per launch; peak {PEAK_TF} TFLOP/s fp32 MFMA; algorithmic MACs per image from DESIGN section 5)',
            f'{"kernel":28s} {"calls":>6s} {"all_avg_us":>11s} {"median_us":>14s} {"min_us":>14s} {"images":>8s} {"TFLOP/s":>9s} {"frac":>7s}']
@@ -55,7 +72,12 @@ def steady_table(d, rows_arg):
         avg = (durs[(len(durs) - 1) // 2] + durs[len(durs) // 2]) / 2e3
         mn = durs[0] / 1e3
         n_img = big if k in per_img else rows
-        if k in macs and n_img:
+        sp = split_peak(k)
+        if sp and n_img:
+            tf = 2.0 * sp[0] * n_img / (avg * 1e-6) / 1e12
+            fr[k] = tf / sp[1]
+            out.append(f'{k:28s} {len(c):6d} {avg_all:11.1f} {avg:14.1f} {mn:14.1f} {n_img:8d} {tf:9.1f} {tf / sp[1]:7.3f}   (fp32-equivalent; of {sp[1]:.1f} = 16-bit peak / products)')
+        elif k in macs and n_img:
             tf = 2.0 * macs[k] * n_img / (avg * 1e-6) / 1e12
             fr[k] = tf / PEAK_TF
             out.append(f'{k:28s} {len(c):6d} {avg_all:11.1f} {avg:14.1f} {mn:14.1f} {n_img:8d} {tf:9.1f} {tf / PEAK_TF:7.3f}')
@@ -137,7 +159,7 @@ def main(d, rows_arg=0):
             cs = glob.glob(os.path.join(d, sub, '**', '*counter_collection.csv'), recursive=True)
             for r in csv.DictReader(open(cs[0])):
                 k = short(r['Kernel_Name'])
-                if r['Counter_Name'] != key or not k.startswith('k_dec'):
+                if r['Counter_Name'] != key or not k.startswith('k_dec') or k.startswith('k_dec_b_b3'):        # (k_dec_b_b3 is persistent: its grid is not its image count)
                     continue
                 k = 'k_dec_b' if k.startswith('k_dec_b') else k.split('<')[0]      # k_dec_b4 / k_dec_b<SR,RW>: one workgroup = one image
                 e = tr.setdefault(k, {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0, 'images_f': 0, 'images_w': 0})
