@@ -346,6 +346,21 @@ def test_device_noise_simulate_has_the_reference_distribution(model):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('opt', ['mfma_bf16x3', 'mfma_f16x2'])
+def test_device_noise_distributions_with_split_operands(model, opt):
+    """the opt-in split-operand decoder kernels (csrc/bf16x3.hip: three bf16 planes / two fp16 planes per operand) under the SAME
+    distribution tests, same bounds: calculate_G over 262 144 rows, the rollout over 4 096 rows and the 2 048-episode simulation are all
+    launches of far more than 128 images, i.e. they run k_fc4_b3 / k_dec_a_b3 / k_dec_b_b3"""
+    model.set_option(opt, 1)
+    try:
+        test_device_noise_calculate_G_over_rows_has_the_reference_distribution(model)
+        test_device_noise_rollout_has_the_reference_distribution(model)
+        test_device_noise_simulate_has_the_reference_distribution(model)
+    finally:
+        model.set_option(opt, 0)
+
+
+@pytest.mark.gpu
 def test_device_noise_planner_decisions_have_the_reference_distribution(model):
     """one level up: whole DECISIONS.  512 runs of the reference planner (active_inference_mcts, /root/reference/src/mcts.py:150-195, its
     default parameters at repeats 12 / depth 3 / threshold 0.3) under torch's own generator (oracle/make_golden_stats_planner.py) against 2 048 episodes of

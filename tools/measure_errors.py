@@ -1,6 +1,7 @@
 """dev tool: observed |engine - fixture| per quantity over the committed goldens (basis of the tolerances in tests/test_gpu_parity.py)
 
-  python tools/measure_errors.py [bf16x3]      bf16x3: with the opt-in experiment mfma_bf16x3 on (csrc/bf16x3.hip)"""
+  python tools/measure_errors.py [bf16x3 | f16x2]      with the opt-in split-operand experiment mfma_bf16x3 / mfma_f16x2 on (csrc/bf16x3.hip);
+                                                       the small fixtures reach k_fc4_b3 only -- the last block measures the large-launch kernels too"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,12 +10,13 @@ import daimc_amd
 from conftest import load_golden, eps_calcG, eps_rollout
 from oracle import synth, philox as PX
 worst = {}
-B3 = len(sys.argv) > 1 and sys.argv[1] == 'bf16x3'
+OPT = {'bf16x3': 'mfma_bf16x3', 'f16x2': 'mfma_f16x2'}.get(sys.argv[1] if len(sys.argv) > 1 else '', None)
+B3 = OPT is not None
 _orig_load = daimc_amd.ActiveInferenceModel.load_flat_weights
 def _load(self, w):
     _orig_load(self, w)
     if B3:
-        self.set_option('mfma_bf16x3', 1)
+        self.set_option(OPT, 1)
 daimc_amd.ActiveInferenceModel.load_flat_weights = _load
 def upd(k, a, b):
     d = float(np.max(np.abs(a.detach().cpu().numpy() - b)))
@@ -45,6 +47,16 @@ for name in ('rollout_cfg1', 'rollout_m8d2s2', 'rollout_m8d2s2mean'):
     D, S, st, M = int(g['steps']), int(g['samples']), int(g['stage']), len(g['o'])
     sG, T, po1 = m.calculate_G_repeated(g['o'], g['pi'], steps=D, calc_mean=bool(g['calc_mean']), samples=S, stage=st, eps=eps_rollout(int(g['nseed']), M, D, S, st))
     upd('rollout sum_G', sG, g['sum_G']); upd('rollout t0', T[0], g['t0']); upd('rollout t1', T[1], g['t1'])
-print('engine option mfma_bf16x3 =', int(B3))
+# large launches (the persistent split kernels need more than 128 images): 1 100 decoder rows against the oracle
+from oracle import efe_oracle as EO
+w = synth.make_weights(1234, 1.15)
+m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=31, init_weights=False)
+m.load_flat_weights(w)
+s_ = PX.uniform_fill(12, (1100, 10), 400, -1.5, 1.5)
+got = m.model_down.decoder(s_, stage=5, pass_=PX.PASS_D2A)
+with torch.no_grad():
+    o = EO.OracleModel(w, EO.PhiloxNoise(31)).decoder(torch.from_numpy(s_[:300]), PX.PASS_D2A, 0, 5).numpy()
+upd('decoder po, 1100-row launch vs oracle', got[:300], o)
+print('engine option', OPT, '=', int(B3))
 for k, v in worst.items():
-    print(f'{k:16s} max |engine - reference fixture| = {v:.3e}')
+    print(f'{k:40s} max |engine - reference| = {v:.3e}')
