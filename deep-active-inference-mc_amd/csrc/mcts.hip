@@ -22,19 +22,24 @@ __device__ __forceinline__ int argmax_nan_first(const float* v, int n) {        
     return best;
 }
 
+// Tree-policy walk of ONE episode (mcts.py:49-62).  A level costs ONE memory latency: the W / N / Qpi / child rows of the current node are
+// requested together, and "the node just reached has no children" (mcts.py:56) is read off the child row that the next level loads anyway.
+// Entries of path_nodes / path_act at and beyond path_len are not written (every consumer stops at path_len).
 __device__ __forceinline__ void mcts_select_one(const MctsTree& t, int e, const uint8_t* active, float C, int use_prior, int max_depth,
                                                 int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf,
                                                 float* leaf_s /*[E][s_dim]*/, float* leaf_s_rep /*[E*A][s_dim]*/) {
     const int A = t.A;
     int cur = 0, len = 0;
-    for (int d = 0; d < max_depth; ++d) { path_nodes[(size_t)e * max_depth + d] = 0; path_act[(size_t)e * max_depth + d] = 0; }
     if (active[e]) {
         for (int d = 0; d < max_depth; ++d) {
             const size_t o = ((size_t)e * t.cap + cur) * A;
+            float w[8], n[8], qp[8]; int ch[8];
+            for (int i = 0; i < A; ++i) { w[i] = t.W[o + i]; n[i] = t.N[o + i]; ch[i] = t.child[o + i]; qp[i] = use_prior ? t.Qpi[o + i] : 0.f; }
+            if (d > 0 && ch[0] < 0) break;                           // the node reached by the previous level is a leaf
             float q[8], sc[8];
             float qmin = 0.f; bool nan_min = false;
             for (int i = 0; i < A; ++i) {
-                q[i] = t.W[o + i] / t.N[o + i];
+                q[i] = w[i] / n[i];
                 if (q[i] != q[i]) nan_min = true;
                 if (i == 0 || q[i] < qmin) qmin = q[i];
             }
@@ -43,15 +48,14 @@ __device__ __forceinline__ void mcts_select_one(const MctsTree& t, int e, const 
             for (int i = 0; i < A; ++i) { q[i] = q[i] - qmin; sum = (i == 0) ? q[i] : sum + q[i]; }
             for (int i = 0; i < A; ++i) {
                 // mcts.py:45-47: `C * Qpi * 1.0 / N` evaluates left to right as ((C * Qpi) * 1.0) / N; without the prior (C * 1.0) / N
-                const float bonus = use_prior ? rounded(C * t.Qpi[o + i]) / t.N[o + i] : C / t.N[o + i];
+                const float bonus = use_prior ? rounded(C * qp[i]) / n[i] : C / n[i];
                 sc[i] = rounded(q[i] / sum) + bonus;
             }
             const int a = argmax_nan_first(sc, A);
             path_nodes[(size_t)e * max_depth + d] = cur;
             path_act[(size_t)e * max_depth + d] = a;
             len = d + 1;
-            cur = t.child[o + a];
-            if (t.child[((size_t)e * t.cap + cur) * A] < 0) break;      // the reached node has no children: it is the leaf
+            cur = ch[a];
         }
     }
     path_len[e] = len;
@@ -104,10 +108,20 @@ __device__ __forceinline__ void mcts_backprop_one(const MctsTree& t, int e, cons
     const int A = t.A;
     const size_t ol = ((size_t)e * t.cap + leaf[e]) * A;
     for (int a = 0; a < A; ++a) t.Qpi[ol + a] = q0[(size_t)e * A + a];
-    for (int d = 0; d < path_len[e]; ++d) {
-        const size_t o = ((size_t)e * t.cap + path_nodes[(size_t)e * max_depth + d]) * A + path_act[(size_t)e * max_depth + d];
-        t.W[o] -= g;
-        t.N[o] += 1.0f;
+    // (a path visits every node once: its entries are independent, requested back to back)
+    const int L = path_len[e];
+    for (int d0 = 0; d0 < L; d0 += 8) {
+        size_t o[8]; float w[8], n[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int d = d0 + i < L ? d0 + i : d0;                  // (entries past the path re-read a valid one and store nothing)
+            o[i] = ((size_t)e * t.cap + path_nodes[(size_t)e * max_depth + d]) * A + path_act[(size_t)e * max_depth + d];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { w[i] = t.W[o[i]]; n[i] = t.N[o[i]]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (d0 + i < L) { t.W[o[i]] = w[i] - g; t.N[o[i]] = n[i] + 1.0f; }
     }
 }
 __global__ void k_mcts_backprop(const MctsTree t, const int32_t* path_nodes, const int32_t* path_act, const int32_t* path_len,
