@@ -40,7 +40,10 @@ __device__ __forceinline__ void glds_drain() { asm volatile("s_waitcnt vmcnt(0)"
 
 template <int NPL> struct Fc4L {
     static constexpr int ROWB = NPL * 512 + 16;                   // bytes per staged row: NPL planes of 256 x 16 bit + padding
-    static constexpr size_t LDS = (size_t)64 * ROWB;              // 99 328 B (three planes): one workgroup per CU
+    // 32-row tiles per workgroup pass: 64 rows with three planes (99 328 B), 96 rows with two (99 840 B) -- a weight fragment crosses the L1
+    // once per wave and (row tile, feature step): 1.5 x the rows = two thirds of the fragment traffic, which is what bounds this kernel
+    static constexpr int NT = NPL == 2 ? 3 : 2;        // (four tiles need 128 accumulator + 96 fragment registers: spills)
+    static constexpr size_t LDS = (size_t)32 * NT * ROWB;
 };
 
 // round-to-nearest-even fp32 -> bf16 (finite inputs), as the upper 16 bits
@@ -132,7 +135,7 @@ __host__ __device__ inline int fc4b3_spg(int mtiles) { return ((mtiles + 15) / 1
 
 template <class SC>
 __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
-    constexpr int NPL = SC::NPL, B3_ROWB = Fc4L<SC::NPL>::ROWB;
+    constexpr int NPL = SC::NPL, B3_ROWB = Fc4L<SC::NPL>::ROWB, NT = Fc4L<SC::NPL>::NT, RT = 32 * NT;      // NT 32-row tiles per workgroup pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -143,26 +146,28 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
     const int fgrp = blockIdx.x & 7;
     const int nper = gridDim.x >> 3, k = blockIdx.x >> 3;
     const int SPG = fc4b3_spg(a.mtiles);
-    const int nsteps = ((a.n_pix + 63) / 64) * SPG;
+    const int nsteps = ((a.n_pix + RT - 1) / RT) * SPG;
     const int q0 = (int)(((long)nsteps * k) / nper), q1 = (int)(((long)nsteps * (k + 1)) / nper);
     const __amdgpu_buffer_rsrc_t wr = wrsrc(a.Wb3);
     const unsigned ln = (unsigned)lane * 16u;
     // this lane's B fragments: row nt * 32 + j, plane p, step ks at byte  row * B3_ROWB + p * 512 + ks * 32 + g * 16
-    const unsigned char* brow[2] = {smb + (size_t)j * B3_ROWB + g * 16, smb + (size_t)(32 + j) * B3_ROWB + g * 16};
+    const unsigned char* brow[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) brow[nt] = smb + (size_t)(32 * nt + j) * B3_ROWB + g * 16;
     int cur_rt = -1;
-    uint32_t krow[2] = {0, 0}, kstream[2] = {0, 0}, kstage[2] = {0, 0};
-    bool rv[2] = {false, false};
+    uint32_t krow[NT] = {}, kstream[NT] = {}, kstage[NT] = {};
+    bool rv[NT] = {};
 #pragma unroll 1
     for (int q = q0; q < q1; ++q) {
         const int rt = q / SPG, fs = q - rt * SPG;
-        const int row0 = rt * 64;
+        const int row0 = rt * RT;
         if (rt != cur_rt) {
             if (cur_rt >= 0) __syncthreads();
             cur_rt = rt;
             const f32x4* X = reinterpret_cast<const f32x4*>(a.X);
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = it * 512 + tid;                        // 64 rows x 64 quads
+            for (int it = 0; it < RT / 8; ++it) {
+                const int idx = it * 512 + tid;                        // RT rows x 64 quads
                 const int r = idx >> 6, c4 = idx & 63;
                 const int gr = row0 + r;
                 const f32x4 v = (gr < a.n_pix) ? X[(size_t)gr * 64 + c4] : (f32x4)(0.f);
@@ -174,7 +179,7 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
             }
             __syncthreads();
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {                            // dropout keys of this lane's two rows
+            for (int nt = 0; nt < NT; ++nt) {                           // dropout keys of this lane's rows
                 const int m = row0 + nt * 32 + j;
                 rv[nt] = m < a.n_pix;
                 const int mg = a.m0 + (rv[nt] ? m : 0);
@@ -186,37 +191,38 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
         }
         const int mt0 = (fgrp * SPG + fs) * 16 + 2 * w;                 // this wave's first 32-feature tile
         if (mt0 >= a.mtiles) continue;                                  // wave-uniform (mtiles is even)
-        f32x16 acc[2][2];
+        f32x16 acc[2][NT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
-        float4 bq[2][4];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) bq[mt][g4] = *reinterpret_cast<const float4*>(a.bias + (mt0 + mt) * 32 + 8 * g4 + 4 * g);
         const float ws_inv = SC::SCALED ? a.wb3_scale_inv : 1.0f;        // fp16 split: the accumulators hold (weight scale) x W x
         // fragment of (tile mt, step ks, plane p): float4 index ((mt * 16 + ks) * 3 + p) * 64 + lane
         auto afrag = [&](int mt, int ks, int p) -> float4 { return wfrag(wr, ln, (size_t)(((mt0 + mt) * 16 + ks) * NPL + p) * 64); };
         auto bfrag = [&](int nt, int ks, int p) -> float4 { return *reinterpret_cast<const float4*>(brow[nt] + p * 512 + ks * 32); };
         // fragments of step ks live in buffer set ks & 1; the loop is fully unrolled so that every index is static (hipcc copies a
         // software-pipeline buffer it cannot rename: 48 v_mov per step and an s_waitcnt vmcnt(0) on the loads that were meant to stay in flight)
-        float4 af[2][2][NPL], bf[2][2][NPL];
+        float4 af[2][2][NPL], bf[2][NT][NPL];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) { af[0][t][p] = afrag(t, 0, p); bf[0][t][p] = bfrag(t, 0, p); }
+            for (int t = 0; t < 2; ++t) af[0][t][p] = afrag(t, 0, p);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bf[0][t][p] = bfrag(t, 0, p);
+        }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const int cb = ks & 1, nb = cb ^ 1;
             if (ks < 15) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-                    for (int p = 0; p < NPL; ++p) { af[nb][t][p] = afrag(t, ks + 1, p); bf[nb][t][p] = bfrag(t, ks + 1, p); }
+                    for (int t = 0; t < 2; ++t) af[nb][t][p] = afrag(t, ks + 1, p);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bf[nb][t][p] = bfrag(t, ks + 1, p);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             // the products, smallest first (SchB3: (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi); SchH2: (lo, hi) (hi, lo) (hi, hi))
@@ -225,13 +231,19 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = SC::mfma(af[cb][mt][SC::PA(pr)], bf[cb][nt][SC::PB(pr)], acc[mt][nt]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // epilogue: the same as k_fc4 (bias, ReLU, dropout mask from Philox, NHWC store)
+        // epilogue: the same as k_fc4 (bias, ReLU, dropout mask from Philox, NHWC store); the bias is requested here, not held through the
+        // contraction (32 registers that the three-tile form does not have)
+        float4 bq[2][4];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) bq[mt][g4] = *reinterpret_cast<const float4*>(a.bias + (mt0 + mt) * 32 + 8 * g4 + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
             if (!rv[nt]) continue;
             const uint4 rnd = noise_words(a.k0, a.k1, a.tag, (uint32_t)((mt0 * 32) >> 7), krow[nt], kstream[nt], kstage[nt]);
             float* yp = a.Y + (size_t)(row0 + nt * 32 + j) * a.ldy;
@@ -844,7 +856,8 @@ int init_bf16x3_kernels() {
 
 void launch_fc4_b3(const GemmArgs& a, hipStream_t st) {
     // persistent: one 8-wave workgroup per CU, 8 feature groups x 32 workgroups, each with >= 1 (row tile, step) pair
-    const int nsteps = ((a.n_pix + 63) / 64) * fc4b3_spg(a.mtiles);
+    const int rt = a.split == 2 ? 32 * Fc4L<2>::NT : 32 * Fc4L<3>::NT;
+    const int nsteps = ((a.n_pix + rt - 1) / rt) * fc4b3_spg(a.mtiles);
     const int nper = nsteps < 32 ? nsteps : 32;
     if (a.split == 2) hipLaunchKernelGGL(k_fc4_b3<SchH2>, dim3(8 * nper), dim3(512), Fc4L<2>::LDS, st, a);
     else hipLaunchKernelGGL(k_fc4_b3<SchB3>, dim3(8 * nper), dim3(512), Fc4L<3>::LDS, st, a);

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_a(const DecAArgs a) {
         const int j = tl_ & 31, h = (tl_ >> 5) & 1;
         const int pcol = j & 15;
         const int prow0 = 2 * NTW * w + (j >> 4);                      // tile nt covers rows prow0 + 2*nt
-        // a dead row of the call (efe_set_row_mask) keeps the schedule -- barriers, ticket, the next image's prefetch -- and skips the work
+        // a dead row of the call (efe_rows.mask) keeps the schedule -- barriers, ticket, the next image's prefetch -- and skips the work
         const bool live = row_live(a.live, img);
         if (live) {   // pixel it * (NTHR / 16) + (tid >> 4), quad tid & 15: one address register, immediate offsets
             const int sbase = (tl_ >> 4) * DA_PS + (tl_ & 15);
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_b4(const DecBArgs a) {
     constexpr int parts = PARTS;
     const int img = parts == 1 ? (int)blockIdx.x : (int)(blockIdx.x >> 2);
     const int qtr = parts == 1 ? 0 : (int)(blockIdx.x & 3);
-    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_rows.mask): workgroup-uniform
     const int s_lo = parts == 1 ? 0 : (qtr ? 2 * qtr - 1 : 0);          // first strip contracted (the halo strip of quarters 1..3)
     const int s_hi = parts == 1 ? NS : 2 * qtr + 2;
 

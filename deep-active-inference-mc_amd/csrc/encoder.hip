@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256, EFE_ENC_WAVES) k_enc_trunk(const EncArgs 
     const float4* W4 = reinterpret_cast<const float4*>(a.w4);             // [9][4][4][64], packed for the 16x16x4 form
 
     for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
-        if (!row_live(a.live, img)) continue;            // a dead row of the call (efe_set_row_mask): workgroup-uniform
+        if (!row_live(a.live, img)) continue;            // a dead row of the call (efe_rows.mask): workgroup-uniform
         // lane index laundered per image: hoisted out of the image loop, the per-phase LDS addresses derived from it are ~20 spilled VGPRs
         int ll = lane; asm volatile("" : "+v"(ll));
         const int j = ll & 31, h = ll >> 5;

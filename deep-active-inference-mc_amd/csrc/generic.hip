@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256, 2) k_final_g(const FinalGArgs a) {
     for (int i = tid; i < 27 * PS; i += 256) fg_T[i] = 0.0f;
 
     const int img = blockIdx.x;
-    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_rows.mask): workgroup-uniform
     const int mg = a.m0 + img;
     const int g = mg / a.rows_per_group;
     const int r = mg - g * a.rows_per_group;

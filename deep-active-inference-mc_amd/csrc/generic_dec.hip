@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256, 3) k_convt_p(const ConvGArgs a) {
     const int TH = (32 * ntw) / Win;
     const int spi = (Hin + TH - 1) / TH;
     const int img = blockIdx.x;
-    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_rows.mask): workgroup-uniform
     const int SPX = TH * Win;                          // pixels of a strip
     const int RP = (TH + PADT + 1) * Win, RPa = (RP + 15) & ~15, ZP = RPa;
     const int npix_img = Hin * Win;
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256, 2) k_convt_12(const ConvT12Args a) {
     const int TH = 64 / Win;
     const int NS = (Hin + TH - 1) / TH;
     const int img = blockIdx.x;
-    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_rows.mask): workgroup-uniform
     const int SPX = TH * Win;                          // pixels of a strip
     const int RP = (TH + 2) * Win, RPa = (RP + 15) & ~15;      // x ring: rows r0 - 1 .. r0 + TH
     const int RY = 2 * SPX, YB = RPa, ZP = RPa + ((RY + 15) & ~15);
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256, 2) k_dec_bg(const DecBGArgs a) {
     float* sE = sH + RING * NG * Wout;                                         // [RING][NG][2 sides][4 tiles][2]
     float* sD = sE + RING * NG * 16;                                           // [64 lanes][2]: where lanes without a pixel / a row group write
     const int img = blockIdx.x;
-    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_rows.mask): workgroup-uniform
 
     const int mg = a.m0 + img;
     const int g = mg / a.rows_per_group;

@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_e(const ConvEArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int img = blockIdx.x;
-    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_rows.mask): workgroup-uniform
     const int Win = a.Win, Hin = a.Hin, Wout = a.Wout, Hout = a.Hout, TY = a.TY;
     const int NR = 2 * TY + 1, WE = (Win + 1) >> 1;
     const int npix_img = Hin * Win;
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_e12(const ConvE12Args a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int img = blockIdx.x;
-    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_set_row_mask): workgroup-uniform
+    if (!row_live(a.live, img)) return;                // a dead row of the call (efe_rows.mask): workgroup-uniform
     const int W0 = a.W0, W1 = a.W1, W2 = a.W2, H2 = a.H2, TY = a.TY;
     const int NR = 2 * TY + 1, WE = (W1 + 1) >> 1;
     const char* ximg = reinterpret_cast<const char*>(a.in + (size_t)img * a.H0 * W0 * GEN_IMG_LD);
