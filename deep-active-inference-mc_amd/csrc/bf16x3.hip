@@ -82,8 +82,8 @@ __device__ __forceinline__ void split3_pk(float x0, float x1, uint32_t& hi, uint
 //          the matrix work, two thirds of the operand bytes.  fp16 has 5 exponent bits: the WEIGHTS are scaled by a power of two at pack
 //          time (largest |w| just below 2^14; the kernels multiply the accumulators back, exactly) so that their low planes are normal
 //          numbers; activations stay unscaled -- the matrix pipe and v_cvt_pk_f16_f32 keep fp16 denormals (tools/ubench/f16_probe.hip), so
-//          an activation below 2^-3 loses at most 2^-25 absolutely -- and must stay below 65 504 (a larger one becomes inf -> NaN
-//          sums: loud, never silently wrong).  Operand representation error 2^-22 relative: tools/f16_split_check.py.
+//          an activation below 2^-3 loses at most 2^-25 absolutely -- and must stay below 65 504: a larger one is DETECTED where it is
+//          split and the row / image poisoned (SchH2::overflow below): loud, never silently wrong.  Operand representation error 2^-22 relative: tools/f16_split_check.py.
 // Plane 0 = hi.  PA / PB: the weight / activation plane of product pr, small terms first.
 // ---------------------------------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -97,6 +97,7 @@ struct SchB3 {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ void split_pk(float x0, float x1, uint32_t (&pl)[3]) { split3_pk(x0, x1, pl[0], pl[1], pl[2]); }
+    static __device__ __forceinline__ uint32_t overflow(uint32_t) { return 0u; }       // bf16 has fp32's exponent range
 };
 struct SchH2 {
     static constexpr int NPL = 2, NPR = 3, MODE = 2;
@@ -113,6 +114,11 @@ struct SchH2 {
         const f32x2 r = v - __builtin_convertvector(hh, f32x2);          // exact
         pl[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2_t));
     }
+    // non-zero iff one of the two NON-NEGATIVE values behind the packed high plane `hi` did not fit fp16 (exponent field 31: inf, or a NaN
+    // that came in) -- every activation these kernels split is the output of a ReLU.  The kernels OR it over what they stage and POISON the
+    // outputs of an image / row that saw it (+inf downstream, NaN in the per-image sums): the integer-max ReLU would otherwise turn the
+    // (negative-signed) NaN of inf - inf into a finite, silently wrong number.
+    static __device__ __forceinline__ uint32_t overflow(uint32_t hi) { return (hi + 0x04000400u) & 0x80008000u; }
 };
 // host side: x (already scaled) -> NPL 16-bit planes
 inline void split_host(int mode, float x, uint32_t (&p)[3]) {
@@ -154,7 +160,11 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
     const unsigned char* brow[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) brow[nt] = smb + (size_t)(32 * nt + j) * B3_ROWB + g * 16;
-    int cur_rt = -1;
+    int cur_rt = -1, tpar = 1;
+    // fp16 split: rows whose input did not fit fp16, per row tile in flight (two arrays: tile k uses k & 1, the other one is cleared meanwhile)
+    __shared__ int sflag[2][32 * NT];
+    if (tid < 32 * NT) { sflag[0][tid] = 0; sflag[1][tid] = 0; }
+    __syncthreads();
     uint32_t krow[NT] = {}, kstream[NT] = {}, kstage[NT] = {};
     bool rv[NT] = {};
 #pragma unroll 1
@@ -164,6 +174,7 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
         if (rt != cur_rt) {
             if (cur_rt >= 0) __syncthreads();
             cur_rt = rt;
+            tpar ^= 1;
             const f32x4* X = reinterpret_cast<const f32x4*>(a.X);
 #pragma unroll
             for (int it = 0; it < RT / 8; ++it) {
@@ -173,11 +184,13 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
                 const f32x4 v = (gr < a.n_pix) ? X[(size_t)gr * 64 + c4] : (f32x4)(0.f);
                 uint32_t pa_[NPL], pb_[NPL];
                 SC::split_pk(v[0], v[1], pa_); SC::split_pk(v[2], v[3], pb_);
+                if (SC::SCALED && (SC::overflow(pa_[0]) | SC::overflow(pb_[0]))) sflag[tpar][r] = 1;        // (rare; every writer stores the same value)
                 unsigned char* d = smb + (size_t)r * B3_ROWB + c4 * 8;
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(d + p * 512) = make_uint2(pa_[p], pb_[p]);
             }
             __syncthreads();
+            if (SC::SCALED && tid < 32 * NT) sflag[tpar ^ 1][tid] = 0;  // (the previous tile's flags: its epilogues ended in front of this tile's first barrier)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {                           // dropout keys of this lane's rows
                 const int m = row0 + nt * 32 + j;
@@ -247,6 +260,7 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
             if (!rv[nt]) continue;
             const uint4 rnd = noise_words(a.k0, a.k1, a.tag, (uint32_t)((mt0 * 32) >> 7), krow[nt], kstream[nt], kstage[nt]);
             float* yp = a.Y + (size_t)(row0 + nt * 32 + j) * a.ldy;
+            const bool rbad = SC::SCALED && sflag[tpar][nt * 32 + j] != 0;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -264,6 +278,7 @@ __global__ void __launch_bounds__(512, 1) k_fc4_b3(const GemmArgs a) {
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = ((word >> ((co + e) & 31)) & 1u) ? fmaxf(v[e], 0.f) * 2.0f : 0.0f;
+                    if (SC::SCALED && rbad) v[0] = v[1] = v[2] = v[3] = __builtin_inff();      // an input of this row did not fit fp16: the row is poisoned (k_dec_a_b3 passes it on)
                     *reinterpret_cast<float4*>(yp + co) = make_float4(v[0], v[1], v[2], v[3]);
                 }
         }
@@ -332,12 +347,19 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
         for (int i = 0; i < PP; ++i) glds16(sp + i * 1024, lds_w0 + (unsigned)(buf * DA3_SLAB + i * 1024));
     };
     // fp32 quad (4 consecutive channels c .. c + 3 of one pixel) -> the three planes of that pixel
+    uint32_t ovf = 0;                                    // fp16 split: something this thread staged did not fit fp16
     auto put_planes = [&](unsigned char* px, int c, const float v0, const float v1, const float v2, const float v3) {
         uint32_t pa_[NPL], pb_[NPL];
         SC::split_pk(v0, v1, pa_); SC::split_pk(v2, v3, pb_);
+        ovf |= SC::overflow(pa_[0]) | SC::overflow(pb_[0]);
 #pragma unroll
         for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(px + p * 128 + c * 2) = make_uint2(pa_[p], pb_[p]);
     };
+    // the image's overflow flag: word (image count & 1), set behind the two staging phases, read by the layer-2 stores (tap barriers in
+    // between), the other word cleared meanwhile
+    __shared__ int sovf[2];
+    if (tid < 2) sovf[tid] = 0;
+    int nimgs = 0;
     f32x4 pf[NPF];                                       // the next image: 64 KiB / NTHR threads
     {
         const f32x4* X = reinterpret_cast<const f32x4*>(a.x4) + (size_t)blockIdx.x * 4096;
@@ -351,13 +373,17 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
     for (int img = blockIdx.x; img < a.rows; img += gridDim.x) {
         const bool live = row_live(a.live, img);
         const int nimg = img + (int)gridDim.x;
+        const int fpar = nimgs & 1;
+        ++nimgs;
         __syncthreads();                                  // every wave is done with the previous image's planes
+        if (SC::SCALED && tid == 0) sovf[fpar ^ 1] = 0;
         if (live) {
 #pragma unroll
             for (int it = 0; it < NPF; ++it) {
                 const int idx = it * NTHR + tid;          // pixel idx >> 4, channel quad idx & 15
                 put_planes(sm3 + (size_t)(idx >> 4) * DA3_PXB, 4 * (idx & 15), pf[it][0], pf[it][1], pf[it][2], pf[it][3]);
             }
+            if (SC::SCALED && ovf) { sovf[fpar] = 1; ovf = 0; }
         }
         slab_dma(W1, 0);
         f32x16 acc[2][NTW];
@@ -448,6 +474,7 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
                                    SC::SCALED ? relu_bits(acc[mt][nt][4 * g4 + 2]) * u : relu_bits(acc[mt][nt][4 * g4 + 2]), SC::SCALED ? relu_bits(acc[mt][nt][4 * g4 + 3]) * u : relu_bits(acc[mt][nt][4 * g4 + 3]));
                     }
             }
+            if (SC::SCALED && ovf) { sovf[fpar] = 1; ovf = 0; }
         }
         // ---------------- layer 2 (stride 2): 4 output parities, oh = 2 ih - 1 + kh (the tap order of ConvT2Addr, mfma_pipe.h) ---------------
         float* Y = a.y2 + (size_t)img * (32 * 32 * 64);
@@ -471,6 +498,7 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
                 tap(T, pb, T < 17 ? W2 + (size_t)l2_wt(npar, nt_) * (DA3_SLAB / 16) : nullptr);
             }
             if (live) {
+                const bool ibad = SC::SCALED && sovf[fpar] != 0;
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     float4* yp = reinterpret_cast<float4*>(Y) + (size_t)par * 4096 + ((2 * NTW * w + 2 * nt) * 16 + j) * 2 + g;
@@ -482,6 +510,7 @@ __global__ void __launch_bounds__(512 / NTW, 1) k_dec_a_b3(const DecAArgs a) {
                             v.x = relu_bits(acc[mt][nt][4 * g4 + 0]); v.y = relu_bits(acc[mt][nt][4 * g4 + 1]);
                             v.z = relu_bits(acc[mt][nt][4 * g4 + 2]); v.w = relu_bits(acc[mt][nt][4 * g4 + 3]);
                             if (SC::SCALED) { v.x *= a.w2s_inv; v.y *= a.w2s_inv; v.z *= a.w2s_inv; v.w *= a.w2s_inv; }
+                            if (SC::SCALED && ibad) v.x = v.y = v.z = v.w = __builtin_inff();      // x4 or y1 did not fit fp16: the image is poisoned (k_dec_b_b3 turns it into a NaN sum)
                             yp[(mt * 4 + g4) * 512] = v;
                         }
                 }
@@ -623,9 +652,11 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
     constexpr bool RES = DbbL<SC>::RES;
     if (RES) { slab_dma(0, 0); slab_dma(1, 1); slab_dma(2, 2); slab_dma(3, 3); }      // resident weights: no per-step copies, no per-step barriers
     else slab_dma(0, 0);
+    uint32_t ovf = 0;                                    // fp16 split: something this thread staged for the current image did not fit fp16
     auto put_planes = [&](unsigned char* px, int c, const float v0, const float v1, const float v2, const float v3) {
         uint32_t pa_[NPL], pb_[NPL];
         SC::split_pk(v0, v1, pa_); SC::split_pk(v2, v3, pb_);
+        ovf |= SC::overflow(pa_[0]) | SC::overflow(pb_[0]);
 #pragma unroll
         for (int p = 0; p < NPL; ++p) *reinterpret_cast<uint2*>(px + p * 128 + c * 2) = make_uint2(pa_[p], pb_[p]);
     };
@@ -789,11 +820,20 @@ __global__ void __launch_bounds__(512, 1) k_dec_b_b3(const DecBArgs a) {
         float v = part;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (SC::SCALED) {                                 // an input of this image did not fit fp16 (or arrived poisoned): the sum is NaN, never a finite wrong number
+            if (__any((int)(ovf != 0))) v = __builtin_nanf("");
+            ovf = 0;
+        }
         if (lane == 0) sred[nimgs & 1][w] = v;
         __syncthreads();
-        if (tid == 0) {
+        {
             const float* q = sred[nimgs & 1];
-            a.val[mg] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+            const float tot = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+            if (tid == 0) a.val[mg] = tot;
+            if (SC::SCALED && po && tot != tot) {           // a poisoned image that is also STORED (the D1 pass, efe_decoder): the stored pixels say so too
+#pragma unroll
+                for (int i = 0; i < 4096 / NTHR; ++i) po[i * NTHR + tid] = tot;
+            }
         }
         img = nimg;
     }

@@ -1462,6 +1462,36 @@ def test_split_operands_large_launches_vs_oracle(models_b3, weights_cache):
 
 
 @pytest.mark.parametrize('opt', SPLITS)
+def test_split_operands_launch_groups_rows_and_masks_change_nothing(models, opt):
+    """inside ONE split mode results are a function of the noise keys alone as long as every launch group stays on the persistent split
+    kernels (> 128 images): decoder launch groups of 360 / 240 images instead of one of 720, a global row offset, and a liveness mask (live rows
+    bit-identical; k_dec_a_b3 / k_dec_b_b3 skip dead images, the persistent image loop walks on to the next live one)"""
+    from daimc_amd.model import Rows
+    m = models(1234, 1.15, 12)
+    M, S = 60, 4                                        # 720 decoder images per call
+    s0 = torch.from_numpy(PX.uniform_fill(2, (M, 10), 91, -1, 1)).to(m.device)
+    pi0 = torch.from_numpy(np.eye(4, dtype=np.float32)[np.arange(M) % 4]).to(m.device)
+    try:
+        m.set_option(opt, 1)
+        ref = m.calculate_G(s0, pi0, samples=S, stage=4)
+        for chunk in (360, 240):             # (720 = 2 x 360 = 3 x 240: every group stays above the 128-image small-launch threshold)
+            m.set_option('dec_chunk', chunk)
+            got = m.calculate_G(s0, pi0, samples=S, stage=4)
+            assert all(torch.equal(a_, b_) for a_, b_ in zip((got[0], got[2], got[4]), (ref[0], ref[2], ref[4]))), chunk
+        m.set_option('dec_chunk', 32768)
+        # rows 8 .. 59 evaluated alone at their global offset
+        part = m.calculate_G(s0[8:], pi0[8:], samples=S, stage=4, row_offset=8)
+        assert torch.equal(part[0], ref[0][8:]) and torch.equal(part[4], ref[4][8:])
+        alive = torch.ones(M // 4, dtype=torch.uint8, device=m.device); alive[[0, 3, 4, 14]] = 0
+        out = m.calculate_G(s0, pi0, samples=S, stage=4, rows=Rows(mask=alive, rows_per_entry=4))
+        rows = alive.bool().repeat_interleave(4)
+        assert torch.equal(out[0][rows], ref[0][rows]) and torch.equal(out[4][rows], ref[4][rows])
+    finally:
+        m.set_option('dec_chunk', 32768)
+        m.set_option(opt, 0)
+
+
+@pytest.mark.parametrize('opt', SPLITS)
 def test_split_operands_vs_fp32_path_and_oracle_on_many_rows(models, weights_cache, opt):
     """1100 decoder rows (several 64-row tiles + a ragged tail, every feature group): the experiment against the fp32 kernels (same masks,
     images within the sigmoid tolerance) and against the oracle; and it really is another kernel (not bit-identical); switching from one
@@ -1506,6 +1536,27 @@ def test_fp16_split_weight_scale_follows_the_weights(models, weights_cache):
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=4e-6)
     base = models(1234, 1.15, 5)
     np.testing.assert_allclose(ref, c(base.model_down.decoder(s, stage=2, pass_=PX.PASS_D1)), rtol=1e-5, atol=4e-6)     # (the rescaled network IS the same function)
+
+
+def test_fp16_split_overflow_is_loud(weights_cache):
+    """the stated limit of mfma_f16x2: an activation beyond fp16's range (65 504) cannot be split -- the affected images come out NaN
+    (hi = inf, lo = x - inf), never as finite wrong numbers; the exact fp32 kernels and the bf16 split (fp32's exponent range) are unaffected"""
+    import daimc_amd
+    w = dict(weights_cache(1234, 1.15))
+    w['down.po_net.9.weight'] = w['down.po_net.9.weight'] * np.float32(1.0e6)       # x4 = relu(W h + b) * 2 reaches ~1e6
+    w['down.po_net.13.weight'] = w['down.po_net.13.weight'] * np.float32(1.0e-6)
+    m = daimc_amd.ActiveInferenceModel(10, 4, 0.0, 1.0, 1.0, device='cuda:0', seed=5, init_weights=False)
+    m.load_flat_weights(w)
+    s = PX.uniform_fill(13, (300, 10), 401, -1.5, 1.5)
+    ref = c(m.model_down.decoder(s, stage=2, pass_=PX.PASS_D1))
+    assert np.isfinite(ref).all()
+    m.set_option('mfma_bf16x3', 1)
+    np.testing.assert_allclose(c(m.model_down.decoder(s, stage=2, pass_=PX.PASS_D1)), ref, rtol=1e-5, atol=4e-6)
+    m.set_option('mfma_f16x2', 1)
+    got = c(m.model_down.decoder(s, stage=2, pass_=PX.PASS_D1))
+    bad = ~np.isfinite(got).all(axis=(1, 2, 3))
+    assert bad.any()                                                   # some image saw an activation above 65 504 ...
+    np.testing.assert_allclose(got[~bad], ref[~bad], rtol=1e-5, atol=4e-6)      # ... and every image that did not is still right
 
 
 def test_split_operands_are_off_by_default_and_refused_on_other_geometries(models):
