@@ -118,6 +118,6 @@ def load():
     lib.efe_mcts_expand.argtypes = [p, tp, p, p, p, f32p, f32p, p]; lib.efe_mcts_expand.restype = i
     lib.efe_mcts_backprop.argtypes = [p, tp, p, p, p, p, p, f32p, i, f32p, i, f32p, p, p]; lib.efe_mcts_backprop.restype = i
     lib.efe_mcts_stop.argtypes = [p, tp, p, p, i, C.c_float, p, p]; lib.efe_mcts_stop.restype = i
-    lib.efe_mcts_step.argtypes = [p, tp, p, p, f32p, i, f32p, f32p, p, p, p, i, C.c_float, p, C.c_float, i, i, p, p, p, p, f32p, f32p, p]; lib.efe_mcts_step.restype = i
+    lib.efe_mcts_step.argtypes = [p, tp, p, p, f32p, i, f32p, f32p, p, p, p, i, C.c_float, p, C.c_float, i, i, p, p, p, p, f32p, f32p, p, f32p, f32p, p]; lib.efe_mcts_step.restype = i
     _lib = lib
     return lib

@@ -1185,16 +1185,17 @@ int efe_mcts_backprop(efe_ctx* ctx, const efe_mcts_tree* tree, const int32_t* pa
 int efe_mcts_step(efe_ctx* ctx, const efe_mcts_tree* tree, const int32_t* prev_path_act, const int32_t* prev_path_len, const float* sims, int n_sims,
                   const float* q0, float* prev_g_out, uint8_t* prev_active_out, uint8_t* active, int32_t* stop_at, int repeat, float threshold,
                   int32_t* n_active, float C, int use_prior, int max_depth, int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf,
-                  float* leaf_s, float* leaf_s_rep, void* stream) {
+                  float* leaf_s, float* leaf_s_rep, int32_t* prev_n_nodes, const float* prev_G, const float* prev_ps_next, void* stream) {
     EFE_LOCK(ctx);
     MctsTree t;
     if (mcts_tree(ctx, tree, t)) return 1;
+    const int n_exp = (prev_n_nodes != nullptr) + (prev_G != nullptr) + (prev_ps_next != nullptr);
     if (!active || !stop_at || !n_active || !path_nodes || !path_act || !path_len || !leaf || !leaf_s || !leaf_s_rep || max_depth < 1 ||
-        (prev_path_len && (!prev_path_act || !sims || n_sims < 1 || !q0 || !prev_g_out || !prev_active_out)))
+        (prev_path_len && (!prev_path_act || !sims || n_sims < 1 || !q0 || !prev_g_out || !prev_active_out)) || (n_exp != 0 && n_exp != 3))
         return ctx->fail("efe_mcts_step: bad arguments");
     HIPCHK(hipSetDevice(ctx->device));
     MctsStepArgs a{prev_path_act, prev_path_len, sims, n_sims, q0, prev_g_out, prev_active_out, active, stop_at, repeat, threshold, n_active,
-                   C, use_prior, max_depth, path_nodes, path_act, path_len, leaf, leaf_s, leaf_s_rep};
+                   C, use_prior, max_depth, path_nodes, path_act, path_len, leaf, leaf_s, leaf_s_rep, prev_n_nodes, prev_G, prev_ps_next};
     launch_mcts_step(t, a, (hipStream_t)stream);
     return finish(ctx);
 }

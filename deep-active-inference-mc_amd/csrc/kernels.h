@@ -215,6 +215,8 @@ struct MctsStepArgs {
     // selection
     float C; int use_prior, max_depth;
     int32_t *path_nodes, *path_act, *path_len, *leaf; float *leaf_s, *leaf_s_rep;
+    // expansion bookkeeping of the previous iteration's leaf (exp_n_nodes == nullptr: done by the caller with efe_mcts_expand)
+    int32_t* exp_n_nodes = nullptr; const float* exp_G = nullptr; const float* exp_ps_next = nullptr;
 };
 void launch_mcts_step(const MctsTree& t, const MctsStepArgs& a, hipStream_t st);
 

@@ -76,10 +76,9 @@ __global__ void k_mcts_select(const MctsTree t, const uint8_t* active, float C, 
 }
 
 // Node.expand bookkeeping (mcts.py:64-86): W -= G, N += 1, pi_dim children with the predicted states
-__global__ void k_mcts_expand(const MctsTree t, int32_t* n_nodes, const int32_t* nodes, const uint8_t* mask, const float* G,
-                              const float* ps_next) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= t.E || !mask[e]) return;
+__device__ __forceinline__ void mcts_expand_one(const MctsTree& t, int e, int32_t* n_nodes, const int32_t* nodes, const uint8_t* mask, const float* G,
+                                                const float* ps_next) {
+    if (!mask[e]) return;
     const int A = t.A, n = nodes[e];
     const size_t o = ((size_t)e * t.cap + n) * A;
     const int base = n_nodes[e];
@@ -92,6 +91,12 @@ __global__ void k_mcts_expand(const MctsTree t, int32_t* n_nodes, const int32_t*
         for (int k = 0; k < t.s_dim; ++k) sd[k] = ss[k];
     }
     n_nodes[e] = base + A;
+}
+__global__ void k_mcts_expand(const MctsTree t, int32_t* n_nodes, const int32_t* nodes, const uint8_t* mask, const float* G,
+                              const float* ps_next) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= t.E) return;
+    mcts_expand_one(t, e, n_nodes, nodes, mask, G, ps_next);
 }
 
 // after the simulations: habit prior of the leaf, g = mean of the simulated G (left to right), back-propagation along the
@@ -157,12 +162,13 @@ __global__ void k_mcts_stop(const MctsTree t, uint8_t* active, int32_t* stop_at,
     if (e >= t.E) return;
     mcts_stop_one(t, e, active, stop_at, repeat, threshold, n_active);
 }
-// One launch for the tree work between two iterations' engine calls: back-propagation of the previous iteration (skipped for the
-// first), early-stop test, selection of the next leaf -- the three one-thread-per-episode kernels above, in that order, per episode.
+// One launch for the tree work between two iterations' engine calls: expansion bookkeeping and back-propagation of the previous iteration
+// (skipped for the first), early-stop test, selection of the next leaf -- the three one-thread-per-episode kernels above, in that order, per episode.
 // n_active is a zero-initialised word of its own per iteration (no memset launch).
 __global__ void k_mcts_step(const MctsTree t, MctsStepArgs a) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= t.E) return;
+    if (a.exp_n_nodes) mcts_expand_one(t, e, a.exp_n_nodes, a.leaf, a.active, a.exp_G, a.exp_ps_next);       // the previous iteration's leaf (a.leaf is rewritten by the selection below)
     if (a.prev_path_len)
         mcts_backprop_one(t, e, a.path_nodes, a.prev_path_act, a.prev_path_len, a.leaf, a.active, a.sims, a.n_sims, a.q0, a.max_depth, a.prev_g_out,
                           a.prev_active_out);

@@ -346,8 +346,9 @@ class BatchedMCTS:
         self._ids = (idx.to(torch.int32).contiguous(), ids.tolist(), idx)
         self._rows_cache = {}
 
-    def _expand(self, nodes, mask, states_rep, stage=None, use_mask=True):
-        """ONE engine call over E x pi_dim rows (Node.expand, mcts.py:64-86); tree bookkeeping only where mask[e]"""
+    def _expand(self, nodes, mask, states_rep, stage=None, use_mask=True, defer=False):
+        """ONE engine call over E x pi_dim rows (Node.expand, mcts.py:64-86); tree bookkeeping only where mask[e].  defer: the bookkeeping
+        (W -= G, N += 1, children, their states) is left to the NEXT efe_mcts_step launch -> returns the (G, ps_next) tensors it needs"""
         m, p_, A = self.model, self._p, self.pi_dim
         ro = self.ep0 * A
         rows = self._rows(mask if use_mask else None, A)
@@ -366,7 +367,10 @@ class BatchedMCTS:
             self.ps_full.view(self.E, A, -1).index_copy_(0, idx, ps_next.view(idx.numel(), A, -1))
             G, ps_next = self.G_full, self.ps_full
         G, ps_next = G.contiguous(), ps_next.contiguous()
+        if defer:
+            return G, ps_next
         self._call(m._engine.lib.efe_mcts_expand, p_(self.n_nodes), p_(nodes), p_(mask), p_(G), p_(ps_next))
+        return None
 
     def _simulate(self, model, mask, stage_of, direct=False):
         """the iteration's simulations from the selected leaves (mcts.py:186-189) -> self.sims, self.q0 (direct: with one simulation per
@@ -464,13 +468,15 @@ class BatchedMCTS:
         pending = None                                   # (iteration, sims, q0) whose back-propagation is still to run
         for repeat in range(p.repeats):
             if pending is None:
-                prev = (None, None, None, 1, None, None, None)
+                prev, pexp = (None, None, None, 1, None, None, None), (None, None, None)
             else:
-                pr, sims_t, q0_t = pending
+                pr, sims_t, q0_t, G_t, ps_t = pending
                 prev = (p_(self.H_act[pr]), p_(self.H_len[pr]), p_(sims_t), int(p.simulation_repeats), p_(q0_t), p_(self.H_g[pr]), p_(self.H_active[pr]))
+                pexp = (p_(self.n_nodes), p_(G_t), p_(ps_t))          # the previous leaf's expansion bookkeeping rides in the same launch
             self._call(lib.efe_mcts_step, prev[0], prev[1], prev[2], prev[3], prev[4], prev[5], prev[6], p_(active), p_(self.stop_at), repeat,
                        float(p.threshold), p_(self.n_active_it[repeat:]), float(p.C), 1 if p.using_prior_for_exploration else 0, self.max_depth,
-                       p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep))
+                       p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep),
+                       pexp[0], pexp[1], pexp[2])
             pending = None
             if can_stop and E == 1:                       # one episode: stop the loop in the iteration the episode stops in
                 if int(self.n_active_it[repeat].item()) == 0:
@@ -506,15 +512,16 @@ class BatchedMCTS:
                     self.sim_stream.wait_event(self.ev_sel)              # leaf_s is ready; the previous back-propagation has read sims / q0
                     self._simulate(self.sim_model, active if skip else None, lambda r: st_exp + 1 + r, direct=True)
                     self.ev_sim.record(self.sim_stream)
-                self._expand(self.leaf, active, self.leaf_rep, stage=st_exp, use_mask=skip)
+                exp_out = self._expand(self.leaf, active, self.leaf_rep, stage=st_exp, use_mask=skip, defer=True)
                 cur.wait_event(self.ev_sim)
             else:
-                self._expand(self.leaf, active, self.leaf_rep, stage=st_exp, use_mask=skip)
+                exp_out = self._expand(self.leaf, active, self.leaf_rep, stage=st_exp, use_mask=skip, defer=True)
                 self._simulate(m, active if skip else None, lambda r: st_exp + 1 + r, direct=True)
-            pending = (repeat,) + (self._sim_out if self._sim_out is not None else (self.sims, self.q0))
+            pending = (repeat,) + (self._sim_out if self._sim_out is not None else (self.sims, self.q0)) + exp_out
             n_iter += 1
         if pending is not None:
-            pr, sims_t, q0_t = pending
+            pr, sims_t, q0_t, G_t, ps_t = pending
+            self._call(lib.efe_mcts_expand, p_(self.n_nodes), p_(self.leaf), p_(active), p_(G_t), p_(ps_t))
             self._call(lib.efe_mcts_backprop, p_(self.path_nodes), p_(self.H_act[pr]), p_(self.H_len[pr]), p_(self.leaf), p_(active),
                        p_(sims_t), int(p.simulation_repeats), p_(q0_t), self.max_depth, p_(self.H_g[pr]), p_(self.H_active[pr]))
         # read the history back once, then plain Python lists on the host: per-element torch indexing here cost ~30 ms per 64-episode

@@ -221,13 +221,14 @@ int efe_env_render(efe_ctx*, const float* state, const float* last_r, const uint
  *   efe_mcts_stop    : early stop (:130-131, 176) active[e] &= !(max(N0/sum) - mean(N0/sum) > threshold), stop_at[e] = repeat
  *                      for the episodes that stop now, *n_active = episodes still active */
 typedef struct efe_mcts_tree { float* W; float* N; float* Qpi; int32_t* child; float* S; int32_t E, cap, A, s_dim; } efe_mcts_tree;
-/* efe_mcts_step (ABI 4): the tree work between two iterations' engine calls as ONE launch, per episode in this order: efe_mcts_backprop of the
- * PREVIOUS iteration (prev_path_len == NULL: none; path_nodes / leaf must still hold that iteration's selection), efe_mcts_stop, efe_mcts_select.
- * n_active: a zero-initialised word of its own per iteration (no memset is issued). */
+/* efe_mcts_step (ABI 4): the tree work between two iterations' engine calls as ONE launch, per episode in this order: efe_mcts_expand of the
+ * PREVIOUS iteration's leaf (ABI 6: prev_n_nodes / prev_G / prev_ps_next, all three or none -- NULL: the caller has run efe_mcts_expand itself),
+ * efe_mcts_backprop of the PREVIOUS iteration (prev_path_len == NULL: none; path_nodes / leaf must still hold that iteration's selection),
+ * efe_mcts_stop, efe_mcts_select.  n_active: a zero-initialised word of its own per iteration (no memset is issued). */
 int efe_mcts_step(efe_ctx*, const efe_mcts_tree* tree, const int32_t* prev_path_act, const int32_t* prev_path_len, const float* sims, int n_sims,
                   const float* q0, float* prev_g_out, uint8_t* prev_active_out, uint8_t* active, int32_t* stop_at, int repeat, float threshold,
                   int32_t* n_active, float C, int use_prior, int max_depth, int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf,
-                  float* leaf_s, float* leaf_s_rep, void* stream);
+                  float* leaf_s, float* leaf_s_rep, int32_t* prev_n_nodes, const float* prev_G, const float* prev_ps_next, void* stream);
 int efe_mcts_select(efe_ctx*, const efe_mcts_tree* tree, const uint8_t* active, float C, int use_prior, int max_depth,
                     int32_t* path_nodes, int32_t* path_act, int32_t* path_len, int32_t* leaf, float* leaf_s, float* leaf_s_rep,
                     void* stream);

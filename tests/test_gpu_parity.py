@@ -968,8 +968,9 @@ def test_mcts_tree_kernels_vs_host_torch(models):
 
 
 def test_mcts_step_equals_backprop_stop_select(models):
-    """efe_mcts_step (ONE launch between two iterations' engine calls) == efe_mcts_backprop of the previous iteration, then efe_mcts_stop,
-    then efe_mcts_select, on random trees: same tree statistics, history row, active set, stop iterations, active count and selection"""
+    """efe_mcts_step (ONE launch between two iterations' engine calls) == efe_mcts_expand of the previous iteration's leaf, efe_mcts_backprop of
+    the previous iteration, then efe_mcts_stop, then efe_mcts_select, on random trees: same tree statistics, children, node states and counts,
+    history row, active set, stop iterations, active count and selection"""
     import ctypes as C
     from daimc_amd import _lib
     m = models(1234, 1.15, 21)
@@ -986,17 +987,19 @@ def test_mcts_step_equals_backprop_stop_select(models):
         N[:, 0] = torch.randint(1, 6, (E, A), generator=gg).float()
         Qpi = torch.rand(E, cap, A, generator=gg)
         child = torch.full((E, cap, A), -1, dtype=torch.int32)
+        nn_ = torch.zeros(E, dtype=torch.int32)
         for ep in range(E):
             nxt = 1
             for node in range(cap):
                 if node >= nxt:
                     break
-                if (node == 0 or torch.rand(1, generator=gg).item() < 0.6) and nxt + A <= cap:
+                if (node == 0 or torch.rand(1, generator=gg).item() < 0.6) and nxt + A <= cap - A:      # (room for one more expansion)
                     child[ep, node] = torch.arange(nxt, nxt + A, dtype=torch.int32)
                     nxt += A
+            nn_[ep] = nxt
         S = torch.randn(E, cap, sd, generator=gg)
         active = (torch.rand(E, generator=gg) < 0.85).to(torch.uint8)
-        t = [x.to(dev).contiguous() for x in (W, N, Qpi, child, S, active)]
+        t = [x.to(dev).contiguous() for x in (W, N, Qpi, child, S, active, nn_)]
         tree = _lib.EfeMctsTree(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), E, cap, A, sd)
         bufs = dict(pn=torch.zeros(E, depth, dtype=torch.int32, device=dev), pa=torch.zeros(2, E, depth, dtype=torch.int32, device=dev),
                     pl=torch.zeros(2, E, dtype=torch.int32, device=dev), leaf=torch.zeros(E, dtype=torch.int32, device=dev),
@@ -1005,6 +1008,8 @@ def test_mcts_step_equals_backprop_stop_select(models):
         return t, tree, bufs
     sims = torch.randn(R, E, generator=g).to(dev)
     q0 = torch.rand(E, A, generator=g).to(dev)
+    Gx = torch.randn(E * A, generator=g).to(dev)                    # the previous iteration's expansion results
+    psx = torch.randn(E * A, sd, generator=g).to(dev)
     out = []
     for fused in (False, True):
         t, tree, b = fresh()
@@ -1012,13 +1017,14 @@ def test_mcts_step_equals_backprop_stop_select(models):
         # iteration 0: selection (no previous iteration)
         if fused:
             e.check(e.lib.efe_mcts_step(e.ctx, C.byref(tree), None, None, None, 1, None, None, None, p(act), p(b['stop']), 0, 0.25, p(b['nact'][0:]),
-                                        1.5, 1, depth, p(b['pn']), p(b['pa'][0]), p(b['pl'][0]), p(b['leaf']), p(b['ls']), p(b['lr']), e.stream()))
+                                        1.5, 1, depth, p(b['pn']), p(b['pa'][0]), p(b['pl'][0]), p(b['leaf']), p(b['ls']), p(b['lr']), None, None, None, e.stream()))
             e.check(e.lib.efe_mcts_step(e.ctx, C.byref(tree), p(b['pa'][0]), p(b['pl'][0]), p(sims), R, p(q0), p(b['g']), p(b['hact']), p(act), p(b['stop']),
                                         1, 0.25, p(b['nact'][1:]), 1.5, 1, depth, p(b['pn']), p(b['pa'][1]), p(b['pl'][1]), p(b['leaf']), p(b['ls']), p(b['lr']),
-                                        e.stream()))
+                                        p(t[6]), p(Gx), p(psx), e.stream()))
         else:
             for it in (0, 1):
                 if it == 1:
+                    e.check(e.lib.efe_mcts_expand(e.ctx, C.byref(tree), p(t[6]), p(b['leaf']), p(act), p(Gx), p(psx), e.stream()))
                     e.check(e.lib.efe_mcts_backprop(e.ctx, C.byref(tree), p(b['pn']), p(b['pa'][0]), p(b['pl'][0]), p(b['leaf']), p(act), p(sims), R, p(q0),
                                                     depth, p(b['g']), p(b['hact']), e.stream()))
                 na = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -1027,7 +1033,7 @@ def test_mcts_step_equals_backprop_stop_select(models):
                 e.check(e.lib.efe_mcts_select(e.ctx, C.byref(tree), p(act), 1.5, 1, depth, p(b['pn']), p(b['pa'][it]), p(b['pl'][it]), p(b['leaf']),
                                               p(b['ls']), p(b['lr']), e.stream()))
         torch.cuda.synchronize()
-        out.append([x.cpu() for x in t[:3]] + [act.cpu()] + [b[k].cpu() for k in ('pn', 'pa', 'pl', 'leaf', 'ls', 'lr', 'stop', 'nact', 'g', 'hact')])
+        out.append([x.cpu() for x in t[:3]] + [act.cpu()] + [b[k].cpu() for k in ('pn', 'pa', 'pl', 'leaf', 'ls', 'lr', 'stop', 'nact', 'g', 'hact')] + [t[3].cpu(), t[4].cpu(), t[6].cpu()])
     for x, y in zip(*out):
         assert torch.equal(x, y) or (torch.isnan(x) == torch.isnan(y)).all() and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y))
     assert int(out[0][11][1]) < int(out[0][11][0]) or int(out[0][11][0]) < E        # the stop test did something
