@@ -1456,6 +1456,10 @@ def test_split_operands_every_decoder_fixture_at_unchanged_tolerances(golden, mo
         test_simulate_vs_golden(golden, models_b3, name)
     for name in ('mcts_deep_s10_thr',):
         test_planners_at_benchmark_depth_vs_reference(golden, models_b3, name)
+    # ... and the reference planner's own default call (300 repeats, use_means: 480-image expansions of the 40-episode batch) and two
+    # simulations per iteration -- every path, stop and visit count as captured
+    for name in ('mcts_defaults', 'mcts_simrep2_s10'):
+        test_planner_at_the_reference_defaults_and_with_two_simulations(golden, models_b3, name)
 
 
 def test_split_operands_large_launches_vs_oracle(models_b3, weights_cache):
