@@ -463,7 +463,10 @@ class BatchedMCTS:
         # stop, selection -- per episode in the reference's order (mcts.py:176-191).  The active count of iteration r lands in its own
         # zero-initialised word (no memset launch); the last iteration's back-propagation follows the loop.
         self.n_active_it.zero_()
-        lagged = bool(getattr(p, 'lagged_check', True)) and E > 1
+        # (one episode too, since round 6: reading the active count in every iteration -- a device synchronisation -- cost 12 % of a
+        # one-episode iteration, the lagged snapshot 2 %; the price is up to LAG masked iterations behind the stop.  lagged_single = False:
+        # the immediate read)
+        lagged = bool(getattr(p, 'lagged_check', True)) and (E > 1 or bool(getattr(p, 'lagged_single', True)))
         LAG = 2
         pending = None                                   # (iteration, sims, q0) whose back-propagation is still to run
         for repeat in range(p.repeats):
@@ -478,7 +481,7 @@ class BatchedMCTS:
                        p_(self.path_nodes), p_(self.H_act[repeat]), p_(self.H_len[repeat]), p_(self.leaf), p_(self.leaf_s), p_(self.leaf_rep),
                        pexp[0], pexp[1], pexp[2])
             pending = None
-            if can_stop and E == 1:                       # one episode: stop the loop in the iteration the episode stops in
+            if can_stop and E == 1 and not lagged:        # one episode: stop the loop in the iteration the episode stops in
                 if int(self.n_active_it[repeat].item()) == 0:
                     break
             elif can_stop and lagged:
