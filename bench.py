@@ -191,6 +191,22 @@ def committed_traffic(kernel='k_dec_b', geometry='dsprites'):
     return None, None
 
 
+def committed_split_traffic(kernel_prefix, opt):
+    """HBM bytes per launch of a persistent split-operand kernel from the newest committed profile of that mode (profiles/rN_vM_b3_* for
+    mfma_bf16x3, rN_vM_f16_* for mfma_f16x2; the profiled launch is the headline's 19 200 images).  -> (bytes, file name) or (None, None)"""
+    tag = {'mfma_bf16x3': 'b3', 'mfma_f16x2': 'f16'}[opt]
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, 'profiles', f'r*_{tag}_rocprof_summary.txt'))
+                    if re.match(rf'^r\d+_v\d+_{tag}_rocprof_summary\.txt$', os.path.basename(f))), key=natural_key)
+    for best in reversed(files):
+        m_ = re.search(r'== HBM traffic \(JSON\) ==\n(\{.*\})', open(best).read())
+        if not m_:
+            continue
+        for k, tj in json.loads(m_.group(1)).items():
+            if k.startswith(kernel_prefix) and 'hbm_read_bytes_per_launch' in tj:
+                return tj['hbm_read_bytes_per_launch'] + tj['hbm_write_bytes_per_launch'], os.path.basename(best)
+    return None, None
+
+
 def timed_regions(step, steps, k0, rk, min_total_s=10.0, max_regions=60):
     """time EXACTLY `steps` steps between sync() pairs (barrier + device synchronise on both sides); repeat the region until
     min_total_s of measured time.  The stop decision uses the MAX-over-ranks time of every region (one scalar all_reduce outside
@@ -891,6 +907,12 @@ def main():
                                   'avg_launch_ms': dom3['avg_launch_ms'], 'traffic': None},
                      'speedup_vs_headline': (R * a.steps / dt3) / value if rank == 0 else None}
                 x['roofline'].update(clk3.report(dom3['frac_of_16bit_peak_over_products']))
+                if n_img == 19200:                       # the committed PMC profile of this mode is a 19 200-image launch
+                    bpl, src = committed_split_traffic(dom3['name'].split(' ')[0], opt)
+                    if bpl is not None:
+                        x['roofline']['traffic'] = bpl
+                        x['roofline']['traffic_unit'] = 'bytes per launch'
+                        x['roofline']['traffic_from_profile'] = {'file': 'profiles/' + src, 'how': 'rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE in separate passes, mean per dispatch'}
                 splits[opt] = x
             except Exception as ex:          # an experiment must never cost the line its headline
                 splits[opt] = {'error': repr(ex)[:300]}

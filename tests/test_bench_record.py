@@ -59,3 +59,16 @@ def test_rank_count_is_labelled_by_backend():
         rk = bench.Ranks(FakeDist(be), 8, 0, torch.device('cpu'), be)
         info = rk.info()
         assert info == {key: 8, 'backend': be}
+
+
+def test_split_mode_traffic_comes_from_that_modes_profile():
+    """the experiment legs' roofline.traffic: bytes per launch of the persistent split kernel from the newest committed profile of the SAME mode"""
+    import bench
+    for opt, tag in (('mfma_bf16x3', 'b3'), ('mfma_f16x2', 'f16')):
+        b, src = bench.committed_split_traffic('k_dec_b_b3', opt)
+        assert re.fullmatch(rf'r\d+_v\d+_{tag}_rocprof_summary\.txt', src), src
+        # ConvT3 reads y2 (19 200 x 256 KiB = 5.03 GB) once -- halo rows mostly from L2 -- and writes sums + every third image
+        assert 5.0e9 <= b <= 7.0e9, b
+        a_, _ = bench.committed_split_traffic('k_dec_a_b3', opt)
+        assert 6.0e9 <= a_ <= 7.5e9, a_              # x4 in (1.26 GB) + weights + y2 out (5.03 GB)
+    assert bench.committed_split_traffic('k_nothing', 'mfma_f16x2') == (None, None)
